@@ -1,0 +1,182 @@
+/*
+ * mcm.h — C ABI of libmcm_hip.so, the MI355X (gfx950) Maximum-Concept-Matching scorer.
+ *
+ * The reference (deeplearning-wisc/MCM) has no FFI: its boundary is the duck-typed
+ * Python contract of utils/detection_util.py:209-249 (`get_ood_scores_clip`) over a
+ * `net` exposing `get_image_features` / `get_text_features` (HF transformers
+ * modeling_clip.py:683-753).  This header is the C boundary a maintainer binds
+ * *underneath* that contract (ctypes stub: INTEGRATION.md).  Each entry point names the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross the boundary;
+ *   - every function returns 0 on success or a negative MCM_E* code and never throws;
+ *     mcm_last_error(h) returns a human-readable message for the last failure;
+ *   - `*_dev` pointers are device (HBM) addresses, `*_host` pointers are host addresses;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all compute
+ *     entry points are asynchronous on it;
+ *   - no device allocation happens after mcm_create (workspace is sized from
+ *     cfg.max_batch / cfg.max_prompt_tokens), so calls are hipGraph-capturable;
+ *   - one handle is used from one host thread at a time (the reference is
+ *     single-threaded: utils/detection_util.py:219).
+ */
+#ifndef MCM_H_
+#define MCM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCM_ABI_VERSION 1
+
+/* error codes */
+#define MCM_OK 0
+#define MCM_EINVAL (-1)   /* bad argument (shape, size, NULL)                         */
+#define MCM_ENOMEM (-2)   /* hipMalloc failed                                         */
+#define MCM_EHIP (-3)     /* a HIP runtime call failed                                */
+#define MCM_ENOWEIGHT (-4)/* a required parameter was never set                       */
+#define MCM_ENAME (-5)    /* unknown parameter name                                   */
+#define MCM_ESHAPE (-6)   /* parameter shape does not match the config                */
+#define MCM_ERANGE (-7)   /* batch / prompt count / sequence exceeds the config       */
+
+/* arithmetic modes for the GEMM/attention operands (accumulation is always fp32,
+ * the residual stream, LayerNorm statistics, softmax and the whole scoring tail are
+ * always fp32). */
+#define MCM_PREC_BF16 0   /* bf16 MFMA operands  (v_mfma_f32_16x16x32_bf16)            */
+#define MCM_PREC_F32 1    /* exact fp32 MFMA     (v_mfma_f32_16x16x4_f32) — parity arm  */
+
+/* score kinds — the epilogues of utils/detection_util.py:233-248 */
+#define MCM_SCORE_MCM 0       /* -max_k softmax(cos/T)             (:236,:248) */
+#define MCM_SCORE_MAX_LOGIT 1 /* -max_k cos                        (:234,:248) */
+#define MCM_SCORE_ENERGY 2    /* -T*logsumexp(cos/T)               (:239)      */
+#define MCM_SCORE_ENTROPY 3   /* Shannon entropy of softmax(cos/T) (:243)      */
+#define MCM_SCORE_VAR 4       /* -var_k softmax(cos/T), ddof=0     (:246)      */
+
+typedef struct mcm_handle mcm_handle;
+
+/* Model geometry = the fields of transformers CLIPVisionConfig / CLIPTextConfig that
+ * the path reads (configuration_clip.py), plus workspace bounds. */
+typedef struct mcm_config {
+  int32_t abi_version;      /* must be MCM_ABI_VERSION                                */
+  int32_t device;           /* HIP device ordinal                                     */
+  int32_t precision;        /* MCM_PREC_*                                             */
+  /* vision tower (modeling_clip.py:138-218, 594-656) */
+  int32_t image_size;       /* 224                                                    */
+  int32_t patch_size;       /* 16 (B/16), 32 (B/32), 14 (L/14)                        */
+  int32_t v_width;          /* 768 / 1024                                             */
+  int32_t v_heads;          /* 12 / 16  (head_dim = width / heads must be 64)         */
+  int32_t v_layers;         /* 12 / 24                                                */
+  int32_t v_mlp;            /* 3072 / 4096                                            */
+  /* text tower (modeling_clip.py:221-256, 494-586) */
+  int32_t vocab_size;       /* 49408                                                  */
+  int32_t max_positions;    /* 77                                                     */
+  int32_t t_width;          /* 512 / 768                                              */
+  int32_t t_heads;          /* 8 / 12                                                 */
+  int32_t t_layers;         /* 12                                                     */
+  int32_t t_mlp;            /* 2048 / 3072                                            */
+  int32_t proj_dim;         /* 512 / 768  (visual_projection / text_projection rows)  */
+  float ln_eps;             /* 1e-5 (configuration_clip.py layer_norm_eps)            */
+  /* workspace bounds */
+  int32_t max_batch;        /* images per mcm_encode_image / mcm_score call           */
+  int32_t max_prompt_tokens;/* K*S per mcm_encode_text call                           */
+} mcm_config;
+
+int mcm_abi_version(void);
+
+/* Replaces CLIPModel.__init__ + .cuda() (utils/train_eval_util.py:23-24): allocates the
+ * parameter store and the activation workspace on cfg->device. */
+int mcm_create(const mcm_config* cfg, mcm_handle** out);
+void mcm_destroy(mcm_handle* h);
+const char* mcm_last_error(const mcm_handle* h); /* h may be NULL: last create error */
+
+/* Replaces load_state_dict / from_pretrained (utils/train_eval_util.py:23): copies one
+ * fp32 parameter, keyed by its HF state_dict name, host → device.
+ * The caller keeps ownership of host_ptr.  `shape`/`ndim` are checked against cfg. */
+int mcm_set_weight(mcm_handle* h, const char* hf_name, const float* host_ptr,
+                   const int64_t* shape, int32_t ndim);
+/* Verifies every parameter was set and builds the packed operand copies the kernels
+ * read (concatenated QKV, bf16 copies).  Must be called once before any encode. */
+int mcm_finalize_weights(mcm_handle* h);
+
+/* Replaces `net.get_text_features(input_ids, attention_mask).float()` followed by
+ * `/= norm` (utils/detection_util.py:229-231; modeling_clip.py:683-715).
+ * ids_host: int32 [K,S] row-major, each row BOS … EOS pad…; the pooled row is the
+ * first EOS (= argmax id, modeling_clip.py:561-581).  attention_mask is not needed:
+ * the mask is causal and pooling reads the first EOS.
+ * out_dev: fp32 [K, proj_dim], L2-normalised rows. */
+int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S,
+                    float* out_dev, void* stream);
+
+/* Replaces `net.get_image_features(pixel_values=images).float()` followed by `/= norm`
+ * (utils/detection_util.py:225-226; modeling_clip.py:719-753).
+ * pixels_dev: fp32 NCHW [B,3,image_size,image_size] contiguous, already normalised by
+ * the preprocess of utils/train_eval_util.py:27-33.
+ * out_dev: fp32 [B, proj_dim], L2-normalised rows. */
+int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev,
+                     void* stream);
+
+/* Replaces the scoring tail utils/detection_util.py:232-248 on already-normalised
+ * features: sim = img @ text.T, softmax(sim/T), reduction `kind` → scores_dev fp32 [B].
+ * Never materialises [B,K]. */
+int mcm_score_features(mcm_handle* h, const float* img_feat_dev, int32_t B,
+                       const float* text_feat_dev, int32_t K, float T, int32_t kind,
+                       float* scores_dev, void* stream);
+
+/* One batch of the whole hot loop body utils/detection_util.py:223-248:
+ * mcm_encode_image + mcm_score_features, text bank pre-encoded (hoisted out of the
+ * loop; the reference re-encodes it every batch with identical results). */
+int mcm_score(mcm_handle* h, const float* pixels_dev, int32_t B, const float* text_feat_dev,
+              int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
+
+/* ---- per-kernel timing (HIP events on the caller's stream) -------------------------
+ * When enabled, every kernel launch of the encode path is bracketed by a pair of
+ * pre-created hipEvents.  mcm_profile_read synchronises the stream, accumulates the
+ * elapsed times per kernel class and returns them; it resets the accumulators.
+ * Classes: see MCM_KC_*. */
+#define MCM_KC_PATCHIFY 0
+#define MCM_KC_GEMM 1
+#define MCM_KC_LAYERNORM 2
+#define MCM_KC_ATTENTION 3
+#define MCM_KC_POOL_PROJECT 4
+#define MCM_KC_SCORE 5
+#define MCM_KC_EMBED 6
+#define MCM_KC_COUNT 7
+int mcm_profile_enable(mcm_handle* h, int32_t on);
+/* ms_out[MCM_KC_COUNT], launches_out[MCM_KC_COUNT], flops_out[MCM_KC_COUNT] (algorithmic
+ * FLOP issued by that class since the last read; GEMM counts 2*M*N*K of the *logical*
+ * problem, not the padded tile grid). */
+int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, double* flops_out);
+
+/* ---- operator-level entry points (same kernels the towers launch; used by the parity
+ * tests to pin each kernel against the oracle, and usable as building blocks) --------
+ * All tensors row-major.  `prec` = MCM_PREC_*: in BF16 mode activations/weights that
+ * feed MFMA are bf16 (uint16 storage), in F32 mode they are fp32. */
+
+/* y[M,N] = x[M,K] · w[N,K]^T + bias[N]  with epilogue `epi`:
+ *   0: store (+bias)                out dtype = operand dtype
+ *   1: QuickGELU(acc+bias)          out dtype = operand dtype   (activations.py:117-123)
+ *   2: resid[M,N] (fp32) += acc+bias   in place; `y` ignored
+ * M,K arbitrary ≥1 with K % 32 == 0 (bf16) or K % 4 == 0 (fp32); N % 16 == 0; rows of x
+ * must be readable up to M rounded up to 128 (workspace rule: pad rows exist). */
+int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev,
+                  const float* bias_dev, void* y_dev, float* resid_dev, int32_t M, int32_t N,
+                  int32_t K, int32_t epi, void* stream);
+/* LayerNorm over the last dim (modeling_clip.py:370,379,605,608): x fp32 [M,D] →
+ * y (operand dtype of `prec`, or fp32 when out_f32 != 0) [M,D]. */
+int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const float* gamma_dev,
+                     const float* beta_dev, void* y_dev, int32_t M, int32_t D, float eps,
+                     int32_t out_f32, void* stream);
+/* Multi-head SDPA (modeling_clip.py:259-277,313-331): qkv [nseq*seq_len, 3*heads*64]
+ * packed as [q | k | v], head_dim 64, scale 0.125; causal != 0 for the text tower.
+ * seq_lens_dev (int32 [nseq]) may be NULL (all = seq_len): rows ≥ len are not attended.
+ * out [nseq*seq_len, heads*64]. */
+int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev,
+                     int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCM_H_ */

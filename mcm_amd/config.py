@@ -1,0 +1,147 @@
+"""CLIP geometry for the checkpoints the reference accepts, and the ctypes mirror of
+`mcm_config` (include/mcm.h).
+
+The checkpoint names are the reference's `--CLIP_ckpt` choices
+(eval_ood_detection.py:34-35) and their HF hub ids (utils/train_eval_util.py:19-21);
+the dimensions are those of the HF configs (verified by instantiating
+`CLIPConfig` in the build container).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, asdict, replace
+
+ABI_VERSION = 1
+PREC_BF16 = 0
+PREC_F32 = 1
+
+SCORE_KINDS = {"MCM": 0, "max-logit": 1, "energy": 2, "entropy": 3, "var": 4}
+
+
+class CConfig(ctypes.Structure):
+    """Field-for-field mirror of `struct mcm_config` in include/mcm.h."""
+
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("image_size", ctypes.c_int32),
+        ("patch_size", ctypes.c_int32),
+        ("v_width", ctypes.c_int32),
+        ("v_heads", ctypes.c_int32),
+        ("v_layers", ctypes.c_int32),
+        ("v_mlp", ctypes.c_int32),
+        ("vocab_size", ctypes.c_int32),
+        ("max_positions", ctypes.c_int32),
+        ("t_width", ctypes.c_int32),
+        ("t_heads", ctypes.c_int32),
+        ("t_layers", ctypes.c_int32),
+        ("t_mlp", ctypes.c_int32),
+        ("proj_dim", ctypes.c_int32),
+        ("ln_eps", ctypes.c_float),
+        ("max_batch", ctypes.c_int32),
+        ("max_prompt_tokens", ctypes.c_int32),
+    ]
+
+
+@dataclass(frozen=True)
+class ClipGeometry:
+    name: str
+    image_size: int = 224
+    patch_size: int = 16
+    v_width: int = 768
+    v_heads: int = 12
+    v_layers: int = 12
+    v_mlp: int = 3072
+    vocab_size: int = 49408
+    max_positions: int = 77
+    t_width: int = 512
+    t_heads: int = 8
+    t_layers: int = 12
+    t_mlp: int = 2048
+    proj_dim: int = 512
+    ln_eps: float = 1e-5
+
+    @property
+    def n_patches(self) -> int:
+        g = self.image_size // self.patch_size
+        return g * g
+
+    @property
+    def v_tokens(self) -> int:
+        return self.n_patches + 1
+
+    def vision_flops_per_image(self) -> float:
+        """Algorithmic FLOP of the vision tower for one image (SURVEY.md §6:
+        L·(8·N·d² + 4·N²·d + 4·N·d·ff) + patch-embed + projection)."""
+        n, d, ff, L = self.v_tokens, self.v_width, self.v_mlp, self.v_layers
+        enc = L * (8 * n * d * d + 4 * n * n * d + 4 * n * d * ff)
+        patch = 2 * self.n_patches * d * 3 * self.patch_size ** 2
+        proj = 2 * d * self.proj_dim
+        return float(enc + patch + proj)
+
+    def text_flops_per_token(self) -> float:
+        d, ff, L = self.t_width, self.t_mlp, self.t_layers
+        return float(L * (8 * d * d + 4 * d * ff))
+
+    def to_c(self, *, device: int = 0, precision: int = PREC_BF16, max_batch: int = 512,
+             max_prompt_tokens: int = 1024 * 77) -> CConfig:
+        d = asdict(self)
+        d.pop("name")
+        return CConfig(abi_version=ABI_VERSION, device=device, precision=precision,
+                       max_batch=max_batch, max_prompt_tokens=max_prompt_tokens, **d)
+
+    def hf_configs(self):
+        """HF `CLIPConfig` of the same geometry (golden-fixture generation and the
+        cpu_baseline leg only; transformers is the reference's own dependency)."""
+        from transformers import CLIPConfig
+
+        return CLIPConfig(
+            text_config=dict(vocab_size=self.vocab_size, hidden_size=self.t_width,
+                             intermediate_size=self.t_mlp, num_hidden_layers=self.t_layers,
+                             num_attention_heads=self.t_heads,
+                             max_position_embeddings=self.max_positions,
+                             hidden_act="quick_gelu", layer_norm_eps=self.ln_eps,
+                             projection_dim=self.proj_dim, eos_token_id=49407,
+                             bos_token_id=49406, pad_token_id=49407),
+            vision_config=dict(hidden_size=self.v_width, intermediate_size=self.v_mlp,
+                               num_hidden_layers=self.v_layers,
+                               num_attention_heads=self.v_heads, image_size=self.image_size,
+                               patch_size=self.patch_size, hidden_act="quick_gelu",
+                               layer_norm_eps=self.ln_eps, projection_dim=self.proj_dim),
+            projection_dim=self.proj_dim,
+        )
+
+
+# --CLIP_ckpt → geometry (reference: eval_ood_detection.py:34-35; hub ids
+# utils/train_eval_util.py:19-21)
+CHECKPOINTS = {
+    "ViT-B/32": ClipGeometry("ViT-B/32", patch_size=32),
+    "ViT-B/16": ClipGeometry("ViT-B/16", patch_size=16),
+    "ViT-L/14": ClipGeometry("ViT-L/14", patch_size=14, v_width=1024, v_heads=16, v_layers=24,
+                             v_mlp=4096, t_width=768, t_heads=12, t_mlp=3072, proj_dim=768),
+}
+HUB_IDS = {
+    "ViT-B/32": "openai/clip-vit-base-patch32",
+    "ViT-B/16": "openai/clip-vit-base-patch16",
+    "ViT-L/14": "openai/clip-vit-large-patch14",
+}
+
+# Reduced geometries for fast parity tests: full-width heads (head_dim 64) and every code
+# path of the real towers, few layers / small images so the CPU oracle runs in seconds.
+TEST_GEOMETRIES = {
+    # 2-layer full-width B/16: per-op / per-layer intermediates
+    "B16-2L": replace(CHECKPOINTS["ViT-B/16"], name="B16-2L", v_layers=2, t_layers=2),
+    # tiny: 64-px images, 16 patches + CLS = 17 tokens, width 128 (2 heads)
+    "tiny": ClipGeometry("tiny", image_size=64, patch_size=16, v_width=128, v_heads=2,
+                         v_layers=2, v_mlp=512, vocab_size=49408, max_positions=77,
+                         t_width=128, t_heads=2, t_layers=2, t_mlp=512, proj_dim=64),
+}
+
+
+def geometry(name: str) -> ClipGeometry:
+    if name in CHECKPOINTS:
+        return CHECKPOINTS[name]
+    if name in TEST_GEOMETRIES:
+        return TEST_GEOMETRIES[name]
+    raise KeyError(f"unknown CLIP geometry {name!r}")
