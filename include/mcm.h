@@ -158,8 +158,8 @@ int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, doubl
  *   0: store (+bias)                out dtype = operand dtype
  *   1: QuickGELU(acc+bias)          out dtype = operand dtype   (activations.py:117-123)
  *   2: resid[M,N] (fp32) += acc+bias   in place; `y` ignored
- * M,K arbitrary ≥1 with K % 32 == 0 (bf16) or K % 4 == 0 (fp32); N % 16 == 0; rows of x
- * must be readable up to M rounded up to 128 (workspace rule: pad rows exist). */
+ * M ≥ 1 arbitrary (ragged tiles are clamped/masked); K % 64 == 0 (bf16) or K % 32 == 0
+ * (fp32): one K-step is 128 bytes per row; N % 16 == 0. */
 int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev,
                   const float* bias_dev, void* y_dev, float* resid_dev, int32_t M, int32_t N,
                   int32_t K, int32_t epi, void* stream);
@@ -169,9 +169,8 @@ int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const floa
                      const float* beta_dev, void* y_dev, int32_t M, int32_t D, float eps,
                      int32_t out_f32, void* stream);
 /* Multi-head SDPA (modeling_clip.py:259-277,313-331): qkv [nseq*seq_len, 3*heads*64]
- * packed as [q | k | v], head_dim 64, scale 0.125; causal != 0 for the text tower.
- * seq_lens_dev (int32 [nseq]) may be NULL (all = seq_len): rows ≥ len are not attended.
- * out [nseq*seq_len, heads*64]. */
+ * packed as [q | k | v], head_dim 64, scale 0.125; causal != 0 for the text tower;
+ * seq_len ≤ 288.  out [nseq*seq_len, heads*64]. */
 int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev,
                      int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
                      void* stream);

@@ -1,0 +1,278 @@
+// attention.hip — fused multi-head SDPA for short, fixed sequences (197 / 257 / 50 vision
+// tokens, <=77 text tokens), head_dim 64, scale 0.125, fp32 softmax.
+//
+// Replaces CLIPAttention's SDPA (HF modeling_clip.py:259-277 eager definition, :313-331;
+// causal for the text tower :543-556).  One workgroup per (sequence, head): the whole K
+// and V of the head live in LDS (<= 62 KiB at 197 keys), so nothing is re-read and the
+// [L,L] score matrix never exists in HBM.
+//
+// bf16 path (MFMA 16x16x32): each wave owns 16-query blocks.
+//   S^T = K·Q^T   (K fragment as A, Q fragment as B)  → a lane holds, for ONE query
+//                 (lane&15), 4 consecutive keys per 16-key tile: the softmax row lives in
+//                 registers, the max/sum need only 2 cross-lane steps (xor 16, 32);
+//   P (bf16) stays in those registers and is fed straight back as the B operand of
+//   O^T = V^T·P^T (V^T fragment as A): the MFMA contraction index is a free permutation,
+//                 so the key order "4 keys of tile 2u, 4 keys of tile 2u+1" is used for
+//                 both operands; V is transposed once while being staged into LDS.
+//   A lane ends with 4 consecutive head-dims of one query → 8-byte stores.
+// fp32 path (parity arm): plain fp32 VALU kernel, same staging idea, exact expf.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ int ktile_off(int r, int c) {  // same image as the GEMM tile
+  const int p = r >> 1;
+  return p * 256 + ((((r & 1) << 3) | ((c ^ p) & 7)) << 4);
+}
+
+__host__ __device__ constexpr int vt_stride(int LP) {  // bytes; ≡ 16 (mod 256): ds_read_b64
+  return ((LP * 2 - 16 + 255) / 256) * 256 + 16;       // of 16 rows x 2 groups is conflict-free
+}
+
+template <int LP, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv,
+                                                           uint16_t* __restrict__ out, int L,
+                                                           int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = LP / 16;       // key tiles
+  constexpr int NU = LP / 32;       // key tile pairs (PV k-steps)
+  constexpr int VS = vt_stride(LP);
+  char* Ks = smem;                  // [LP rows][128 B], swizzled
+  char* Vt = smem + LP * 128;       // [64 d][VS bytes]: V transposed, keys contiguous
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
+  const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+
+  // ---- stage K (LDS-DMA, swizzled source) : LP/8 pieces of 8 rows
+  for (int blk = wave; blk < LP / 8; blk += 4) {
+    const int p = blk * 4 + (lane >> 4), s = lane & 15;
+    const int row = min(2 * p + (s >> 3), L - 1);
+    const int chunk = (s & 7) ^ (p & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + D + chunk * 8),
+                                     (lptr_t)(Ks + blk * 1024), 16, 0, 0);
+  }
+  // ---- stage V transposed: a thread takes a key pair x 8 dims, writes 8 dwords
+  for (int item = threadIdx.x; item < (LP / 2) * 8; item += 256) {
+    const int dc = item & 7, kp = item >> 3;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+    if (2 * kp < L) v0 = *(const uint4*)(base + (size_t)(2 * kp) * rs + 2 * D + dc * 8);
+    if (2 * kp + 1 < L) v1 = *(const uint4*)(base + (size_t)(2 * kp + 1) * rs + 2 * D + dc * 8);
+    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
+      const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+      *(uint32_t*)(Vt + (dc * 8 + 2 * j) * VS + kp * 4) = lo;
+      *(uint32_t*)(Vt + (dc * 8 + 2 * j + 1) * VS + kp * 4) = hi;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, g = lane >> 4;
+  int koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = ktile_off(fr, kk * 4 + g);
+  constexpr float SC = 0.125f * 1.4426950408889634f;  // scale * log2(e)
+
+  const int nqb = (L + 15) / 16;
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int q = qb * 16 + fr;
+    const int qr = min(q, L - 1);
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[kk] = __builtin_bit_cast(bf16x8_t,
+                                  *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8));
+    // S^T tiles
+    // (fragment reads are software-pipelined one tile ahead; the sched_barrier stops hipcc
+    //  from hoisting all NT*2 ds_read_b128 up front, which spills at NT = 14/18)
+    f32x4_t s[NT];
+    uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint4 k0 = kn0, k1 = kn1;
+      if (t + 1 < NT) {
+        kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
+        kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
+      }
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0), qf[0],
+                                                     (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1), qf[1],
+                                                     s[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // mask + row max (row = this lane's query; keys spread over regs and the 4 g-groups)
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + g * 4 + r;
+        const bool ok = key < L && (!CAUSAL || key <= q);
+        s[t][r] = ok ? s[t][r] * SC : -INFINITY;
+        m = fmaxf(m, s[t][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    // P = exp2(s - m) → bf16 in MFMA operand order; row sum of the rounded values
+    float lsum = 0.f;
+    bf16x8_t pf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      uint32_t w[4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * u + half;
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = exp2f(s[t][r] - m);
+        const uint16_t b0 = f2bf(e[0]), b1 = f2bf(e[1]), b2 = f2bf(e[2]), b3 = f2bf(e[3]);
+        lsum += (bf2f(b0) + bf2f(b1)) + (bf2f(b2) + bf2f(b3));
+        w[half * 2 + 0] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+        w[half * 2 + 1] = (uint32_t)b2 | ((uint32_t)b3 << 16);
+      }
+      pf[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float rl = 1.0f / lsum;
+    // O^T = V^T · P^T
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const char* vrow = Vt + (dt * 16 + fr) * VS + g * 8;
+      uint2 ln = *(const uint2*)(vrow), hn = *(const uint2*)(vrow + 32);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const uint2 lo = ln, hi = hn;
+        if (u + 1 < NU) {
+          ln = *(const uint2*)(vrow + (2 * u + 2) * 32);
+          hn = *(const uint2*)(vrow + (2 * u + 3) * 32);
+        }
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], o, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q < L) {
+        uint2 pk;
+        pk.x = pack_bf2(o[0] * rl, o[1] * rl);
+        pk.y = pack_bf2(o[2] * rl, o[3] * rl);
+        *(uint2*)(out + ((size_t)seq * L + q) * D + h * 64 + dt * 16 + g * 4) = pk;
+      }
+    }
+  }
+}
+
+// ---- fp32 parity arm -------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv,
+                                                       float* __restrict__ out, int L, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ks = (float*)smem;            // [L][65]
+  float* Vs = Ks + (size_t)L * 65;     // [L][64]
+  float* qs = Vs + (size_t)L * 64;     // [4][64]
+  float* ps = qs + 4 * 64;             // [4][L]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const size_t rs = (size_t)3 * D;
+  const float* base = qkv + (size_t)seq * L * rs + h * 64;
+  for (int i = threadIdx.x; i < L * 64; i += 256) {
+    const int j = i >> 6, d = i & 63;
+    Ks[j * 65 + d] = base[(size_t)j * rs + D + d];
+    Vs[j * 64 + d] = base[(size_t)j * rs + 2 * D + d];
+  }
+  __syncthreads();
+  float* myq = qs + wave * 64;
+  float* myp = ps + wave * L;
+  for (int q = wave; q < L; q += 4) {
+    myq[lane] = base[(size_t)q * rs + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int jmax = CAUSAL ? q + 1 : L;
+    float m = -INFINITY;
+    for (int j = lane; j < jmax; j += 64) {
+      float a = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < 64; ++d) a = fmaf(myq[d], Ks[j * 65 + d], a);
+      a *= 0.125f;
+      myp[j] = a;
+      m = fmaxf(m, a);
+    }
+    m = wave_max(m);
+    float z = 0.f;
+    for (int j = lane; j < jmax; j += 64) {
+      const float e = expf(myp[j] - m);
+      myp[j] = e;
+      z += e;
+    }
+    z = wave_sum(z);
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int j = 0; j < jmax; ++j) o = fmaf(myp[j], Vs[j * 64 + lane], o);
+    out[((size_t)seq * L + q) * D + h * 64 + lane] = o / z;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int LP>
+hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
+                       hipStream_t s) {
+  constexpr int lds = LP * 128 + 64 * vt_stride(LP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<LP, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_bf16_kernel<LP, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (causal)
+    hipLaunchKernelGGL((attn_bf16_kernel<LP, true>), dim3(nseq * heads), dim3(256), lds, s,
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+  else
+    hipLaunchKernelGGL((attn_bf16_kernel<LP, false>), dim3(nseq * heads), dim3(256), lds, s,
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
+                            bool causal, hipStream_t s) {
+  if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
+  if (prec == MCM_PREC_BF16) {
+    if (L <= 32) return launch_bf16<32>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 64) return launch_bf16<64>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 96) return launch_bf16<96>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 128) return launch_bf16<128>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 224) return launch_bf16<224>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 288) return launch_bf16<288>(qkv, out, nseq, L, heads, causal, s);
+    return hipErrorInvalidValue;
+  }
+  const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_f32_kernel<true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (causal)
+    hipLaunchKernelGGL(attn_f32_kernel<true>, dim3(nseq * heads), dim3(256), lds, s,
+                       (const float*)qkv, (float*)out, L, heads);
+  else
+    hipLaunchKernelGGL(attn_f32_kernel<false>, dim3(nseq * heads), dim3(256), lds, s,
+                       (const float*)qkv, (float*)out, L, heads);
+  return hipGetLastError();
+}

@@ -1,0 +1,90 @@
+// common.hpp — shared types of the gfx950 MCM kernels (internal; the public boundary is
+// include/mcm.h).  CDNA4 only: 64-lane wavefronts, MFMA, 160 KiB LDS, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// fp32 → bf16, round-to-nearest-even (NaN kept quiet)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) {
+  return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// QuickGELU: x * sigmoid(1.702 x)  (transformers activations.py:117-123)
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+// wave64 butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// element size in bytes of the MFMA operand dtype of a precision mode
+__host__ __device__ constexpr int prec_esize(int prec) { return prec == MCM_PREC_BF16 ? 2 : 4; }
+
+// ---- host launchers (one per kernel family; defined in the .hip files) ----------------
+
+enum GemmEpi : int {
+  EPI_STORE = 0,   // out[M,N] (operand dtype) = acc + bias
+  EPI_GELU = 1,    // out = QuickGELU(acc + bias)
+  EPI_RESID = 2,   // resid[M,N] (fp32) += acc + bias
+  EPI_PATCH = 3,   // x[b*(np+1)+1+p, :] (fp32) = acc + pos[1+p, :]   (m = b*np + p)
+};
+
+struct GemmArgs {
+  const void* x;      // [M, K] operand dtype, row stride ldx elements
+  const void* w;      // [N, K] operand dtype, row stride K
+  const float* bias;  // [N] or nullptr
+  void* out;          // EPI_STORE / EPI_GELU: [M, N] operand dtype; EPI_PATCH: fp32 x
+  float* resid;       // EPI_RESID: [M, N] fp32
+  const float* pos;   // EPI_PATCH: position embedding [np+1, N]
+  int M, N, K;
+  int ldx;            // elements
+  int ldo;            // elements (row stride of out / resid)
+  int np;             // EPI_PATCH: patches per image
+};
+hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
+
+hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
+                            int M, int D, float eps, bool out_f32, hipStream_t s);
+
+hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
+                            bool causal, hipStream_t s);
+
+hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
+                           int patch, int kpad, hipStream_t s);
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D,
+                           hipStream_t s);
+hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* pos, float* x,
+                             int K, int S, int D, hipStream_t s);
+hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, int cols,
+                             int cols_pad, hipStream_t s);
+
+// pooled row → LayerNorm → projection (no bias) → L2 normalise; out fp32 [n, P]
+hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_stride, int n,
+                               int D, const float* g, const float* b, float eps,
+                               const float* proj, int P, float* out, hipStream_t s);
+
+hipError_t launch_score(const float* img, int B, const float* text, int K, int P, float T,
+                        int kind, float* scores, hipStream_t s);

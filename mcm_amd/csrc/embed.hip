@@ -1,0 +1,183 @@
+// embed.hip — the HBM-bound data-movement kernels around the towers' GEMMs.
+//
+//   patchify      CLIPVisionEmbeddings' Conv2d(3,D,k=s=P,bias=False) operand gather
+//                 (HF modeling_clip.py:148-154,209-210): NCHW fp32 pixels → patch matrix
+//                 [B*np, Kpad], k = (c,py,px) = the [D,3,P,P] weight flattening, in the GEMM
+//                 operand dtype, zero-padded to Kpad (L/14: 588 → 640).
+//   cls_rows      row 0 of every image: class_embedding + position_embedding[0] (:212-217)
+//   text_embed    token_embedding[id] + position_embedding[s]                  (:251-254)
+//   cvt_weight    fp32 [rows, cols] → operand dtype [rows, cols_pad], zero padded
+//   pool_project  pooled row → LayerNorm → projection (no bias) → L2 normalise, all fp32:
+//                 CLS pool + post_layernorm + visual_projection (:650-651,:751) and
+//                 EOS pool + final_layer_norm + text_projection (:559-581,:713), fused
+//                 with the reference's `x /= x.norm()` (utils/detection_util.py:226,231)
+#include "common.hpp"
+
+namespace {
+
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, void* out,
+                                                       int B, int S, int P, int kpad) {
+  const int g = S / P, np = g * g, kreal = 3 * P * P;
+  const size_t total = (size_t)B * np * kpad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % kpad);
+    const size_t m = i / kpad;
+    float v = 0.f;
+    if (k < kreal) {
+      const int b = (int)(m / np), p = (int)(m % np);
+      const int gy = p / g, gx = p % g;
+      const int c = k / (P * P), rem = k % (P * P), py = rem / P, pxx = rem % P;
+      v = px[(((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + pxx];
+    }
+    if (OUT_BF16) ((uint16_t*)out)[i] = f2bf(v);
+    else ((float*)out)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* x, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, int B,
+                                                       int ntok, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  x[(size_t)b * ntok * D + d] = cls[d] + pos[d];
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids,
+                                                         const float* __restrict__ tok,
+                                                         const float* __restrict__ pos, float* x,
+                                                         int K, int S, int D) {
+  const int row = blockIdx.x;  // k*S + s
+  const int s = row % S;
+  const int id = ids[row];
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    const float4 a = *(const float4*)(tok + (size_t)id * D + d);
+    const float4 p = *(const float4*)(pos + (size_t)s * D + d);
+    *(float4*)(x + (size_t)row * D + d) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void cvt_weight_kernel(const float* __restrict__ src, void* dst,
+                                                         int rows, int cols, int cols_pad) {
+  const size_t total = (size_t)rows * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % cols_pad);
+    const size_t r = i / cols_pad;
+    const float v = c < cols ? src[r * cols + c] : 0.f;
+    if (OUT_BF16) ((uint16_t*)dst)[i] = f2bf(v);
+    else ((float*)dst)[i] = v;
+  }
+}
+
+// one workgroup per pooled row; D <= 1024, P <= 1024
+__global__ __launch_bounds__(256) void pool_project_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ row_idx, int row_stride, int D,
+    const float* __restrict__ g, const float* __restrict__ b, float eps,
+    const float* __restrict__ proj, int P, float* __restrict__ out) {
+  __shared__ float y[1024];
+  __shared__ float o[1024];
+  __shared__ float red[8];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row = row_idx ? (size_t)row_idx[n] : (size_t)n * row_stride;
+  const float* xr = x + row * D;
+  // LayerNorm (two-pass, fp32)
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) s += xr[d];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)D;
+  float q = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    const float c = xr[d] - mean;
+    q += c * c;
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wave] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + eps);
+  for (int d = tid; d < D; d += 256) y[d] = (xr[d] - mean) * rstd * g[d] + b[d];
+  __syncthreads();
+  // projection: wave per output feature, lanes split D
+  float sq = 0.f;  // lane 0 of each wave accumulates squares of its outputs
+  for (int p = wave; p < P; p += 4) {
+    const float* w = proj + (size_t)p * D;
+    float a = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 wv = *(const float4*)(w + d);
+      a = fmaf(wv.x, y[d], a);
+      a = fmaf(wv.y, y[d + 1], a);
+      a = fmaf(wv.z, y[d + 2], a);
+      a = fmaf(wv.w, y[d + 3], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+      o[p] = a;
+      sq += a * a;
+    }
+  }
+  __syncthreads();  // red[] reuse
+  if (lane == 0) red[wave] = sq;
+  __syncthreads();
+  const float rn = 1.0f / sqrtf(red[0] + red[1] + red[2] + red[3]);
+  for (int p = tid; p < P; p += 256) out[(size_t)n * P + p] = o[p] * rn;
+}
+
+inline int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g > 2048 ? 2048 : (g ? g : 1));
+}
+
+}  // namespace
+
+hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
+                           int patch, int kpad, hipStream_t s) {
+  const int g = image / patch;
+  const size_t total = (size_t)B * g * g * kpad;
+  if (prec == MCM_PREC_BF16)
+    hipLaunchKernelGGL(patchify_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, pixels, patches,
+                       B, image, patch, kpad);
+  else
+    hipLaunchKernelGGL(patchify_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, pixels, patches,
+                       B, image, patch, kpad);
+  return hipGetLastError();
+}
+
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, cls, pos, B,
+                     ntok, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* pos, float* x,
+                             int K, int S, int D, hipStream_t s) {
+  if (D % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(text_embed_kernel, dim3(K * S), dim3(256), 0, s, ids, tok, pos, x, K, S, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, int cols,
+                             int cols_pad, hipStream_t s) {
+  const size_t total = (size_t)rows * cols_pad;
+  if (prec == MCM_PREC_BF16)
+    hipLaunchKernelGGL(cvt_weight_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, src, dst, rows,
+                       cols, cols_pad);
+  else
+    hipLaunchKernelGGL(cvt_weight_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, src, dst, rows,
+                       cols, cols_pad);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_stride, int n,
+                               int D, const float* g, const float* b, float eps,
+                               const float* proj, int P, float* out, hipStream_t s) {
+  if (n <= 0 || D > 1024 || D % 4 || P > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_project_kernel, dim3(n), dim3(256), 0, s, x, row_idx, row_stride, D, g, b,
+                     eps, proj, P, out);
+  return hipGetLastError();
+}

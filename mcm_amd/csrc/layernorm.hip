@@ -1,0 +1,79 @@
+// layernorm.hip — row LayerNorm, fp32 statistics, one 64-lane wave per row.
+//
+// Replaces nn.LayerNorm of the CLIP towers (HF modeling_clip.py:358,360 layer_norm1/2,
+// :605 pre_layrnorm, :608 post_layernorm, :507 final_layer_norm; eps 1e-5 from
+// configuration_clip.py).  HBM-bound: reads the fp32 residual row once (16 B/lane),
+// keeps it in registers for the exact two-pass mean / centred variance, writes the
+// normalised row in the GEMM operand dtype (bf16 or fp32).  In-place (y == x, fp32) is
+// safe: a wave has its whole row in registers before it stores.
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane: D <= 64*4*4 = 1024
+
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b, void* y,
+                                                        int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = (i * 64 + lane) * 4;
+    if (d < D) {
+      v[i] = *(const float4*)(xr + d);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = (i * 64 + lane) * 4;
+    if (d < D) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = (i * 64 + lane) * 4;
+    if (d < D) {
+      const float4 gv = *(const float4*)(g + d);
+      const float4 bv = *(const float4*)(b + d);
+      float4 o;
+      o.x = v[i].x * rstd * gv.x + bv.x;
+      o.y = v[i].y * rstd * gv.y + bv.y;
+      o.z = v[i].z * rstd * gv.z + bv.z;
+      o.w = v[i].w * rstd * gv.w + bv.w;
+      if (OUT_BF16) {
+        uint2 pk;
+        pk.x = pack_bf2(o.x, o.y);
+        pk.y = pack_bf2(o.z, o.w);
+        *(uint2*)((uint16_t*)y + (size_t)row * D + d) = pk;
+      } else {
+        *(float4*)((float*)y + (size_t)row * D + d) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
+                            int M, int D, float eps, bool out_f32, hipStream_t s) {
+  if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  if (prec == MCM_PREC_BF16 && !out_f32)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, g, b, y, M, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x, g, b, y, M, D, eps);
+  return hipGetLastError();
+}

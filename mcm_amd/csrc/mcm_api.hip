@@ -1,0 +1,533 @@
+// mcm_api.hip — the C ABI of libmcm_hip.so (include/mcm.h): parameter store, workspace,
+// the two CLIP towers as sequences of kernel launches on the caller's stream, the fused
+// scoring tail, per-kernel HIP-event timing, and operator-level entry points.
+//
+// Tower structure follows HF modeling_clip.py (the library the reference delegates to):
+//   vision  CLIPVisionEmbeddings.forward :202-218 → pre_layrnorm :642 → CLIPEncoderLayer
+//           ×L :362-383 → CLS pool + post_layernorm :650-651 → visual_projection :751
+//   text    CLIPTextEmbeddings :232-256 → causal CLIPEncoderLayer ×L → final_layer_norm
+//           :559 → EOS pool :561-581 → text_projection :713
+// and the reference's own tail utils/detection_util.py:226,231-248.
+// The residual stream is fp32 in HBM; GEMM operands are bf16 (or fp32 in the parity mode).
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct Param {
+  std::vector<int64_t> shape;
+  int64_t numel = 0;
+  float* dev = nullptr;
+  bool set = false;
+};
+
+struct LayerW {
+  void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // operand dtype
+  float *bqkv = nullptr;                                               // [3D] packed
+  const float *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;               // fp32 masters
+};
+
+struct Tower {
+  int D = 0, heads = 0, layers = 0, ff = 0;
+  std::vector<LayerW> L;
+};
+
+struct EvPair {
+  hipEvent_t a, b;
+  int kc;
+};
+
+}  // namespace
+
+struct mcm_handle {
+  mcm_config cfg;
+  std::map<std::string, Param> params;
+  bool finalized = false;
+  Tower vis, txt;
+  void* wpatch = nullptr;  // [v_width, kpad] operand dtype
+  int kpad = 0, np = 0, ntok = 0;
+  // workspace
+  float* x = nullptr;
+  void *ln = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
+  float* feat = nullptr;          // [max_batch, proj_dim] scratch for mcm_score
+  int32_t *ids_dev = nullptr, *rowidx_dev = nullptr;
+  int32_t *ids_pin = nullptr, *rowidx_pin = nullptr;
+  int64_t max_rows = 0;
+  std::vector<void*> owned;       // every hipMalloc'd pointer
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> ev_pool;
+  size_t ev_used = 0;
+  double ms_acc[MCM_KC_COUNT] = {0};
+  int64_t launches[MCM_KC_COUNT] = {0};
+  double flops[MCM_KC_COUNT] = {0};
+  std::string err;
+};
+
+namespace {
+
+int fail(mcm_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                 \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return fail(h, MCM_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+void add_param(mcm_handle* h, const std::string& name, std::vector<int64_t> shape) {
+  Param p;
+  p.shape = shape;
+  p.numel = 1;
+  for (auto d : shape) p.numel *= d;
+  h->params[name] = p;
+}
+
+void add_layer_params(mcm_handle* h, const std::string& pre, int D, int ff) {
+  for (const char* pr : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+    add_param(h, pre + ".self_attn." + pr + ".weight", {D, D});
+    add_param(h, pre + ".self_attn." + pr + ".bias", {D});
+  }
+  for (const char* ln : {"layer_norm1", "layer_norm2"}) {
+    add_param(h, pre + "." + ln + ".weight", {D});
+    add_param(h, pre + "." + ln + ".bias", {D});
+  }
+  add_param(h, pre + ".mlp.fc1.weight", {ff, D});
+  add_param(h, pre + ".mlp.fc1.bias", {ff});
+  add_param(h, pre + ".mlp.fc2.weight", {D, ff});
+  add_param(h, pre + ".mlp.fc2.bias", {D});
+}
+
+int dev_alloc(mcm_handle* h, void** out, size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  if (e != hipSuccess)
+    return fail(h, MCM_ENOMEM, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  h->owned.push_back(p);
+  *out = p;
+  return MCM_OK;
+}
+
+const float* W(mcm_handle* h, const std::string& name) { return h->params.at(name).dev; }
+
+// ---- profiling wrappers ---------------------------------------------------------------
+struct Scope {
+  mcm_handle* h;
+  hipStream_t s;
+  int kc;
+  EvPair* ev = nullptr;
+  Scope(mcm_handle* h_, hipStream_t s_, int kc_, double fl) : h(h_), s(s_), kc(kc_) {
+    if (!h->prof) return;
+    if (h->ev_used == h->ev_pool.size()) {
+      EvPair e;
+      (void)hipEventCreate(&e.a);
+      (void)hipEventCreate(&e.b);
+      h->ev_pool.push_back(e);
+    }
+    ev = &h->ev_pool[h->ev_used++];
+    ev->kc = kc;
+    h->launches[kc] += 1;
+    h->flops[kc] += fl;
+    (void)hipEventRecord(ev->a, s);
+  }
+  ~Scope() {
+    if (ev) (void)hipEventRecord(ev->b, s);
+  }
+};
+
+hipError_t gemm(mcm_handle* h, hipStream_t s, int epi, const GemmArgs& a) {
+  Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);
+  return launch_gemm(h->cfg.precision, epi, a, s);
+}
+hipError_t lnorm(mcm_handle* h, hipStream_t s, const float* x, const float* g, const float* b,
+                 void* y, int M, int D, bool out_f32) {
+  Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
+  return launch_layernorm(h->cfg.precision, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s);
+}
+hipError_t attn(mcm_handle* h, hipStream_t s, int nseq, int L, int heads, bool causal) {
+  Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)L * L * 64 * (causal ? 0.5 : 1.0));
+  return launch_attention(h->cfg.precision, h->qkv, h->att, nseq, L, heads, causal, s);
+}
+
+// CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place)
+int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal) {
+  const int M = nseq * L, D = t.D;
+  for (int l = 0; l < t.layers; ++l) {
+    const LayerW& w = t.L[l];
+    HIP_TRY(h, lnorm(h, s, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    GemmArgs a{};
+    a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
+    a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
+    HIP_TRY(h, gemm(h, s, EPI_STORE, a));
+    HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal));
+    GemmArgs o{};
+    o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
+    o.M = M; o.N = D; o.K = D; o.ldx = D; o.ldo = D;
+    HIP_TRY(h, gemm(h, s, EPI_RESID, o));
+    HIP_TRY(h, lnorm(h, s, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+    GemmArgs f1{};
+    f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
+    f1.M = M; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
+    HIP_TRY(h, gemm(h, s, EPI_GELU, f1));
+    GemmArgs f2{};
+    f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
+    f2.M = M; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = D;
+    HIP_TRY(h, gemm(h, s, EPI_RESID, f2));
+  }
+  return MCM_OK;
+}
+
+int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s) {
+  const int prec = h->cfg.precision, es = prec_esize(prec), D = t.D, ff = t.ff;
+  t.L.resize(t.layers);
+  for (int l = 0; l < t.layers; ++l) {
+    LayerW& w = t.L[l];
+    const std::string pre = tower + ".encoder.layers." + std::to_string(l);
+    int rc;
+    if ((rc = dev_alloc(h, &w.wqkv, (size_t)3 * D * D * es))) return rc;
+    if ((rc = dev_alloc(h, &w.wo, (size_t)D * D * es))) return rc;
+    if ((rc = dev_alloc(h, &w.w1, (size_t)ff * D * es))) return rc;
+    if ((rc = dev_alloc(h, &w.w2, (size_t)D * ff * es))) return rc;
+    if ((rc = dev_alloc(h, (void**)&w.bqkv, (size_t)3 * D * sizeof(float)))) return rc;
+    const char* parts[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int p = 0; p < 3; ++p) {
+      HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".self_attn." + parts[p] + ".weight"),
+                                   (char*)w.wqkv + (size_t)p * D * D * es, D, D, D, s));
+      HIP_TRY(h, hipMemcpyAsync(w.bqkv + (size_t)p * D, W(h, pre + ".self_attn." + parts[p] + ".bias"),
+                                (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".self_attn.out_proj.weight"), w.wo, D, D, D, s));
+    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc1.weight"), w.w1, ff, D, D, s));
+    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc2.weight"), w.w2, D, ff, ff, s));
+    w.bo = W(h, pre + ".self_attn.out_proj.bias");
+    w.b1 = W(h, pre + ".mlp.fc1.bias");
+    w.b2 = W(h, pre + ".mlp.fc2.bias");
+    w.ln1w = W(h, pre + ".layer_norm1.weight");
+    w.ln1b = W(h, pre + ".layer_norm1.bias");
+    w.ln2w = W(h, pre + ".layer_norm2.weight");
+    w.ln2b = W(h, pre + ".layer_norm2.bias");
+  }
+  return MCM_OK;
+}
+
+int check_ready(mcm_handle* h) {
+  if (!h) return MCM_EINVAL;
+  if (!h->finalized) return fail(h, MCM_ENOWEIGHT, "mcm_finalize_weights has not been called");
+  return MCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcm_abi_version(void) { return MCM_ABI_VERSION; }
+
+const char* mcm_last_error(const mcm_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mcm_create(const mcm_config* cfg, mcm_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MCM_EINVAL, "null argument");
+  if (cfg->abi_version != MCM_ABI_VERSION) return fail(nullptr, MCM_EINVAL, "ABI version mismatch");
+  const mcm_config& c = *cfg;
+  if (c.precision != MCM_PREC_BF16 && c.precision != MCM_PREC_F32)
+    return fail(nullptr, MCM_EINVAL, "unknown precision");
+  if (c.v_heads <= 0 || c.t_heads <= 0 || c.v_width != c.v_heads * 64 || c.t_width != c.t_heads * 64)
+    return fail(nullptr, MCM_EINVAL, "head_dim must be 64");
+  if (c.patch_size <= 0 || c.image_size % c.patch_size)
+    return fail(nullptr, MCM_EINVAL, "image_size must be a multiple of patch_size");
+  if (c.v_width % 64 || c.t_width % 64 || c.v_mlp % 64 || c.t_mlp % 64 || c.v_width > 1024 ||
+      c.t_width > 1024 || c.proj_dim % 4 || c.proj_dim > 1024)
+    return fail(nullptr, MCM_EINVAL, "widths must be multiples of 64 and <= 1024; proj_dim % 4 == 0");
+  if (c.max_batch <= 0 || c.max_prompt_tokens <= 0 || c.max_positions <= 0 ||
+      c.max_prompt_tokens < c.max_positions)
+    return fail(nullptr, MCM_EINVAL, "bad workspace bounds");
+  {
+    const int g = c.image_size / c.patch_size;
+    if (g * g + 1 > 288) return fail(nullptr, MCM_EINVAL, "more than 288 vision tokens");
+  }
+  hipError_t e = hipSetDevice(c.device);
+  if (e != hipSuccess) return fail(nullptr, MCM_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+  mcm_handle* h = new mcm_handle();
+  h->cfg = c;
+  const int g = c.image_size / c.patch_size;
+  h->np = g * g;
+  h->ntok = h->np + 1;
+  const int es = prec_esize(c.precision);
+  const int kreal = 3 * c.patch_size * c.patch_size;
+  const int kalign = 128 / es;
+  h->kpad = (kreal + kalign - 1) / kalign * kalign;
+  h->vis = Tower{c.v_width, c.v_heads, c.v_layers, c.v_mlp, {}};
+  h->txt = Tower{c.t_width, c.t_heads, c.t_layers, c.t_mlp, {}};
+
+  // parameter registry (HF state_dict names)
+  add_param(h, "vision_model.embeddings.class_embedding", {c.v_width});
+  add_param(h, "vision_model.embeddings.patch_embedding.weight", {c.v_width, 3, c.patch_size, c.patch_size});
+  add_param(h, "vision_model.embeddings.position_embedding.weight", {h->ntok, c.v_width});
+  add_param(h, "vision_model.pre_layrnorm.weight", {c.v_width});
+  add_param(h, "vision_model.pre_layrnorm.bias", {c.v_width});
+  for (int l = 0; l < c.v_layers; ++l)
+    add_layer_params(h, "vision_model.encoder.layers." + std::to_string(l), c.v_width, c.v_mlp);
+  add_param(h, "vision_model.post_layernorm.weight", {c.v_width});
+  add_param(h, "vision_model.post_layernorm.bias", {c.v_width});
+  add_param(h, "visual_projection.weight", {c.proj_dim, c.v_width});
+  add_param(h, "text_model.embeddings.token_embedding.weight", {c.vocab_size, c.t_width});
+  add_param(h, "text_model.embeddings.position_embedding.weight", {c.max_positions, c.t_width});
+  for (int l = 0; l < c.t_layers; ++l)
+    add_layer_params(h, "text_model.encoder.layers." + std::to_string(l), c.t_width, c.t_mlp);
+  add_param(h, "text_model.final_layer_norm.weight", {c.t_width});
+  add_param(h, "text_model.final_layer_norm.bias", {c.t_width});
+  add_param(h, "text_projection.weight", {c.proj_dim, c.t_width});
+
+  int rc = MCM_OK;
+  for (auto& kv : h->params) {
+    if ((rc = dev_alloc(h, (void**)&kv.second.dev, (size_t)kv.second.numel * sizeof(float)))) break;
+  }
+  // activation workspace
+  const int64_t mv = (int64_t)c.max_batch * h->ntok, mt = c.max_prompt_tokens;
+  h->max_rows = mv > mt ? mv : mt;
+  const int64_t dmax = c.v_width > c.t_width ? c.v_width : c.t_width;
+  const int64_t ffmax = c.v_mlp > c.t_mlp ? c.v_mlp : c.t_mlp;
+  const size_t R = (size_t)h->max_rows;
+  if (!rc) rc = dev_alloc(h, (void**)&h->x, R * dmax * sizeof(float));
+  if (!rc) rc = dev_alloc(h, &h->ln, R * dmax * es);
+  if (!rc) rc = dev_alloc(h, &h->qkv, R * 3 * dmax * es);
+  if (!rc) rc = dev_alloc(h, &h->att, R * dmax * es);
+  if (!rc) rc = dev_alloc(h, &h->hbuf, R * ffmax * es);
+  if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
+  if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
+  if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
+  if (!rc) rc = dev_alloc(h, (void**)&h->rowidx_dev, (size_t)mt * sizeof(int32_t));
+  if (!rc) rc = dev_alloc(h, &h->wpatch, (size_t)c.v_width * h->kpad * es);
+  if (!rc && hipHostMalloc((void**)&h->ids_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
+    rc = fail(h, MCM_ENOMEM, "hipHostMalloc ids");
+  if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
+    rc = fail(h, MCM_ENOMEM, "hipHostMalloc rowidx");
+  if (rc) {
+    g_create_err = h->err;
+    mcm_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MCM_OK;
+}
+
+void mcm_destroy(mcm_handle* h) {
+  if (!h) return;
+  (void)hipDeviceSynchronize();
+  for (void* p : h->owned) (void)hipFree(p);
+  if (h->ids_pin) (void)hipHostFree(h->ids_pin);
+  if (h->rowidx_pin) (void)hipHostFree(h->rowidx_pin);
+  for (auto& e : h->ev_pool) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  delete h;
+}
+
+int mcm_set_weight(mcm_handle* h, const char* hf_name, const float* host_ptr, const int64_t* shape,
+                   int32_t ndim) {
+  if (!h || !hf_name || !host_ptr || (ndim > 0 && !shape)) return fail(h, MCM_EINVAL, "null argument");
+  auto it = h->params.find(hf_name);
+  if (it == h->params.end()) return fail(h, MCM_ENAME, std::string("unknown parameter ") + hf_name);
+  Param& p = it->second;
+  bool ok = (size_t)ndim == p.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == p.shape[i];
+  if (!ok) return fail(h, MCM_ESHAPE, std::string("shape mismatch for ") + hf_name);
+  HIP_TRY(h, hipMemcpy(p.dev, host_ptr, (size_t)p.numel * sizeof(float), hipMemcpyHostToDevice));
+  p.set = true;
+  h->finalized = false;
+  return MCM_OK;
+}
+
+int mcm_finalize_weights(mcm_handle* h) {
+  if (!h) return MCM_EINVAL;
+  for (auto& kv : h->params)
+    if (!kv.second.set) return fail(h, MCM_ENOWEIGHT, "parameter never set: " + kv.first);
+  // operand copies are re-built from the fp32 masters each time (pointers are stable)
+  if (h->vis.L.empty()) {
+    int rc;
+    if ((rc = build_tower(h, h->vis, "vision_model", nullptr))) return rc;
+    if ((rc = build_tower(h, h->txt, "text_model", nullptr))) return rc;
+  } else {
+    return fail(h, MCM_EINVAL, "weights already finalized; create a new handle to reload");
+  }
+  const mcm_config& c = h->cfg;
+  HIP_TRY(h, launch_cvt_weight(c.precision, W(h, "vision_model.embeddings.patch_embedding.weight"),
+                               h->wpatch, c.v_width, 3 * c.patch_size * c.patch_size, h->kpad,
+                               nullptr));
+  HIP_TRY(h, hipDeviceSynchronize());
+  h->finalized = true;
+  return MCM_OK;
+}
+
+int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
+  if (B <= 0 || B > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds cfg.max_batch");
+  hipStream_t s = (hipStream_t)stream;
+  const mcm_config& c = h->cfg;
+  const int D = c.v_width;
+  {
+    Scope sc(h, s, MCM_KC_PATCHIFY, 0.0);
+    HIP_TRY(h, launch_patchify(c.precision, pixels_dev, h->patches, B, c.image_size, c.patch_size,
+                               h->kpad, s));
+  }
+  GemmArgs a{};
+  a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
+  a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
+  a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np;
+  HIP_TRY(h, gemm(h, s, EPI_PATCH, a));
+  {
+    Scope sc(h, s, MCM_KC_EMBED, 0.0);
+    HIP_TRY(h, launch_cls_rows(h->x, W(h, "vision_model.embeddings.class_embedding"), a.pos, B,
+                               h->ntok, D, s));
+  }
+  HIP_TRY(h, lnorm(h, s, h->x, W(h, "vision_model.pre_layrnorm.weight"),
+                   W(h, "vision_model.pre_layrnorm.bias"), h->x, B * h->ntok, D, true));
+  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false))) return rc;
+  {
+    Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * B * D * c.proj_dim);
+    HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,
+                                   W(h, "vision_model.post_layernorm.weight"),
+                                   W(h, "vision_model.post_layernorm.bias"), c.ln_eps,
+                                   W(h, "visual_projection.weight"), c.proj_dim, out_dev, s));
+  }
+  return MCM_OK;
+}
+
+int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S, float* out_dev,
+                    void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!ids_host || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
+  const mcm_config& c = h->cfg;
+  if (K <= 0 || S <= 0) return fail(h, MCM_EINVAL, "K and S must be positive");
+  if (S > c.max_positions)  // HF modeling_clip.py:241-245 raises ValueError
+    return fail(h, MCM_ERANGE, "sequence length exceeds max_position_embeddings");
+  for (int64_t i = 0; i < (int64_t)K * S; ++i)
+    if (ids_host[i] < 0 || ids_host[i] >= c.vocab_size) return fail(h, MCM_EINVAL, "token id out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c.t_width;
+  const int chunk = c.max_prompt_tokens / S;  // prompts per pass
+  for (int k0 = 0; k0 < K; k0 += chunk) {
+    const int kc = (K - k0) < chunk ? (K - k0) : chunk;
+    HIP_TRY(h, hipStreamSynchronize(s));  // pinned staging buffers are reused
+    for (int k = 0; k < kc; ++k) {
+      const int32_t* row = ids_host + (size_t)(k0 + k) * S;
+      int best = 0;  // first EOS = argmax id (HF modeling_clip.py:561-581)
+      for (int j = 0; j < S; ++j) {
+        h->ids_pin[(size_t)k * S + j] = row[j];
+        if (row[j] > row[best]) best = j;
+      }
+      h->rowidx_pin[k] = k * S + best;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->ids_dev, h->ids_pin, (size_t)kc * S * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->rowidx_dev, h->rowidx_pin, (size_t)kc * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
+    {
+      Scope sc(h, s, MCM_KC_EMBED, 0.0);
+      HIP_TRY(h, launch_text_embed(h->ids_dev, W(h, "text_model.embeddings.token_embedding.weight"),
+                                   W(h, "text_model.embeddings.position_embedding.weight"), h->x,
+                                   kc, S, D, s));
+    }
+    if ((rc = run_layers(h, s, h->txt, kc, S, true))) return rc;
+    {
+      Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * kc * D * c.proj_dim);
+      HIP_TRY(h, launch_pool_project(h->x, h->rowidx_dev, 0, kc, D,
+                                     W(h, "text_model.final_layer_norm.weight"),
+                                     W(h, "text_model.final_layer_norm.bias"), c.ln_eps,
+                                     W(h, "text_projection.weight"), c.proj_dim,
+                                     out_dev + (size_t)k0 * c.proj_dim, s));
+    }
+  }
+  return MCM_OK;
+}
+
+int mcm_score_features(mcm_handle* h, const float* img_feat_dev, int32_t B, const float* text_feat_dev,
+                       int32_t K, float T, int32_t kind, float* scores_dev, void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!img_feat_dev || !text_feat_dev || !scores_dev) return fail(h, MCM_EINVAL, "null pointer");
+  if (B <= 0 || K <= 0 || kind < 0 || kind > MCM_SCORE_VAR || !(T > 0.f))
+    return fail(h, MCM_EINVAL, "bad B / K / kind / T");
+  hipStream_t s = (hipStream_t)stream;
+  Scope sc(h, s, MCM_KC_SCORE, 2.0 * B * (double)K * h->cfg.proj_dim);
+  HIP_TRY(h, launch_score(img_feat_dev, B, text_feat_dev, K, h->cfg.proj_dim, T, kind, scores_dev, s));
+  return MCM_OK;
+}
+
+int mcm_score(mcm_handle* h, const float* pixels_dev, int32_t B, const float* text_feat_dev, int32_t K,
+              float T, int32_t kind, float* scores_dev, void* stream) {
+  int rc = mcm_encode_image(h, pixels_dev, B, h ? h->feat : nullptr, stream);
+  if (rc) return rc;
+  return mcm_score_features(h, h->feat, B, text_feat_dev, K, T, kind, scores_dev, stream);
+}
+
+int mcm_profile_enable(mcm_handle* h, int32_t on) {
+  if (!h) return MCM_EINVAL;
+  h->prof = on != 0;
+  return MCM_OK;
+}
+
+int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, double* flops_out) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, hipDeviceSynchronize());
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
+    h->ms_acc[h->ev_pool[i].kc] += ms;
+  }
+  h->ev_used = 0;
+  for (int k = 0; k < MCM_KC_COUNT; ++k) {
+    if (ms_out) ms_out[k] = h->ms_acc[k];
+    if (launches_out) launches_out[k] = h->launches[k];
+    if (flops_out) flops_out[k] = h->flops[k];
+    h->ms_acc[k] = 0;
+    h->launches[k] = 0;
+    h->flops[k] = 0;
+  }
+  return MCM_OK;
+}
+
+// ---- operator-level entry points ------------------------------------------------------
+
+int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev, const float* bias_dev,
+                  void* y_dev, float* resid_dev, int32_t M, int32_t N, int32_t K, int32_t epi,
+                  void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (epi < EPI_STORE || epi > EPI_RESID) return fail(h, MCM_EINVAL, "bad epilogue");
+  GemmArgs a{};
+  a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.out = y_dev; a.resid = resid_dev;
+  a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
+  HIP_TRY(h, launch_gemm(prec, epi, a, (hipStream_t)stream));
+  return MCM_OK;
+}
+
+int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const float* gamma_dev,
+                     const float* beta_dev, void* y_dev, int32_t M, int32_t D, float eps, int32_t out_f32,
+                     void* stream) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, launch_layernorm(prec, x_dev, gamma_dev, beta_dev, y_dev, M, D, eps, out_f32 != 0,
+                              (hipStream_t)stream));
+  return MCM_OK;
+}
+
+int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq,
+                     int32_t seq_len, int32_t heads, int32_t causal, void* stream) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0,
+                              (hipStream_t)stream));
+  return MCM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""The hot path's host side: `get_ood_scores_clip` and its reporting helpers, re-written
+from scratch with the reference's signatures (utils/detection_util.py:209-265).
+
+Differences from the reference that do not change results:
+  * the prompt bank is tokenised and encoded ONCE per call instead of once per batch
+    (reference :228-231 is loop-invariant);
+  * the per-batch body runs as one fused native call (`net.score_images`), so only [b]
+    scores exist per batch and they stay in HBM until the dataset is done (the reference
+    copies the whole [b,K] softmax to the host every batch, :236);
+  * under torch.distributed (one process per GPU) each rank scores a contiguous shard of the
+    batches and the shards are all-gathered, so every rank returns the full vector in the
+    reference's sample order.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import dist as mdist
+from .config import SCORE_KINDS
+from .metrics import get_measures
+from .tokenizer import load_tokenizer
+
+PROMPT = "a photo of a {c}"  # reference utils/detection_util.py:228 (no trailing period)
+
+
+def encode_prompt_bank(args, net, test_labels):
+    """`text_features` of the reference (:228-231): K prompts → [K,P] unit-norm fp32."""
+    tokenizer = load_tokenizer(getattr(args, "ckpt", ""))
+    text_inputs = tokenizer([PROMPT.format(c=c) for c in test_labels], padding=True, return_tensors="pt")
+    return net.get_text_features(input_ids=text_inputs["input_ids"],
+                                 attention_mask=text_inputs["attention_mask"])
+
+
+def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
+    """Scores every sample of `loader` against the concept bank `test_labels`.
+
+    Same contract as reference utils/detection_util.py:209-249: reads `args.ckpt`,
+    `args.model`, `args.score`, `args.T`; `loader` yields `(images[b,3,S,S] fp32, labels)`
+    in dataset order; returns float32 ndarray `[len(loader.dataset)]` of *negated*
+    confidences (lower = more ID) for MCM / max-logit / energy / var and the entropy for
+    'entropy'.  `in_dist` and the labels are unused, as in the reference.
+    """
+    import torch
+
+    if getattr(args, "model", "CLIP") != "CLIP":
+        raise ValueError(f"unsupported --model {args.model!r} (the reference only defines CLIP)")
+    if args.score not in SCORE_KINDS:
+        raise ValueError(f"unsupported --score {args.score!r} for get_ood_scores_clip")
+    if not hasattr(net, "score_images"):
+        raise TypeError("net must be a mcm_amd NativeCLIP (fused score_images path); "
+                        "there is no eager fallback")
+    rank, ws = mdist.world()
+    n_total = len(loader.dataset)
+    with torch.no_grad():
+        text_features = encode_prompt_bank(args, net, test_labels)
+        if ws > 1 and hasattr(loader, "shard"):
+            lo, hi = mdist.shard_range(n_total, rank, ws)
+            batches = loader.shard(lo, hi)
+            mine = lambda i: True  # noqa: E731
+        else:
+            nb = len(loader)
+            blo, bhi = mdist.shard_range(nb, rank, ws)
+            batches = loader
+            mine = lambda i: blo <= i < bhi  # noqa: E731
+        parts = []
+        for batch_idx, (images, _labels) in enumerate(batches):
+            if not mine(batch_idx):
+                continue
+            parts.append(net.score_images(images, text_features, float(args.T), args.score))
+        local = torch.cat(parts) if parts else torch.empty(0, dtype=torch.float32,
+                                                           device=text_features.device)
+        if ws > 1:
+            if hasattr(loader, "shard"):
+                full = mdist.all_gather_scores(local, n_total)
+            else:  # batch-range shards of a generic loader: sizes follow the batch split
+                full = _gather_batch_shards(local, loader, n_total, ws)
+        else:
+            full = local
+    return full.detach().cpu().numpy().astype(np.float32, copy=False)[:n_total].copy()
+
+
+def _gather_batch_shards(local, loader, n_total, ws):
+    import torch
+    import torch.distributed as dist
+
+    nb = len(loader)
+    bs = -(-n_total // nb) if nb else 0
+    per_b = -(-nb // ws)
+    cap = per_b * bs
+    buf = torch.zeros(cap, dtype=torch.float32, device=local.device)
+    buf[: local.numel()] = local
+    out = torch.empty(ws * cap, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    parts = []
+    for r in range(ws):
+        blo, bhi = mdist.shard_range(nb, r, ws)
+        n_r = max(0, min(n_total, bhi * bs) - blo * bs)
+        parts.append(out[r * cap: r * cap + n_r])
+    return torch.cat(parts)
+
+
+def print_measures(log, auroc, aupr, fpr, method_name="Ours", recall_level=0.95):
+    """Same output format as reference utils/detection_util.py:37-45."""
+    pct = int(100 * recall_level)
+    if log is None:
+        print("FPR{:d}:\t\t\t{:.2f}".format(pct, 100 * fpr))
+        print("AUROC: \t\t\t{:.2f}".format(100 * auroc))
+        print("AUPR:  \t\t\t{:.2f}".format(100 * aupr))
+    else:
+        log.debug("\t\t\t\t" + method_name)
+        log.debug("  FPR{:d} AUROC AUPR".format(pct))
+        log.debug("& {:.2f} & {:.2f} & {:.2f}".format(100 * fpr, 100 * auroc, 100 * aupr))
+
+
+def get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list):
+    """Reference utils/detection_util.py:253-265: the scores are negated confidences, so the
+    metrics are taken on their negation with ID as the positive class."""
+    auroc, aupr, fpr = get_measures(-in_score, -out_score)
+    print(f"in score samples (random sampled): {in_score[:3]}, out score samples: {out_score[:3]}")
+    auroc_list.append(auroc)
+    aupr_list.append(aupr)
+    fpr_list.append(fpr)
+    print_measures(log, auroc, aupr, fpr, args.score)

@@ -1,0 +1,93 @@
+"""Image-sharded data parallelism: one process per GPU, RCCL (backend "nccl") over xGMI.
+
+The path shards as independent units: an image's score depends only on that image and the
+replicated prompt bank.  No collective sits on the data path; each dataset
+ends with ONE all-gather of the per-rank score shards (≤25 KB/rank — latency-bound), after
+which every rank holds the full score vector in the reference's sample order.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import numpy as np
+
+
+def world() -> Tuple[int, int]:
+    """(rank, world_size) of the initialised default process group, else (0, 1)."""
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); no-op for 1 process."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous index range of `rank`: [r·ceil(n/W), (r+1)·ceil(n/W)) ∩ [0,n).
+    Concatenating shards in rank order reproduces the dataset order the reference's
+    `shuffle=False` loaders give (utils/train_eval_util.py:96,144)."""
+    per = -(-n // world_size)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def all_gather_scores(local, n_total: int):
+    """All-gather per-rank score shards (contiguous `shard_range` split of n_total) into the
+    full fp32 vector, on every rank.  `local` is a 1-D torch tensor (device for nccl, CPU
+    for gloo) holding this rank's shard."""
+    import torch
+    import torch.distributed as dist
+
+    rank, ws = world()
+    if ws == 1:
+        return local
+    per = -(-n_total // ws)
+    buf = torch.zeros(per, dtype=torch.float32, device=local.device)
+    buf[: local.numel()] = local.to(torch.float32)
+    out = torch.empty(ws * per, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    parts = []
+    for r in range(ws):
+        lo, hi = shard_range(n_total, r, ws)
+        parts.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(parts)
+
+
+def all_gather_histograms(local_scores, edges):
+    """Fixed-bin score histogram summed over ranks (BASELINE.json's "all-gather of per-shard
+    score histograms"): a constant-size payload for streaming AUROC estimates.  Exact
+    AUROC/FPR95 parity uses `all_gather_scores` (the raw scores are just as cheap)."""
+    import torch
+    import torch.distributed as dist
+
+    hist = torch.histogram(local_scores.detach().float().cpu(), bins=torch.as_tensor(edges, dtype=torch.float32))[0]
+    rank, ws = world()
+    if ws > 1:
+        h = hist.to(local_scores.device)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        hist = h.cpu()
+    return hist.numpy().astype(np.int64)

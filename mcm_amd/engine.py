@@ -1,0 +1,233 @@
+"""NativeCLIP — the `net` object of the reference's hot path, backed by libmcm_hip.so.
+
+Mirrors the duck-typed model contract the reference relies on
+(utils/detection_util.py:225,229-230; eval_ood_detection.py:61):
+
+    net.eval()
+    net.get_image_features(pixel_values=FloatTensor[b,3,S,S] on device) -> Tensor[b,P]
+    net.get_text_features(input_ids=LongTensor[K,S], attention_mask=LongTensor[K,S]) -> Tensor[K,P]
+
+returning real, writable fp32 tensors (the reference calls `.float()` and in-place `/=`
+on them), plus the fused path `score_images` that the re-written `get_ood_scores_clip`
+uses so the [B,K] softmax never leaves the GPU.
+
+PyTorch is plumbing only: it owns device buffers and the current HIP stream; every FLOP
+of the path runs in the hand-written gfx950 kernels behind the C ABI (include/mcm.h).
+There is no CPU or eager fallback — a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from .config import CConfig, ClipGeometry, PREC_BF16, PREC_F32, SCORE_KINDS, geometry
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcm_hip.so")
+KERNEL_CLASSES = ["patchify", "gemm", "layernorm", "attention", "pool_project", "score", "embed"]
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libmcm_hip.so and declare the C ABI (include/mcm.h).  Raises loudly when the
+    extension has not been built — the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C mcm_amd/csrc).  mcm_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    L.mcm_abi_version.restype = i32
+    L.mcm_create.argtypes = [ctypes.POINTER(CConfig), ctypes.POINTER(vp)]
+    L.mcm_destroy.argtypes = [vp]
+    L.mcm_destroy.restype = None
+    L.mcm_last_error.argtypes = [vp]
+    L.mcm_last_error.restype = ctypes.c_char_p
+    L.mcm_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
+    L.mcm_finalize_weights.argtypes = [vp]
+    L.mcm_encode_text.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.mcm_encode_image.argtypes = [vp, vp, i32, vp, vp]
+    L.mcm_score_features.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
+    L.mcm_score.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
+    L.mcm_profile_enable.argtypes = [vp, i32]
+    L.mcm_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
+    L.mcm_op_linear.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
+    L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    if L.mcm_abi_version() != 1:
+        raise RuntimeError("libmcm_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "mcm_abi_version", "mcm_create", "mcm_destroy", "mcm_last_error", "mcm_set_weight",
+    "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
+    "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
+    "mcm_op_attention",
+]
+
+
+def _stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NativeCLIP:
+    """CLIP towers + MCM scoring tail on one MI355X."""
+
+    def __init__(self, geo: ClipGeometry | str, state_dict: Dict[str, np.ndarray], *,
+                 device: int = 0, precision: str = "bf16", max_batch: int = 512,
+                 max_prompt_tokens: int = 1024 * 77):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeCLIP needs a HIP device (no CPU fallback)")
+        self.geo = geometry(geo) if isinstance(geo, str) else geo
+        self.device = torch.device("cuda", device)
+        self.precision = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}[precision]
+        self.max_batch = int(max_batch)
+        self._lib = load_library()
+        torch.cuda.set_device(self.device)
+        torch.cuda.init()
+        self._cfg = self.geo.to_c(device=device, precision=self.precision, max_batch=max_batch,
+                                  max_prompt_tokens=max_prompt_tokens)
+        self._h = ctypes.c_void_p()
+        rc = self._lib.mcm_create(ctypes.byref(self._cfg), ctypes.byref(self._h))
+        if rc:
+            raise RuntimeError(f"mcm_create rc={rc}: {self._lib.mcm_last_error(None).decode()}")
+        for name, arr in state_dict.items():
+            if name == "logit_scale" or name.endswith("position_ids"):
+                continue  # unused by MCM (reference utils/detection_util.py:232) / HF buffers
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._check(self._lib.mcm_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                                 shape, a.ndim))
+        self._check(self._lib.mcm_finalize_weights(self._h))
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc:
+            raise RuntimeError(f"libmcm_hip rc={rc}: {self._lib.mcm_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mcm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self):  # reference eval_ood_detection.py:61
+        return self
+
+    def _pixels(self, pixel_values):
+        import torch
+
+        S = self.geo.image_size
+        if pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (3, S, S):
+            # HF modeling_clip.py:204-207 raises ValueError on a wrong image size
+            raise ValueError(f"Input image size {tuple(pixel_values.shape)} doesn't match model (3x{S}x{S}).")
+        return pixel_values.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # -- the model contract ----------------------------------------------------------------
+    def get_image_features(self, pixel_values, normalize: bool = False):
+        """[b,3,S,S] → [b,P] fp32.  The kernel emits L2-normalised rows (the reference
+        normalises right after, utils/detection_util.py:226); with normalize=False the
+        result is still unit-norm, which the reference's `/= norm` leaves unchanged."""
+        import torch
+
+        px = self._pixels(pixel_values)
+        out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
+        for s in range(0, px.shape[0], self.max_batch):
+            n = min(self.max_batch, px.shape[0] - s)
+            self._check(self._lib.mcm_encode_image(self._h, px[s:s + n].data_ptr(), n,
+                                                   out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def get_text_features(self, input_ids, attention_mask=None, normalize: bool = False):
+        """[K,S] ids → [K,P] fp32 unit-norm rows.  `attention_mask` is accepted for
+        signature parity and ignored: the mask is causal and the pooled row is the first
+        EOS, so pads never influence it (golden KAT)."""
+        import torch
+
+        ids = np.ascontiguousarray(input_ids.detach().cpu().numpy() if hasattr(input_ids, "detach")
+                                   else np.asarray(input_ids), dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be [K,S]")
+        K, S = ids.shape
+        if S > self.geo.max_positions:  # HF modeling_clip.py:241-245
+            raise ValueError(f"Sequence length must be less than max_position_embeddings (got {S})")
+        out = torch.empty((K, self.geo.proj_dim), device=self.device, dtype=torch.float32)
+        self._check(self._lib.mcm_encode_text(self._h, ids.ctypes.data_as(ctypes.c_void_p), K, S,
+                                              out.data_ptr(), _stream_ptr()))
+        return out
+
+    # -- fused hot-loop body -----------------------------------------------------------------
+    def score_features(self, image_features, text_features, T: float = 1.0, score: str = "MCM"):
+        import torch
+
+        f = image_features.to(device=self.device, dtype=torch.float32).contiguous()
+        t = text_features.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(f.shape[0], device=self.device, dtype=torch.float32)
+        self._check(self._lib.mcm_score_features(self._h, f.data_ptr(), f.shape[0], t.data_ptr(),
+                                                 t.shape[0], float(T), SCORE_KINDS[score],
+                                                 out.data_ptr(), _stream_ptr()))
+        return out
+
+    def score_images(self, pixel_values, text_features, T: float = 1.0, score: str = "MCM", out=None):
+        """pixels [b,3,S,S] + pre-encoded bank [K,P] → scores [b] fp32 on device (one
+        iteration of the reference loop, utils/detection_util.py:223-248)."""
+        import torch
+
+        px = self._pixels(pixel_values)
+        t = text_features
+        if out is None:
+            out = torch.empty(px.shape[0], device=self.device, dtype=torch.float32)
+        for s in range(0, px.shape[0], self.max_batch):
+            n = min(self.max_batch, px.shape[0] - s)
+            self._check(self._lib.mcm_score(self._h, px[s:s + n].data_ptr(), n, t.data_ptr(), t.shape[0],
+                                            float(T), SCORE_KINDS[score], out[s:s + n].data_ptr(),
+                                            _stream_ptr()))
+        return out
+
+    # -- per-kernel timing -------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self._lib.mcm_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        n = len(KERNEL_CLASSES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        fl = (ctypes.c_double * n)()
+        self._check(self._lib.mcm_profile_read(self._h, ms, cnt, fl))
+        return {k: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i]}
+                for i, k in enumerate(KERNEL_CLASSES)}
+
+
+def build_model(ckpt: str = "ViT-B/16", *, weights: Optional[str] = None, seed: int = 0,
+                **kw) -> NativeCLIP:
+    """`set_model_clip` counterpart (reference utils/train_eval_util.py:15-36): checkpoint
+    name → NativeCLIP.  `weights` = path to a real checkpoint; default = seeded synthetic
+    parameters (no checkpoint exists offline)."""
+    from .weights import load_state_dict_file, synth_state_dict
+
+    geo = geometry(ckpt)
+    sd = load_state_dict_file(weights, geo) if weights else synth_state_dict(geo, seed)
+    return NativeCLIP(geo, sd, **kw)

@@ -95,6 +95,10 @@ class SyntheticLoader:
     def __len__(self) -> int:
         return max(0, -(-(self.hi - self.lo) // self.batch_size))
 
+    def shard(self, lo: int, hi: int) -> "SyntheticLoader":
+        """Loader over the sub-range [lo, hi) of the same dataset (per-rank shard)."""
+        return SyntheticLoader(self.dataset, self.batch_size, lo, hi)
+
     def __iter__(self) -> Iterator:
         import torch
 
@@ -118,6 +122,10 @@ class DeviceNoiseLoader:
 
     def __len__(self) -> int:
         return max(0, -(-(self.hi - self.lo) // self.batch_size))
+
+    def shard(self, lo: int, hi: int) -> "DeviceNoiseLoader":
+        return DeviceNoiseLoader(len(self.dataset), self.dataset.size, self.batch_size, self.device,
+                                 self.seed, lo, hi)
 
     def __iter__(self) -> Iterator:
         import torch

@@ -1,0 +1,188 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel of the path, called through the
+C ABI's operator-level entry points (include/mcm.h), against the CPU oracle on the same
+seeded inputs.  bf16-mode comparisons feed the oracle the bf16-rounded operands, so the
+only differences left are fp32 accumulation order and the bf16 rounding of outputs.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _bf16_round(a: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+@pytest.fixture(scope="module")
+def tiny_net():
+    from mcm_amd.engine import NativeCLIP
+    from mcm_amd.config import geometry
+    from mcm_amd.weights import synth_state_dict
+
+    geo = geometry("tiny")
+    net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=64,
+                     max_prompt_tokens=4096)
+    yield net
+    net.close()
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("D", [128, 512, 768, 1024])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_layernorm(tiny_net, D, prec):
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(D)
+    M = 203
+    x = (rng.standard_normal((M, D)) * 2 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    want = orc.layernorm(x, g, b, 1e-5)
+    p = 0 if prec == "bf16" else 1
+    y = torch.empty((M, D), device="cuda", dtype=torch.bfloat16 if p == 0 else torch.float32)
+    xd, gd, bd = _dev(x), _dev(g), _dev(b)
+    rc = tiny_net._lib.mcm_op_layernorm(tiny_net._h, p, _ptr(xd), _ptr(gd), _ptr(bd), _ptr(y), M, D,
+                                        1e-5, 0, None)
+    assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    if p == 0:
+        np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
+        assert np.abs(got - _bf16_round(want)).max() <= 2 ** -6  # ≤ 1 bf16 ulp at |x|<4
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # in-place fp32 (pre_layrnorm form)
+    z = xd.clone()
+    rc = tiny_net._lib.mcm_op_layernorm(tiny_net._h, p, _ptr(z), _ptr(gd), _ptr(bd), _ptr(z), M, D, 1e-5,
+                                        1, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(z.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+GEMM_SHAPES = [
+    (128, 128, 64),       # one tile, one K-step (bf16) / two (fp32)
+    (300, 256, 128),      # ragged M
+    (591, 2304, 768),     # 3 B/16 images through the QKV projection
+    (197, 768, 3072),     # fc2 shape, long K
+    (50, 192, 128),       # N not a multiple of the 128 tile (masked columns)
+    (1000, 1536, 512),    # text-tower QKV
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_linear(tiny_net, M, N, K, prec, epi):
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(M * 7 + N * 3 + K + epi)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)  # asymmetric by construction
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    resid0 = rng.standard_normal((M, N)).astype(np.float32)
+    p = 0 if prec == "bf16" else 1
+    if p == 0:
+        x, w = _bf16_round(x), _bf16_round(w)
+    lin = orc.linear(x, w, bias)
+    dt = torch.bfloat16 if p == 0 else torch.float32
+    xd, wd, bd = _dev(x, dt), _dev(w, dt), _dev(bias)
+    y = torch.zeros((M, N), device="cuda", dtype=dt)
+    rd = _dev(resid0)
+    rc = tiny_net._lib.mcm_op_linear(tiny_net._h, p, _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), _ptr(rd), M, N,
+                                     K, epi, None)
+    assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+    torch.cuda.synchronize()
+    if epi == 0:
+        got, want = y.float().cpu().numpy(), lin
+    elif epi == 1:
+        got, want = y.float().cpu().numpy(), orc.quick_gelu(lin)
+    else:
+        got, want = rd.cpu().numpy(), resid0 + lin
+    if p == 0 and epi != 2:
+        np.testing.assert_allclose(got, want, rtol=1.2e-2, atol=1.2e-2)  # bf16 output rounding
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)      # fp32 accumulation order
+
+
+ATTN_CASES = [(3, 197, 12, False), (2, 50, 12, False), (5, 17, 2, False), (4, 77, 8, True),
+              (6, 16, 8, True), (2, 257, 16, False), (3, 33, 2, True)]
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", ATTN_CASES)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention(tiny_net, nseq, L, heads, causal, prec):
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(L * 31 + heads)
+    D = heads * 64
+    qkv = rng.standard_normal((nseq * L, 3 * D)).astype(np.float32)
+    qkv[:, :2 * D] *= 1.5  # O(1)-spread logits after the 0.125 scale: a non-uniform softmax
+    p = 0 if prec == "bf16" else 1
+    if p == 0:
+        qkv = _bf16_round(qkv)
+    want = orc.attention(qkv, nseq, L, heads, 64, causal)
+    dt = torch.bfloat16 if p == 0 else torch.float32
+    qd = _dev(qkv, dt)
+    out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
+    rc = tiny_net._lib.mcm_op_attention(tiny_net._h, p, _ptr(qd), _ptr(out), nseq, L, heads, int(causal), None)
+    assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    if p == 0:
+        np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)  # bf16 P and bf16 output
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_spiked_logits(tiny_net):
+    """One key dominating a row (softmax ~ one-hot) and large negative logits elsewhere."""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(5)
+    nseq, L, heads = 1, 197, 2
+    D = heads * 64
+    qkv = rng.standard_normal((L, 3 * D)).astype(np.float32)
+    qkv[7, :D] *= 20.0          # query 7 is huge
+    qkv[100, D:2 * D] *= 10.0   # key 100 is huge
+    qkv = _bf16_round(qkv)
+    want = orc.attention(qkv, nseq, L, heads, 64, False)
+    qd = _dev(qkv, torch.bfloat16)
+    out = torch.zeros((L, D), device="cuda", dtype=torch.bfloat16)
+    rc = tiny_net._lib.mcm_op_attention(tiny_net._h, 0, _ptr(qd), _ptr(out), nseq, L, heads, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("K", [10, 37, 100, 1000])
+@pytest.mark.parametrize("T", [1.0, 2.0, 0.01])
+def test_score_kinds(tiny_net, K, T):
+    from mcm_amd.config import SCORE_KINDS
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(K)
+    P, B = tiny_net.geo.proj_dim, 33
+    img = rng.standard_normal((B, P)).astype(np.float32)
+    img /= np.linalg.norm(img, axis=1, keepdims=True)
+    txt = rng.standard_normal((K, P)).astype(np.float32)
+    txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+    for name, kind in SCORE_KINDS.items():
+        want = orc.score_features(img, txt, T, kind)
+        got = tiny_net.score_features(_dev(img), _dev(txt), T, name).cpu().numpy()
+        tol = dict(rtol=3e-5, atol=1e-6) if name != "var" else dict(rtol=2e-3, atol=1e-10)
+        np.testing.assert_allclose(got, want, err_msg=f"{name} K={K} T={T}", **tol)
