@@ -122,15 +122,12 @@ def test_get_ood_scores_clip_vs_reference_outputs(golden_dir, precision):
         net.close()
 
 
-def test_auroc_parity_bf16_vs_oracle_b16_2l():
-    """AUROC / FPR95 of the bf16 path vs the fp32 oracle on a 2-layer full-width B/16 with a
-    few hundred synthetic ID/OOD images (north-star bar: 1e-4 — measured, not assumed)."""
+def _auroc_case(name, K, n, precisions):
     from mcm_amd.metrics import get_measures
     from oracle import oracle as orc
 
-    geo = geometry("B16-2L")
+    geo = geometry(name)
     sd = synth_state_dict(geo, 0)
-    K, n = 20, 96
     ids, _ = make_token_ids(K, seed=2)
     o = orc.OracleCLIP(geo, sd)
     txt_o = o.encode_text(ids)
@@ -140,8 +137,8 @@ def test_auroc_parity_bf16_vs_oracle_b16_2l():
     want_out = orc.score_features(o.encode_image(px_out), txt_o, 1.0, 0)
     want = np.array(get_measures(-want_in, -want_out))
     report = {}
-    for precision in ("fp32", "bf16"):
-        net = _net("B16-2L", precision, max_batch=96, max_prompt_tokens=2048)
+    for precision in precisions:
+        net = _net(name, precision, max_batch=256, max_prompt_tokens=2048)
         try:
             txt = net.get_text_features(input_ids=torch.from_numpy(ids))
             s_in = net.score_images(torch.from_numpy(px_in).cuda(), txt, 1.0, "MCM").cpu().numpy()
@@ -149,14 +146,29 @@ def test_auroc_parity_bf16_vs_oracle_b16_2l():
         finally:
             net.close()
         got = np.array(get_measures(-s_in, -s_out))
-        report[precision] = (np.abs(got - want), np.abs(s_in - want_in).max())
-        if precision == "fp32":
-            np.testing.assert_allclose(s_in, want_in, rtol=2e-5, atol=1e-6)
-            np.testing.assert_allclose(got, want, atol=1e-4)
-        else:
-            # 192 samples → AUROC quantum 1/(96*96)=1.1e-4, FPR quantum 1/96
-            assert abs(got[0] - want[0]) <= 5e-3, report
-    print("AUROC/AUPR/FPR95 |delta| and max|dscore|:", report)
+        report[precision] = dict(d_auroc_aupr_fpr=np.abs(got - want), max_dscore=np.abs(s_in - want_in).max(),
+                                 oracle=want)
+    return report
+
+
+def test_auroc_parity_vs_oracle_large_sample():
+    """North-star bar |ΔAUROC|, |ΔFPR95| ≤ 1e-4 vs the fp32 oracle, on a sample large enough
+    that 1e-4 is above the metric quantum (tiny geometry: 2x1500 images, oracle in seconds)."""
+    rep = _auroc_case("tiny", K=20, n=1500, precisions=("fp32", "bf16"))
+    print("tiny n=1500:", rep)
+    assert 0.05 < rep["fp32"]["oracle"][0] < 0.95  # non-degenerate AUROC
+    assert rep["fp32"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
+    d = rep["bf16"]["d_auroc_aupr_fpr"]
+    assert d[0] <= 1e-3 and d[2] <= 5e-3, rep  # bf16 operands: measured drift, see DESIGN.md
+
+
+def test_auroc_parity_vs_oracle_b16_2l():
+    """Same on a 2-layer full-width B/16 (2x96 images: AUROC quantum 1.1e-4, FPR quantum 1e-2)."""
+    rep = _auroc_case("B16-2L", K=20, n=96, precisions=("fp32", "bf16"))
+    print("B16-2L n=96:", rep)
+    assert rep["fp32"]["max_dscore"] < 1e-6
+    assert rep["fp32"]["d_auroc_aupr_fpr"][0] <= 2.5e-4, rep   # ≤ 2 pair swaps
+    assert rep["bf16"]["d_auroc_aupr_fpr"][0] <= 5e-3, rep
 
 
 @pytest.fixture(scope="module")
