@@ -175,6 +175,12 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
                      int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
                      void* stream);
 
+/* Testing hook: force the GEMM kernel variant (-1 auto [default], 0 = 128x128 tile kernel,
+ * 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 3/4 = persistent 256x256
+ * 2-stage (4: counted epilogue stores)).  Process-wide.
+ * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
+int mcm_debug_gemm_variant(int32_t variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,25 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// LDS-DMA, 16 B per lane: lane i's 16 bytes at `gsrc` land at LDS byte address lds_base + 16*i
+// (lds_base wave-uniform).  Inline asm on purpose: hipcc drains vmcnt(0) before ANY ds_read
+// that follows a __builtin_amdgcn_global_load_lds (it cannot prove the LDS read does not
+// alias the DMA destination), which serialises a multi-stage pipeline.  An asm DMA is
+// invisible to that pass; the kernel counts it itself: s_waitcnt vmcnt(N) → s_barrier →
+// ds_read (guide §5.7).  M0 is compiler-reserved, so it is saved and restored here.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // QuickGELU: x * sigmoid(1.702 x)  (transformers activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
@@ -63,8 +82,13 @@ struct GemmArgs {
   int ldx;            // elements
   int ldo;            // elements (row stride of out / resid)
   int np;             // EPI_PATCH: patches per image
+  int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
+  int dbg;            // ablation bits (bench harness only): 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
+void gemm_set_group_n(int gn);
+void gemm_set_dbg(int d);
+void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s);

@@ -5,38 +5,181 @@
 // conv (:148-154, non-overlapping patches = a GEMM over gathered rows).  X and W are both
 // K-contiguous ("B^T input"), so A- and B-fragments are read from LDS the same way.
 //
-// Structure (v1): 128x128 output tile, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA
-// fragments of 16x16; one K-step = 128 bytes of K per row (64 bf16 or 32 fp32), so the
-// LDS image, the staging code and the fragment reads are identical for both precisions:
+// One K-step = 128 bytes of K per row (64 bf16 or 32 fp32), so the LDS image, the staging
+// code and the fragment reads are identical for both precisions:
 //   bf16: 2 x v_mfma_f32_16x16x32_bf16 per fragment pair and K-step
 //   fp32: 8 x v_mfma_f32_16x16x4_f32   (exact fp32 = fmaf chain; the parity arm)
-// Global→LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction), two
-// stages, next K-step in flight under the MFMAs, one barrier per K-step.
+// Global→LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction), issued from
+// inline asm and counted by hand (common.hpp glds16: the builtin form makes hipcc drain
+// vmcnt(0) before every ds_read, i.e. no load/MFMA overlap at all).
 //
-// LDS layout (per operand tile, 128 rows x 128 B): rows are paired into 256-B bank rows
-// and the 16-B chunk index is XORed with the pair index, so the four 16-lane groups of
-// a ds_read_b128 fragment read (16 rows x one chunk) hit 16 distinct 16-B slots:
+// LDS layout (per operand tile, R rows x 128 B): rows are paired into 256-B bank rows and
+// the 16-B chunk index is XORed with the pair index, so the four 16-lane groups of a
+// ds_read_b128 fragment read (16 rows x one chunk) hit 16 distinct 16-B slots:
 //   off(r, c) = (r>>1)*256 + ((((r&1)<<3) | ((c ^ (r>>1)) & 7)) << 4)
 // LDS-DMA writes lane-linear, so the permutation is applied to each lane's *global*
 // source address (guide rule 21: linear dest + inverse-swizzled source + swizzled read).
 //
 // MFMA operand order is swapped (W fragment as A, X fragment as B) so each lane ends up
 // with 4 consecutive output columns of one row: 16-B fp32 / 8-B bf16 epilogue accesses.
+//
+// Two kernels share the fragment/epilogue code:
+//   gemm_tile_kernel     128x128 tile, 4 waves, 2 LDS stages, one workgroup per tile,
+//                        2 workgroups/CU.  Small problems (text tower, tests).
+//   gemm_persist_kernel  256x128 tile, 8 waves (4x2), 3 LDS stages (144 KiB), ONE
+//                        persistent workgroup per CU walking its tiles; the LDS-DMA stream
+//                        runs two K-steps ahead with counted vmcnt and keeps running across
+//                        tile boundaries, so the next tile's operands land under the
+//                        current tile's epilogue.  Tiles are dealt XCD-first (an XCD's 32
+//                        CUs share X row panels in their private L2).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 
+constexpr int ROWB = 128;  // bytes of K per row per K-step
+
+__device__ __forceinline__ int frag_off(int fr, int g, int kk) {
+  return (fr >> 1) * 256 + ((((fr & 1) << 3) | (((kk * 4 + g) ^ (fr >> 1)) & 7)) << 4);
+}
+
+// one K-step of a (MF*16)x64 wave tile: MF x 4 fragments, operands at xs / ws (+ f*2048 per
+// 16 rows); x fragments are consumed four at a time to bound live registers
+template <int PREC, int MF>
+__device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const int (&foff)[2],
+                                           f32x4_t (&acc)[4][MF]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    uint4 wf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) wf[f] = *(const uint4*)(ws + f * 2048 + foff[kk]);
+#pragma unroll
+    for (int h = 0; h < MF / 4; ++h) {
+    uint4 xf[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xf[f] = *(const uint4*)(xs + (h * 4 + f) * 2048 + foff[kk]);
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+      for (int fq = 0; fq < 4; ++fq) {
+        const int fi = h * 4 + fq;
+        if constexpr (PREC == MCM_PREC_BF16) {
+          acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, wf[fj]), __builtin_bit_cast(bf16x8_t, xf[fq]),
+              acc[fj][fi], 0, 0, 0);
+        } else {
+          const f32x4_t wv = __builtin_bit_cast(f32x4_t, wf[fj]);
+          const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[fq]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], acc[fj][fi], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// W rows are staged into LDS in a permuted order (perm_n below) so that, after the MFMAs, a
+// lane holds 16 CONSECUTIVE output columns of one row: fragment fj, accumulator register r
+// of lane (fr, g) is column  nw + g*16 + fj*4 + r.  The epilogue then moves 32 B (bf16) /
+// 64 B (fp32) contiguous per lane and the 4 g-lanes of a row cover whole 128-B lines.
+// LDS row lr (0..63 inside a wave's 64-column panel) holds tile column perm_n(lr).
+__device__ __forceinline__ int perm_n(int lr) {
+  return ((lr >> 2) & 3) * 16 + (lr >> 4) * 4 + (lr & 3);
+}
+
+// epilogue of a (MF*16)x64 wave tile at (mw, nw)
+template <int PREC, int EPI, int MF>
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
+                                              const f32x4_t (&bv)[4], int mw, int nw, int fr, int g) {
+  const int n = nw + g * 16;
+  if (n >= a.N) return;
+#pragma unroll
+  for (int fi = 0; fi < MF; ++fi) {
+    const int m = mw + fi * 16 + fr;
+    if (m >= a.M) continue;
+    f32x4_t v[4];
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+      v[fj] = acc[fj][fi] + bv[fj];
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu(v[fj][t]);
+      }
+    }
+    if constexpr (EPI == EPI_RESID) {
+      f32x4_t* dst = (f32x4_t*)(a.resid + (size_t)m * a.ldo + n);
+      f32x4_t r[4];
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) r[fj] = dst[fj];
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) dst[fj] = r[fj] + v[fj];
+    } else if constexpr (EPI == EPI_PATCH) {
+      const int b = m / a.np, p = m - b * a.np;
+      f32x4_t* dst = (f32x4_t*)((float*)a.out + (size_t)(b * (a.np + 1) + 1 + p) * a.ldo + n);
+      const f32x4_t* pr = (const f32x4_t*)(a.pos + (size_t)(1 + p) * a.N + n);
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) dst[fj] = v[fj] + pr[fj];
+    } else if constexpr (PREC == MCM_PREC_BF16) {
+      uint4* dst = (uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n);
+      dst[0] = make_uint4(pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]),
+                          pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3]));
+      dst[1] = make_uint4(pack_bf2(v[2][0], v[2][1]), pack_bf2(v[2][2], v[2][3]),
+                          pack_bf2(v[3][0], v[3][1]), pack_bf2(v[3][2], v[3][3]));
+    } else {
+      f32x4_t* dst = (f32x4_t*)((float*)a.out + (size_t)m * a.ldo + n);
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) dst[fj] = v[fj];
+    }
+  }
+}
+
+// bias of the 16 columns a lane owns.  Plain loads, made "consumed" immediately so that no
+// compiler-visible VMEM load is ever pending across a loop back-edge (hipcc would then put
+// s_waitcnt vmcnt(0) in front of unrelated instructions that reuse the registers and drain
+// the hand-counted LDS-DMA pipeline every K-step).
+__device__ __forceinline__ void load_bias(const GemmArgs& a, int n, f32x4_t (&bv)[4]) {
+  const int nc = min(n, a.N - 16);
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) {
+    bv[fj] = a.bias ? *(const f32x4_t*)(a.bias + nc + fj * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+}
+// the same through inline asm: invisible to hipcc's waitcnt pass, counted by the caller
+// (4 VMEM ops per wave); the values may be read only after a covering s_waitcnt vmcnt.
+__device__ __forceinline__ void load_bias_async(const GemmArgs& a, int n, f32x4_t (&bv)[4]) {
+  const float* p = a.bias + min(n, a.N - 16);
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[fj]) : "v"(p + fj * 4) : "memory");
+}
+
+template <int MF>
+__device__ __forceinline__ void zero_acc(f32x4_t (&acc)[4][MF]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+}
+
+// =========================================================================================
+// 128x128 tile kernel (one workgroup per tile)
+// =========================================================================================
+namespace tile {
 constexpr int BM = 128, BN = 128;
-constexpr int ROWB = 128;               // bytes of K per row per K-step
-constexpr int TILE_BYTES = BM * ROWB;   // 16 KiB per operand per stage
+constexpr int TILE_BYTES = BM * ROWB;
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int NSTAGE = 2;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+}  // namespace tile
 
 template <int PREC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
+  using namespace tile;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -53,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
   const int m0 = (lid / nbn) * BM;
   const int n0 = (lid % nbn) * BN;
 
-  // ---- staging addresses: 4 LDS-DMA pieces per operand per wave per K-step
   const char* gx[4];
   const char* gw[4];
 #pragma unroll
@@ -64,38 +206,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     const int row = 2 * p + (s >> 3);
     const int chunk = (s & 7) ^ (p & 7);
     const int mr = min(m0 + row, a.M - 1);
-    const int nr = min(n0 + row, a.N - 1);
+    const int nr = min(n0 + (row & 64) + perm_n(row & 63), a.N - 1);
     gx[i] = (const char*)a.x + ((size_t)mr * a.ldx) * ES + chunk * 16;
     gw[i] = (const char*)a.w + ((size_t)nr * a.K) * ES + chunk * 16;
   }
+  const uint32_t lds0 = lds_addr(smem);
   auto stage = [&](int st, int kt) {
-    char* base = smem + st * STAGE_BYTES;
+    const uint32_t base = lds0 + st * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int blk = i * 4 + wave;
-      __builtin_amdgcn_global_load_lds((gptr_t)(gx[i] + (size_t)kt * ROWB),
-                                       (lptr_t)(base + blk * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(gw[i] + (size_t)kt * ROWB),
-                                       (lptr_t)(base + TILE_BYTES + blk * 1024), 16, 0, 0);
+      glds16(gx[i] + (size_t)kt * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+      glds16(gw[i] + (size_t)kt * ROWB,
+             __builtin_amdgcn_readfirstlane(base + TILE_BYTES + blk * 1024));
     }
   };
 
-  // ---- fragment read offsets (lane part; + f*2048 per 16-row fragment)
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, g = lane >> 4;
-  int foff[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-    foff[kk] = (fr >> 1) * 256 + ((((fr & 1) << 3) | (((kk * 4 + g) ^ (fr >> 1)) & 7)) << 4);
-  const int xbase = wr * 64 * ROWB;                // rows wr*64.. of the X tile
-  const int wbase = TILE_BYTES + wc * 64 * ROWB;   // rows wc*64.. of the W tile
+  const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
+  const int xbase = wr * 64 * ROWB;
+  const int wbase = TILE_BYTES + wc * 64 * ROWB;
 
-  f32x4_t acc[4][4];  // [fj = n fragment][fi = m fragment]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
+  f32x4_t acc[4][4];
+  zero_acc(acc);
   const int nk = (a.K * ES) / ROWB;
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -103,91 +237,377 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     __syncthreads();
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* sb = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      uint4 xf[4], wf[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        xf[f] = *(const uint4*)(sb + xbase + f * 2048 + foff[kk]);
-        wf[f] = *(const uint4*)(sb + wbase + f * 2048 + foff[kk]);
-      }
-#pragma unroll
-      for (int fj = 0; fj < 4; ++fj)
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) {
-          if constexpr (PREC == MCM_PREC_BF16) {
-            acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8_t, wf[fj]), __builtin_bit_cast(bf16x8_t, xf[fi]),
-                acc[fj][fi], 0, 0, 0);
-          } else {
-            const f32x4_t wv = __builtin_bit_cast(f32x4_t, wf[fj]);
-            const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[fi]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], acc[fj][fi], 0, 0, 0);
-          }
-        }
-    }
+    wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
   }
+  f32x4_t bv[4];
+  load_bias(a, n0 + wc * 64 + g * 16, bv);
+  wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g);
+}
 
-  // ---- epilogue: lane holds Y[m][n..n+3], m = m0+wr*64+fi*16+fr, n = n0+wc*64+fj*16+g*4
-#pragma unroll
-  for (int fi = 0; fi < 4; ++fi) {
-    const int m = m0 + wr * 64 + fi * 16 + fr;
-    if (m >= a.M) continue;
-    size_t orow;
-    const float* prow = nullptr;
-    if constexpr (EPI == EPI_PATCH) {
-      const int b = m / a.np, p = m - b * a.np;
-      orow = (size_t)(b * (a.np + 1) + 1 + p) * a.ldo;
-      prow = a.pos + (size_t)(1 + p) * a.N;
-    } else {
-      orow = (size_t)m * a.ldo;
+// =========================================================================================
+// persistent 256x128 kernel, 3-stage LDS-DMA pipeline running across tile boundaries
+// =========================================================================================
+namespace persist {
+constexpr int BM = 256, BN = 128;
+constexpr int A_BYTES = BM * ROWB;           // 32 KiB
+constexpr int W_BYTES = BN * ROWB;           // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB
+constexpr int LOADS_PER_STAGE = 6;               // LDS-DMA instructions per wave per stage
+}  // namespace persist
+
+// XCD-local tile enumeration: N-tiles are walked in groups of `gn` (the group's W panel
+// stays L2-resident while the XCD sweeps its M-tiles); inside a group the order is
+// (mtl, nt) n-fastest, so the 32 CUs of an XCD hold ~32/gn X row panels x gn W panels.
+__device__ __forceinline__ void tile_of(int q, int nmt_x, int nbn, int gn, int& mtl, int& nt) {
+  int start = 0, g0 = 0;
+  for (;;) {
+    const int gw = min(gn, nbn - g0), cnt = nmt_x * gw;
+    if (q < start + cnt || g0 + gw >= nbn) {
+      const int r = q - start;
+      mtl = r / gw;
+      nt = g0 + (r - mtl * gw);
+      return;
     }
+    start += cnt;
+    g0 += gw;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int PREC, int EPI, bool COUNT_STORES>
+__global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) {
+  using namespace persist;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = prec_esize(PREC);
+  // store instructions per wave per full tile: 4 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
+  constexpr int STORES_PER_EPI = (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) ? 8 : 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
+
+  // ---- tile schedule: M-tiles are striped over the 8 XCDs (mt = mtl*8 + xcd); the G/8
+  // workgroups of an XCD walk that XCD's (mtl, nt) list n-fastest, so concurrently running
+  // CUs of one XCD share X row panels through their L2.
+  const int nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nmt_x = (nbm - xcd + 7) >> 3;
+  const int ntl_x = nmt_x * nbn;
+  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
+  if (ntl == 0) return;
+  const int nk = (a.K * ES) / ROWB;
+  const int total = ntl * nk;
+
+  // ---- LDS-DMA source geometry of this lane (constant): piece i covers tile rows
+  // i*64 + r0, 16-B chunk `chunk` (swizzled)
+  const int r0 = wave * 8 + (lane >> 4) * 2 + ((lane & 15) >> 3);
+  const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+  const char* gx[4];
+  const char* gw[2];
+  int ji = 0, kti = 0;  // issue cursor: tile index (of this workgroup) and K-step
+  auto set_issue_tile = [&](int i) {
+    int mtl, nt;
+    tile_of(jx + i * G8, nmt_x, nbn, a.gn, mtl, nt);
+    const int m0 = (mtl * 8 + xcd) * BM, n0 = nt * BN;
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-      const int n = n0 + wc * 64 + fj * 16 + g * 4;
-      if (n >= a.N) continue;
-      f32x4_t v = acc[fj][fi];
-      if (a.bias) {
-        const f32x4_t bv = *(const f32x4_t*)(a.bias + n);
-        v += bv;
-      }
-      if constexpr (EPI == EPI_GELU) {
+    for (int p = 0; p < 4; ++p)
+      gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
-      }
-      if constexpr (EPI == EPI_RESID) {
-        f32x4_t* dst = (f32x4_t*)(a.resid + orow + n);
-        *dst = *dst + v;
-      } else if constexpr (EPI == EPI_PATCH) {
-        v += *(const f32x4_t*)(prow + n);
-        *(f32x4_t*)((float*)a.out + orow + n) = v;
-      } else if constexpr (PREC == MCM_PREC_BF16) {
-        uint2 pk;
-        pk.x = pack_bf2(v[0], v[1]);
-        pk.y = pack_bf2(v[2], v[3]);
-        *(uint2*)((uint16_t*)a.out + orow + n) = pk;
-      } else {
-        *(f32x4_t*)((float*)a.out + orow + n) = v;
+    for (int p = 0; p < 2; ++p)
+      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + ((a.dbg & 8) ? r0 : perm_n(r0)), a.N - 1) * a.K) * ES + chunk * 16;
+  };
+  const uint32_t lds0 = lds_addr(smem);
+  auto issue = [&](int st) {
+    const uint32_t base = lds0 + st * STAGE_BYTES;
+    const size_t ko = (size_t)kti * ROWB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      glds16(gx[p] + ko, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
+    if (++kti == nk) {
+      kti = 0;
+      if (++ji < ntl) set_issue_tile(ji);
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, g = lane >> 4;
+  const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
+  const int xbase = wr * 64 * ROWB;
+  const int wbase = A_BYTES + wc * 64 * ROWB;
+
+  f32x4_t acc[4][4];
+  zero_acc(acc);
+
+  set_issue_tile(0);
+  int issued = 0;
+  for (; issued < 2 && issued < total; ++issued) issue(issued);
+  int st = 0;          // LDS stage of step s
+  int ist = 2;         // LDS stage the next issue goes to
+  int jc = 0, ktc = 0; // compute cursor
+  int since_epi = 1000;
+  int cm0, cn0;        // origin of the tile being computed
+  {
+    int mtl, nt;
+    tile_of(jx, nmt_x, nbn, a.gn, mtl, nt);
+    cm0 = (mtl * 8 + xcd) * BM;
+    cn0 = nt * BN;
+  }
+  f32x4_t bv[4];
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool counted = nk >= 3;  // short K: every wait is vmcnt(0)
+  for (int s = 0; s < total; ++s) {
+    // Stage s must have landed; everything issued after it may stay in flight.  VMEM issue
+    // order around a tile boundary (tile ends at step e):
+    //   step e  : [DMA stage e+2] ........ [epilogue stores, E per wave]
+    //   step e+1: [bias loads, 4] [DMA stage e+3]
+    //   step e+2: [DMA stage e+4]
+    // so the ops younger than the awaited stage are 6+E at e+1, 10+E at e+2, else 6.
+    if (counted && issued > s + 1) {
+      if (COUNT_STORES && since_epi == 1) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI>();
+      else if (COUNT_STORES && since_epi == 2) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI + 4>();
+      else wait_vmcnt<LOADS_PER_STAGE>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
+    if (issued < total) {  // refill the stage that step s-1 just finished reading
+      if (!(a.dbg & 1)) issue(ist);
+      ist = ist == NSTAGE - 1 ? 0 : ist + 1;
+      ++issued;
+    }
+    const char* sb = smem + st * STAGE_BYTES;
+    if (!(a.dbg & 2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
+    st = st == NSTAGE - 1 ? 0 : st + 1;
+    ++since_epi;
+    if (++ktc == nk) {
+      if (!counted) wait_vmcnt<0>();  // bias was issued in this very tile's first step
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+      if (!(a.dbg & 4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g);
+      zero_acc(acc);
+      // only a full tile issues exactly STORES_PER_EPI stores per wave; ragged tiles fall back
+      // to waiting for the stores as well
+      since_epi = (cm0 + BM <= a.M && cn0 + BN <= a.N) ? 0 : 1000;
+      ktc = 0;
+      if (++jc < ntl) {
+        int mtl, nt;
+        tile_of(jx + jc * G8, nmt_x, nbn, a.gn, mtl, nt);
+        cm0 = (mtl * 8 + xcd) * BM;
+        cn0 = nt * BN;
       }
     }
   }
 }
 
+// =========================================================================================
+// persistent 256x256 kernel: 8 waves as 2(M) x 4(N), wave tile 128x64 (acc = 128 VGPRs),
+// two 64-KiB LDS stages.  One K-step = 64 MFMAs per wave = 2048 MFMA-cycles per SIMD, and
+// the next stage's DMA (issued right after the barrier) has that long to land.  Per flop
+// it moves 2/3 of the L2->LDS bytes of the 256x128 tile: on this chip the L1->LDS path
+// (~64 B/clk/CU) is what bounds the smaller tiles, not the matrix pipe.
+// =========================================================================================
+namespace p256 {
+constexpr int BM = 256, BN = 256;
+constexpr int A_BYTES = BM * ROWB;  // 32 KiB
+constexpr int W_BYTES = BN * ROWB;  // 32 KiB
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // 128 KiB
+}  // namespace p256
+
+template <int PREC, int EPI, bool COUNT_STORES>
+__global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
+  using namespace p256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = prec_esize(PREC);
+  // store instructions per wave per full tile: 8 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
+  constexpr int STORES_PER_EPI = (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) ? 16 : 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nmt_x = (nbm - xcd + 7) >> 3;
+  const int ntl_x = nmt_x * nbn;
+  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
+  if (ntl == 0) return;
+  const int nk = (a.K * ES) / ROWB;
+  const int total = ntl * nk;
+
+  const int r0 = wave * 8 + (lane >> 4) * 2 + ((lane & 15) >> 3);
+  const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+  const char* gx[4];
+  const char* gw[4];
+  int ji = 0, kti = 0;
+  auto set_issue_tile = [&](int i) {
+    int mtl, nt;
+    tile_of(jx + i * G8, nmt_x, nbn, a.gn, mtl, nt);
+    const int m0 = (mtl * 8 + xcd) * BM, n0 = nt * BN;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
+      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * a.K) * ES + chunk * 16;
+    }
+  };
+  const uint32_t lds0 = lds_addr(smem);
+  auto issue = [&](int st) {
+    const uint32_t base = lds0 + st * STAGE_BYTES;
+    const size_t ko = (size_t)kti * ROWB;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      glds16(gx[p] + ko, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
+      glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
+    }
+    if (++kti == nk) {
+      kti = 0;
+      if (++ji < ntl) set_issue_tile(ji);
+    }
+  };
+
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
+  const int fr = lane & 15, g = lane >> 4;
+  const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
+  const int xbase = wr * 128 * ROWB;
+  const int wbase = A_BYTES + wc * 64 * ROWB;
+
+  f32x4_t acc[4][8];
+  zero_acc<8>(acc);
+  f32x4_t bv[4];
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (a.dbg & 16) {
+    // De-phase the persistent workgroups: with identical tile sequences every CU reaches its
+    // epilogue at the same moment and the store bursts serialise on HBM while the matrix pipes
+    // idle.  Spreading the start times over one tile period interleaves one CU's burst with
+    // the others' compute.
+    const long long t0 = __builtin_readcyclecounter();
+    const long long delay = (long long)nk * 2600 * ((blockIdx.x * 41) & 255) / 256;
+    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(8);
+  }
+  set_issue_tile(0);
+  issue(0);
+  int issued = 1;
+  int jc = 0, ktc = 0;
+  int cm0, cn0;
+  {
+    int mtl, nt;
+    tile_of(jx, nmt_x, nbn, a.gn, mtl, nt);
+    cm0 = (mtl * 8 + xcd) * BM;
+    cn0 = nt * BN;
+  }
+  bool stores_pending = false;
+  for (int s = 0; s < total; ++s) {
+    // VMEM issue order: step e (tile end): [DMA stage e+1] ... [stores E]; step e+1:
+    // [bias 4] [DMA stage e+2].  Stage s is the youngest DMA at this point, so only the
+    // previous tile's stores may stay in flight.
+    if (COUNT_STORES && stores_pending) wait_vmcnt<STORES_PER_EPI>();
+    else wait_vmcnt<0>();
+    stores_pending = false;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
+    if (issued < total) {
+      if (!(a.dbg & 1)) issue(issued & 1);
+      ++issued;
+    }
+    const char* sb = smem + (s & 1) * STAGE_BYTES;
+    if (!(a.dbg & 2)) wave_kstep<PREC, 8>(sb + xbase, sb + wbase, foff, acc);
+    if (++ktc == nk) {
+      if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+      if (!(a.dbg & 4) && !((a.dbg & 32) && (blockIdx.x & 56))) wave_epilogue<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, fr, g);
+      zero_acc<8>(acc);
+      stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
+      ktc = 0;
+      if (++jc < ntl) {
+        int mtl, nt;
+        tile_of(jx + jc * G8, nmt_x, nbn, a.gn, mtl, nt);
+        cm0 = (mtl * 8 + xcd) * BM;
+        cn0 = nt * BN;
+      }
+    }
+  }
+}
+
+// ---- launch ------------------------------------------------------------------------------
+
+int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores)
+
+int variant() {
+  static int v = [] {
+    const char* e = getenv("MCM_GEMM_VARIANT");
+    return e ? atoi(e) : -1;
+  }();
+  return g_variant >= 0 ? g_variant : v;
+}
+
 template <int PREC, int EPI>
-hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int lds = NSTAGE * STAGE_BYTES;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<PREC, EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, tile::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int nbn = (a.N + BN - 1) / BN, nbm = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((gemm_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), lds, s, a);
+  const int nbn = (a.N + tile::BN - 1) / tile::BN, nbm = (a.M + tile::BM - 1) / tile::BM;
+  hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
   return hipGetLastError();
+}
+
+template <int PREC, int EPI, bool CS>
+hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<PREC, EPI, CS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, persist::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(256), dim3(512), persist::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+template <int PREC, int EPI, bool CS>
+hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS>), dim3(256), dim3(512), p256::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+template <int PREC, int EPI>
+hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+  int v = variant();
+  if (v < 0) {  // auto: persistent 256x256 kernel once every CU gets >= 4 tiles, else tile kernel
+    const long tiles = (long)((a.M + p256::BM - 1) / p256::BM) * ((a.N + p256::BN - 1) / p256::BN);
+    v = tiles >= 1024 ? 3 : 0;
+  }
+  if (v == 0) return launch_tile<PREC, EPI>(a, s);
+  if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
+  if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
+  if (v == 3) return launch_p256<PREC, EPI, false>(a, s);
+  return launch_p256<PREC, EPI, true>(a, s);
 }
 
 template <int PREC>
@@ -203,7 +623,17 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s) {
+void gemm_set_variant(int v) { g_variant = v; }
+
+int g_group_n = 32;
+int g_dbg = 0;
+void gemm_set_dbg(int d) { g_dbg = d; }
+void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 1; }
+
+hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
+  GemmArgs a = a_in;
+  if (a.gn <= 0) a.gn = g_group_n;
+  a.dbg = g_dbg;
   const int es = prec_esize(prec);
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)

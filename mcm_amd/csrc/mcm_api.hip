@@ -530,4 +530,10 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
   return MCM_OK;
 }
 
+int mcm_debug_gemm_variant(int32_t variant) {
+  if (variant < -1 || variant > 4) return MCM_EINVAL;
+  gemm_set_variant(variant);
+  return MCM_OK;
+}
+
 }  // extern "C"

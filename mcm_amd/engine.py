@@ -66,6 +66,7 @@ def load_library():
     L.mcm_op_linear.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    L.mcm_debug_gemm_variant.argtypes = [i32]
     if L.mcm_abi_version() != 1:
         raise RuntimeError("libmcm_hip.so ABI version mismatch")
     _lib = L
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "mcm_abi_version", "mcm_create", "mcm_destroy", "mcm_last_error", "mcm_set_weight",
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
-    "mcm_op_attention",
+    "mcm_op_attention", "mcm_debug_gemm_variant",
 ]
 
 

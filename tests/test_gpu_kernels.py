@@ -73,6 +73,7 @@ def test_layernorm(tiny_net, D, prec):
 
 
 GEMM_SHAPES = [
+    (2600, 768, 192),     # > 8 row tiles: every XCD's persistent workgroups get work, 3 K-steps
     (128, 128, 64),       # one tile, one K-step (bf16) / two (fp32)
     (300, 256, 128),      # ragged M
     (591, 2304, 768),     # 3 B/16 images through the QKV projection
@@ -82,10 +83,19 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[0, 2, 4], ids=["tile128", "persist256x128", "persist256x256"])
+def gemm_variant(request, tiny_net):
+    """Every GEMM kernel variant must pass the same parity cases (the auto policy picks by
+    problem size, so small test shapes would otherwise only exercise the tile kernel)."""
+    assert tiny_net._lib.mcm_debug_gemm_variant(request.param) == 0
+    yield request.param
+    tiny_net._lib.mcm_debug_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_linear(tiny_net, M, N, K, prec, epi):
+def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
     from oracle import oracle as orc
 
     rng = np.random.default_rng(M * 7 + N * 3 + K + epi)

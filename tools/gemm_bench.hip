@@ -1,0 +1,129 @@
+// gemm_bench.hip — standalone A/B harness for the GEMM kernels of mcm_amd/csrc/gemm.hip.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I mcm_amd/csrc tools/gemm_bench.hip \
+//        mcm_amd/csrc/gemm.hip -o /tmp/gemm_bench
+// Run:   gemm_bench M N K epi [iters]   → per-variant time / TFLOP/s, max |diff| vs variant 0
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+#define CK(x)                                                                          \
+  do {                                                                                 \
+    hipError_t e = (x);                                                                \
+    if (e != hipSuccess) {                                                             \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);     \
+      exit(1);                                                                         \
+    }                                                                                  \
+  } while (0)
+
+static uint16_t f2bf_h(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f_h(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static float frand(uint64_t& s) {
+  s = s * 6364136223846793005ull + 1442695040888963407ull;
+  return ((s >> 40) & 0xffffff) / (float)0x800000 - 1.0f;  // uniform [-1,1)
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 100864, N = argc > 2 ? atoi(argv[2]) : 2304,
+            K = argc > 3 ? atoi(argv[3]) : 768, epi = argc > 4 ? atoi(argv[4]) : 0,
+            iters = argc > 5 ? atoi(argv[5]) : 20;
+  if (argc > 6) gemm_set_group_n(atoi(argv[6]));
+  if (argc > 7) gemm_set_dbg(atoi(argv[7]));
+  printf("M=%d N=%d K=%d epi=%d\n", M, N, K, epi);
+  uint64_t seed = 1;
+  std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+  for (auto& v : hx) v = f2bf_h(frand(seed));
+  for (auto& v : hw) v = f2bf_h(frand(seed) * 0.05f);
+  std::vector<float> hb(N), hr((size_t)M * N);
+  for (auto& v : hb) v = frand(seed) * 0.1f;
+  for (auto& v : hr) v = frand(seed);
+  uint16_t *dx, *dw;
+  float *db, *dr;
+  void* dout;
+  CK(hipMalloc(&dx, hx.size() * 2));
+  CK(hipMalloc(&dw, hw.size() * 2));
+  CK(hipMalloc(&db, N * 4));
+  CK(hipMalloc(&dr, (size_t)M * N * 4));
+  CK(hipMalloc(&dout, (size_t)M * N * 4));
+  CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+  GemmArgs a{};
+  a.x = dx; a.w = dw; a.bias = db; a.out = dout; a.resid = dr;
+  a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
+  const size_t out_elems = (size_t)M * N;
+  std::vector<float> ref, got(out_elems);
+  std::vector<uint16_t> tmp(out_elems);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int nvar = 5;
+  double best[nvar] = {0};
+  for (int round = 0; round < 3; ++round)
+    for (int v = 0; v < nvar; ++v) {
+      gemm_set_variant(v);
+      if (round == 0) {  // correctness pass
+        CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(dout, 0, out_elems * 4));
+        CK(launch_gemm(MCM_PREC_BF16, epi, a, 0));
+        CK(hipDeviceSynchronize());
+        if (epi == EPI_RESID) {
+          CK(hipMemcpy(got.data(), dr, out_elems * 4, hipMemcpyDeviceToHost));
+        } else {
+          CK(hipMemcpy(tmp.data(), dout, out_elems * 2, hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < out_elems; ++i) got[i] = bf2f_h(tmp[i]);
+        }
+        if (v == 0) {
+          ref = got;
+          // spot-check variant 0 against a host dot product
+          double worst = 0;
+          for (int t = 0; t < 64; ++t) {
+            const int m = (int)(((uint64_t)t * 7919 * 131) % M), n = (int)(((uint64_t)t * 104729) % N);
+            double acc = hb[n];
+            for (int k = 0; k < K; ++k) acc += (double)bf2f_h(hx[(size_t)m * K + k]) * bf2f_h(hw[(size_t)n * K + k]);
+            if (epi == EPI_GELU) acc = acc / (1.0 + exp(-1.702 * acc));
+            if (epi == EPI_RESID) acc += hr[(size_t)m * N + n];
+            const double d = fabs(acc - ref[(size_t)m * N + n]);
+            if (d > worst) worst = d;
+          }
+          printf("  variant 0 vs host fp64 spot check: max|d| = %.3e\n", worst);
+        } else {
+          double worst = 0;
+          size_t nbad = 0;
+          for (size_t i = 0; i < out_elems; ++i) {
+            const double d = fabs((double)got[i] - ref[i]);
+            if (d > worst) worst = d;
+            if (d > 0) ++nbad;
+          }
+          printf("  variant %d vs variant 0: max|d| = %.3e, %zu differing elements\n", v, worst, nbad);
+        }
+      }
+      CK(launch_gemm(MCM_PREC_BF16, epi, a, 0));  // warm
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) CK(launch_gemm(MCM_PREC_BF16, epi, a, 0));
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = 1e3 * ms / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+      if (tf > best[v]) best[v] = tf;
+      printf("  round %d variant %d: %9.1f us  %7.1f TFLOP/s\n", round, v, us, tf);
+    }
+  printf("BEST M=%d N=%d K=%d epi=%d:", M, N, K, epi);
+  for (int v = 0; v < nvar; ++v) printf(" v%d=%.1f", v, best[v]);
+  printf(" TFLOP/s\n");
+  return 0;
+}
