@@ -32,7 +32,7 @@ __host__ __device__ constexpr int vt_stride(int LP) {  // bytes; ≡ 16 (mod 256
 template <int LP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv,
                                                            uint16_t* __restrict__ out, int L,
-                                                           int heads) {
+                                                           int heads, int qrows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = LP / 16;       // key tiles
   constexpr int NU = LP / 32;       // key tile pairs (PV k-steps)
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
   for (int kk = 0; kk < 2; ++kk) koff[kk] = ktile_off(fr, kk * 4 + g);
   constexpr float SC = 0.125f * 1.4426950408889634f;  // scale * log2(e)
 
-  const int nqb = (L + 15) / 16;
+  const int nqb = (qrows + 15) / 16;  // qrows < L: only the first rows are consumed (CLS)
   for (int qb = wave; qb < nqb; qb += 4) {
     const int q = qb * 16 + fr;
     const int qr = min(q, L - 1);
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 // ---- fp32 parity arm -------------------------------------------------------------------
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv,
-                                                       float* __restrict__ out, int L, int heads) {
+                                                       float* __restrict__ out, int L, int heads,
+                                                       int qrows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Ks = (float*)smem;            // [L][65]
   float* Vs = Ks + (size_t)L * 65;     // [L][64]
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   __syncthreads();
   float* myq = qs + wave * 64;
   float* myp = ps + wave * L;
-  for (int q = wave; q < L; q += 4) {
+  for (int q = wave; q < qrows; q += 4) {
     myq[lane] = base[(size_t)q * rs + lane];
     __builtin_amdgcn_wave_barrier();
     const int jmax = CAUSAL ? q + 1 : L;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 template <int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
-                       hipStream_t s) {
+                       int qrows, hipStream_t s) {
   constexpr int lds = LP * 128 + 64 * vt_stride(LP);
   static bool attr_set = false;
   if (!attr_set) {
@@ -235,25 +236,26 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
   }
   if (causal)
     hipLaunchKernelGGL((attn_bf16_kernel<LP, true>), dim3(nseq * heads), dim3(256), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
   else
     hipLaunchKernelGGL((attn_bf16_kernel<LP, false>), dim3(nseq * heads), dim3(256), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, hipStream_t s) {
+                            bool causal, int qrows, hipStream_t s) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
+  if (qrows <= 0 || qrows > L) qrows = L;
   if (prec == MCM_PREC_BF16) {
-    if (L <= 32) return launch_bf16<32>(qkv, out, nseq, L, heads, causal, s);
-    if (L <= 64) return launch_bf16<64>(qkv, out, nseq, L, heads, causal, s);
-    if (L <= 96) return launch_bf16<96>(qkv, out, nseq, L, heads, causal, s);
-    if (L <= 128) return launch_bf16<128>(qkv, out, nseq, L, heads, causal, s);
-    if (L <= 224) return launch_bf16<224>(qkv, out, nseq, L, heads, causal, s);
-    if (L <= 288) return launch_bf16<288>(qkv, out, nseq, L, heads, causal, s);
+    if (L <= 32) return launch_bf16<32>(qkv, out, nseq, L, heads, causal, qrows, s);
+    if (L <= 64) return launch_bf16<64>(qkv, out, nseq, L, heads, causal, qrows, s);
+    if (L <= 96) return launch_bf16<96>(qkv, out, nseq, L, heads, causal, qrows, s);
+    if (L <= 128) return launch_bf16<128>(qkv, out, nseq, L, heads, causal, qrows, s);
+    if (L <= 224) return launch_bf16<224>(qkv, out, nseq, L, heads, causal, qrows, s);
+    if (L <= 288) return launch_bf16<288>(qkv, out, nseq, L, heads, causal, qrows, s);
     return hipErrorInvalidValue;
   }
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
@@ -270,9 +272,9 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   }
   if (causal)
     hipLaunchKernelGGL(attn_f32_kernel<true>, dim3(nseq * heads), dim3(256), lds, s,
-                       (const float*)qkv, (float*)out, L, heads);
+                       (const float*)qkv, (float*)out, L, heads, qrows);
   else
     hipLaunchKernelGGL(attn_f32_kernel<false>, dim3(nseq * heads), dim3(256), lds, s,
-                       (const float*)qkv, (float*)out, L, heads);
+                       (const float*)qkv, (float*)out, L, heads, qrows);
   return hipGetLastError();
 }

@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 // QuickGELU: x * sigmoid(1.702 x)  (transformers activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// bf16-output form: v_exp_f32 + v_rcp_f32 (≈1 ulp each) instead of the IEEE division expansion
+__device__ __forceinline__ float quick_gelu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
 
 // wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
@@ -90,11 +94,14 @@ void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
+// x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
-                            int M, int D, float eps, bool out_f32, hipStream_t s);
+                            int M, int D, float eps, bool out_f32, hipStream_t s,
+                            size_t x_stride = 0, size_t y_stride = 0);
 
+// qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, hipStream_t s);
+                            bool causal, int qrows, hipStream_t s);
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);

@@ -103,9 +103,10 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
       v[fj] = acc[fj][fi] + bv[fj];
-      if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu(v[fj][t]);
+      if constexpr (EPI == EPI_GELU) {  // same form in every kernel variant: results must not
+#pragma unroll                          // depend on which variant the size heuristic picks
+        for (int t = 0; t < 4; ++t)
+          v[fj][t] = PREC == MCM_PREC_BF16 ? quick_gelu_fast(v[fj][t]) : quick_gelu(v[fj][t]);
       }
     }
     if constexpr (EPI == EPI_RESID) {
@@ -131,6 +132,117 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
       f32x4_t* dst = (f32x4_t*)((float*)a.out + (size_t)m * a.ldo + n);
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) dst[fj] = v[fj];
+    }
+  }
+}
+
+// LDS-staged epilogue of a (MF*16)x64 wave tile (persistent 256x256 kernel).  Row-per-lane
+// stores at a row stride reach only ~12 B/clk/CU on this chip (each store instruction touches
+// 16 partial lines), which made the epilogue cost as much as 40 % of a K=768 tile.  Here each
+// wave bounces its tile through a private 4-KiB LDS window (XOR-swizzled, conflict-free both
+// ways) and writes whole rows: one store instruction = 8 full 128-B lines (bf16) or 4 x 256 B
+// (fp32).  The fp32 residual form reads the matching rows the same way, one chunk ahead.
+template <int PREC, int EPI, int MF>
+__device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
+                                                  const f32x4_t (&bv)[4], int mw, int nw, int lane,
+                                                  char* scratch) {
+  const int fr = lane & 15, g = lane >> 4;
+  if constexpr (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) {
+    const int rrow = lane >> 3, c8 = lane & 7;  // read-back: 8 lanes per 128-B row
+    const int n = nw + c8 * 8;
+#pragma unroll
+    for (int c = 0; c < MF / 2; ++c) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int fi = 2 * c + h, row = h * 16 + fr;
+        f32x4_t v[4];
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+          v[fj] = acc[fj][fi] + bv[fj];
+          if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
+          }
+        }
+        const int sw = row & 7;
+        *(uint4*)(scratch + row * 128 + (((g * 2) ^ sw) << 4)) =
+            make_uint4(pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]),
+                       pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3]));
+        *(uint4*)(scratch + row * 128 + (((g * 2 + 1) ^ sw) << 4)) =
+            make_uint4(pack_bf2(v[2][0], v[2][1]), pack_bf2(v[2][2], v[2][3]),
+                       pack_bf2(v[3][0], v[3][1]), pack_bf2(v[3][2], v[3][3]));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + rrow;
+        const uint4 v = *(const uint4*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int m = mw + c * 32 + row;
+        if (m < a.M && n < a.N) *(uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n) = v;
+      }
+    }
+  } else {
+    // fp32 rows: chunk = 16 rows x 256 B, 16 lanes per row
+    const int rrow = lane >> 4, c16 = lane & 15;
+    const int n = nw + c16 * 4;
+    const bool ncol = n < a.N;
+    f32x4_t rnext[4];
+    auto row_ptr = [&](int c, int t, bool& ok) -> float* {
+      const int m = mw + c * 16 + t * 4 + rrow;
+      ok = ncol && m < a.M;
+      if constexpr (EPI == EPI_PATCH) {
+        const int mm = min(m, a.M - 1), b = mm / a.np, p = mm - b * a.np;
+        return (float*)a.out + (size_t)(b * (a.np + 1) + 1 + p) * a.ldo + n;
+      } else if constexpr (EPI == EPI_RESID) {
+        return a.resid + (size_t)m * a.ldo + n;
+      } else {
+        return (float*)a.out + (size_t)m * a.ldo + n;
+      }
+    };
+    auto prefetch = [&](int c) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bool ok;
+        const float* ptr;
+        if constexpr (EPI == EPI_PATCH) {
+          const int m = min(mw + c * 16 + t * 4 + rrow, a.M - 1);
+          const int p = m - (m / a.np) * a.np;
+          ok = ncol;
+          ptr = a.pos + (size_t)(1 + p) * a.N + n;
+        } else {
+          ptr = row_ptr(c, t, ok);
+        }
+        rnext[t] = ok ? *(const f32x4_t*)ptr : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    constexpr bool ADD = (EPI == EPI_RESID || EPI == EPI_PATCH);
+    if constexpr (ADD) prefetch(0);
+#pragma unroll
+    for (int c = 0; c < MF; ++c) {
+      f32x4_t r[4];
+      if constexpr (ADD) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[t] = rnext[t];
+        if (c + 1 < MF) prefetch(c + 1);
+      }
+      const int sw = fr;  // row = fr inside the chunk
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        f32x4_t v = acc[fj][c] + bv[fj];
+        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
+        }
+        *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ sw) << 4)) = v;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 4 + rrow;
+        f32x4_t v = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
+        if constexpr (ADD) v += r[t];
+        bool ok;
+        float* dst = row_ptr(c, t, ok);
+        if (ok) *(f32x4_t*)dst = v;
+      }
     }
   }
 }
@@ -320,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
       gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + ((a.dbg & 8) ? r0 : perm_n(r0)), a.N - 1) * a.K) * ES + chunk * 16;
+      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * a.K) * ES + chunk * 16;
   };
   const uint32_t lds0 = lds_addr(smem);
   auto issue = [&](int st) {
@@ -423,7 +535,7 @@ constexpr int BM = 256, BN = 256;
 constexpr int A_BYTES = BM * ROWB;  // 32 KiB
 constexpr int W_BYTES = BN * ROWB;  // 32 KiB
 constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // 128 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 KiB epilogue window per wave
 }  // namespace p256
 
 template <int PREC, int EPI, bool COUNT_STORES>
@@ -489,15 +601,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  if (a.dbg & 16) {
-    // De-phase the persistent workgroups: with identical tile sequences every CU reaches its
-    // epilogue at the same moment and the store bursts serialise on HBM while the matrix pipes
-    // idle.  Spreading the start times over one tile period interleaves one CU's burst with
-    // the others' compute.
-    const long long t0 = __builtin_readcyclecounter();
-    const long long delay = (long long)nk * 2600 * ((blockIdx.x * 41) & 255) / 256;
-    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(8);
-  }
   set_issue_tile(0);
   issue(0);
   int issued = 1;
@@ -530,7 +633,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!(a.dbg & 4) && !((a.dbg & 32) && (blockIdx.x & 56))) wave_epilogue<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, fr, g);
+      if (!(a.dbg & 4))
+        wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, lane,
+                                        smem + 2 * STAGE_BYTES + wave * 4096);
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
       ktc = 0;

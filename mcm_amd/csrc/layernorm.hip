@@ -16,11 +16,12 @@ template <int OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, void* y,
-                                                        int M, int D, float eps) {
+                                                        int M, int D, float eps, size_t xs,
+                                                        size_t ys) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float* xr = x + (size_t)row * D;
+  const float* xr = x + (size_t)row * xs;
   float4 v[MAXV];
   float s = 0.f;
 #pragma unroll
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
         uint2 pk;
         pk.x = pack_bf2(o.x, o.y);
         pk.y = pack_bf2(o.z, o.w);
-        *(uint2*)((uint16_t*)y + (size_t)row * D + d) = pk;
+        *(uint2*)((uint16_t*)y + (size_t)row * ys + d) = pk;
       } else {
-        *(float4*)((float*)y + (size_t)row * D + d) = o;
+        *(float4*)((float*)y + (size_t)row * ys + d) = o;
       }
     }
   }
@@ -68,12 +69,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
 }  // namespace
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
-                            int M, int D, float eps, bool out_f32, hipStream_t s) {
+                            int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,
+                            size_t y_stride) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
+  const size_t xs = x_stride ? x_stride : (size_t)D, ys = y_stride ? y_stride : (size_t)D;
+  if (xs % 4 || ys % 4) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
   if (prec == MCM_PREC_BF16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, g, b, y, M, D, eps);
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
   else
-    hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x, g, b, y, M, D, eps);
+    hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
   return hipGetLastError();
 }

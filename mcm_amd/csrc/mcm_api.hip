@@ -153,34 +153,63 @@ hipError_t lnorm(mcm_handle* h, hipStream_t s, const float* x, const float* g, c
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
   return launch_layernorm(h->cfg.precision, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s);
 }
-hipError_t attn(mcm_handle* h, hipStream_t s, int nseq, int L, int heads, bool causal) {
-  Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)L * L * 64 * (causal ? 0.5 : 1.0));
-  return launch_attention(h->cfg.precision, h->qkv, h->att, nseq, L, heads, causal, s);
+hipError_t attn(mcm_handle* h, hipStream_t s, int nseq, int L, int heads, bool causal, int qrows = 0) {
+  const int q = qrows > 0 ? qrows : L;
+  Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)q * L * 64 * (causal ? 0.5 : 1.0));
+  return launch_attention(h->cfg.precision, h->qkv, h->att, nseq, L, heads, causal, qrows, s);
+}
+hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, const float* x, const float* g, const float* b,
+                         void* y, int M, int D, size_t xs, size_t ys) {
+  Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
+  return launch_layernorm(h->cfg.precision, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys);
 }
 
-// CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place)
-int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal) {
+// CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place).
+// pooled_row0: the caller consumes only row 0 of every sequence (CLS pooling, HF
+// modeling_clip.py:649-651).  The last layer then computes K/V for all tokens but Q, the
+// attention output, out_proj, LN2 and the MLP for row 0 only — identical results for the
+// consumed rows (every op after attention is row-wise), 1/12 less work for a 12-layer tower.
+int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal,
+               bool pooled_row0) {
   const int M = nseq * L, D = t.D;
+  const int es = prec_esize(h->cfg.precision);
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
+    const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
     HIP_TRY(h, lnorm(h, s, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
-    GemmArgs a{};
-    a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
-    a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
-    HIP_TRY(h, gemm(h, s, EPI_STORE, a));
-    HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal));
+    if (!cls) {
+      GemmArgs a{};
+      a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
+      a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
+      HIP_TRY(h, gemm(h, s, EPI_STORE, a));
+      HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal));
+    } else {
+      GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
+      kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * D * es; kv.bias = w.bqkv + D;
+      kv.out = (char*)h->qkv + (size_t)D * es;
+      kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D;
+      HIP_TRY(h, gemm(h, s, EPI_STORE, kv));
+      GemmArgs q{};   // Q of row 0 of every sequence (row stride L*D in, L*3D out)
+      q.x = h->ln; q.w = w.wqkv; q.bias = w.bqkv; q.out = h->qkv;
+      q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D;
+      HIP_TRY(h, gemm(h, s, EPI_STORE, q));
+      HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal, 1));
+    }
+    const int Mr = cls ? nseq : M;            // rows that continue
+    const int rs = cls ? L * D : D;           // their stride in x / att
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
-    o.M = M; o.N = D; o.K = D; o.ldx = D; o.ldo = D;
+    o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
     HIP_TRY(h, gemm(h, s, EPI_RESID, o));
-    HIP_TRY(h, lnorm(h, s, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+    if (!cls) HIP_TRY(h, lnorm(h, s, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+    else HIP_TRY(h, lnorm_strided(h, s, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
     GemmArgs f1{};
     f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
-    f1.M = M; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
+    f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
     HIP_TRY(h, gemm(h, s, EPI_GELU, f1));
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
-    f2.M = M; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = D;
+    f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
     HIP_TRY(h, gemm(h, s, EPI_RESID, f2));
   }
   return MCM_OK;
@@ -394,7 +423,7 @@ int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* o
   }
   HIP_TRY(h, lnorm(h, s, h->x, W(h, "vision_model.pre_layrnorm.weight"),
                    W(h, "vision_model.pre_layrnorm.bias"), h->x, B * h->ntok, D, true));
-  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false))) return rc;
+  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true))) return rc;
   {
     Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * B * D * c.proj_dim);
     HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,
@@ -441,7 +470,7 @@ int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S
                                    W(h, "text_model.embeddings.position_embedding.weight"), h->x,
                                    kc, S, D, s));
     }
-    if ((rc = run_layers(h, s, h->txt, kc, S, true))) return rc;
+    if ((rc = run_layers(h, s, h->txt, kc, S, true, false))) return rc;
     {
       Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * kc * D * c.proj_dim);
       HIP_TRY(h, launch_pool_project(h->x, h->rowidx_dev, 0, kc, D,
@@ -525,7 +554,7 @@ int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const floa
 int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq,
                      int32_t seq_len, int32_t heads, int32_t causal, void* stream) {
   if (!h) return MCM_EINVAL;
-  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0,
+  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, 0,
                               (hipStream_t)stream));
   return MCM_OK;
 }
