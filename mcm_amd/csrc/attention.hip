@@ -37,8 +37,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
   constexpr int NT = LP / 16;       // key tiles
   constexpr int NU = LP / 32;       // key tile pairs (PV k-steps)
   constexpr int VS = vt_stride(LP);
+  constexpr int MAXQB = (LP / 16 + 3) / 4;  // q-blocks per wave
   char* Ks = smem;                  // [LP rows][128 B], swizzled
-  char* Vt = smem + LP * 128;       // [64 d][VS bytes]: V transposed, keys contiguous
+  char* Vt = smem + LP * 128;       // [64 d][VS bytes]: V transposed, keys contiguous; the
+                                    // key-pair index is XORed with (d>>3)<<2 (conflict-free
+                                    // transposing writes, pairs of keys stay adjacent)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -46,8 +49,20 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
   const int D = heads * 64;
   const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
   const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+  const int fr = lane & 15, g = lane >> 4;
 
-  // ---- stage K (LDS-DMA, swizzled source) : LP/8 pieces of 8 rows
+  // ---- all global reads are issued up front so their latency is paid once per workgroup:
+  // Q fragments of every q-block this wave owns, then K (LDS-DMA), then V
+  const int nqb = (qrows + 15) / 16;
+  uint4 qf[MAXQB][2];
+#pragma unroll
+  for (int i = 0; i < MAXQB; ++i) {
+    const int qr = min((wave + 4 * i) * 16 + fr, L - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[i][kk] = (wave + 4 * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
+                                       : make_uint4(0, 0, 0, 0);
+  }
   for (int blk = wave; blk < LP / 8; blk += 4) {
     const int p = blk * 4 + (lane >> 4), s = lane & 15;
     const int row = min(2 * p + (s >> 3), L - 1);
@@ -55,42 +70,39 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + D + chunk * 8),
                                      (lptr_t)(Ks + blk * 1024), 16, 0, 0);
   }
-  // ---- stage V transposed: a thread takes a key pair x 8 dims, writes 8 dwords
+  // V transposed: a thread takes a key pair x 8 dims and writes 8 dwords
   for (int item = threadIdx.x; item < (LP / 2) * 8; item += 256) {
     const int dc = item & 7, kp = item >> 3;
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
     if (2 * kp < L) v0 = *(const uint4*)(base + (size_t)(2 * kp) * rs + 2 * D + dc * 8);
     if (2 * kp + 1 < L) v1 = *(const uint4*)(base + (size_t)(2 * kp + 1) * rs + 2 * D + dc * 8);
     const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+    const int kpos = (kp ^ (dc << 2)) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t lo = (a[j] & 0xffffu) | (b[j] << 16);
       const uint32_t hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-      *(uint32_t*)(Vt + (dc * 8 + 2 * j) * VS + kp * 4) = lo;
-      *(uint32_t*)(Vt + (dc * 8 + 2 * j + 1) * VS + kp * 4) = hi;
+      *(uint32_t*)(Vt + (dc * 8 + 2 * j) * VS + kpos) = lo;
+      *(uint32_t*)(Vt + (dc * 8 + 2 * j + 1) * VS + kpos) = hi;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int fr = lane & 15, g = lane >> 4;
   int koff[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) koff[kk] = ktile_off(fr, kk * 4 + g);
   constexpr float SC = 0.125f * 1.4426950408889634f;  // scale * log2(e)
 
-  const int nqb = (qrows + 15) / 16;  // qrows < L: only the first rows are consumed (CLS)
-  for (int qb = wave; qb < nqb; qb += 4) {
-    const int q = qb * 16 + fr;
-    const int qr = min(q, L - 1);
-    bf16x8_t qf[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      qf[kk] = __builtin_bit_cast(bf16x8_t,
-                                  *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8));
-    // S^T tiles
-    // (fragment reads are software-pipelined one tile ahead; the sched_barrier stops hipcc
-    //  from hoisting all NT*2 ds_read_b128 up front, which spills at NT = 14/18)
+  for (int i = 0; i < MAXQB; ++i) {
+    const int qb = wave + 4 * i;
+    if (qb >= nqb) break;
+    const int q = qb * 16 + fr;
+    const bf16x8_t q0 = __builtin_bit_cast(bf16x8_t, qf[i][0]);
+    const bf16x8_t q1 = __builtin_bit_cast(bf16x8_t, qf[i][1]);
+    // S^T tiles (fragment reads software-pipelined one tile ahead; the sched_barrier stops
+    // hipcc from hoisting all NT*2 ds_read_b128 up front, which spills at NT = 14/18)
     f32x4_t s[NT];
     uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
 #pragma unroll
@@ -100,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
         kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
         kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
       }
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0), qf[0],
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0), q0,
                                                      (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1), qf[1],
-                                                     s[t], 0, 0, 0);
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1), q1, s[t],
+                                                     0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // mask + row max (row = this lane's query; keys spread over regs and the 4 g-groups)
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
       }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    // P = exp2(s - m) → bf16 in MFMA operand order; row sum of the rounded values
+    // P = exp2(s - m) → bf16 in MFMA operand order; row sum of the ROUNDED values, so the
+    // weights the PV product actually uses sum to exactly 1 after normalisation
     float lsum = 0.f;
     bf16x8_t pf[NU];
 #pragma unroll
@@ -130,11 +143,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
         const int t = 2 * u + half;
         float e[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = exp2f(s[t][r] - m);
-        const uint16_t b0 = f2bf(e[0]), b1 = f2bf(e[1]), b2 = f2bf(e[2]), b3 = f2bf(e[3]);
-        lsum += (bf2f(b0) + bf2f(b1)) + (bf2f(b2) + bf2f(b3));
-        w[half * 2 + 0] = (uint32_t)b0 | ((uint32_t)b1 << 16);
-        w[half * 2 + 1] = (uint32_t)b2 | ((uint32_t)b3 << 16);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(s[t][r] - m);
+        const uint32_t w0 = pack_bf2(e[0], e[1]), w1 = pack_bf2(e[2], e[3]);
+        lsum += (__builtin_bit_cast(float, w0 << 16) + __builtin_bit_cast(float, w0 & 0xffff0000u)) +
+                (__builtin_bit_cast(float, w1 << 16) + __builtin_bit_cast(float, w1 & 0xffff0000u));
+        w[half * 2 + 0] = w0;
+        w[half * 2 + 1] = w1;
       }
       pf[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
     }
@@ -145,14 +159,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const char* vrow = Vt + (dt * 16 + fr) * VS + g * 8;
-      uint2 ln = *(const uint2*)(vrow), hn = *(const uint2*)(vrow + 32);
+      const char* vrow = Vt + (dt * 16 + fr) * VS;
+      const int vx = (dt * 2 + (fr >> 3)) << 2;  // this row's key-pair XOR
+      auto vaddr = [&](int t) { return vrow + (((t * 8 + g * 2) ^ vx) << 2); };
+      uint2 ln = *(const uint2*)vaddr(0), hn = *(const uint2*)vaddr(1);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const uint2 lo = ln, hi = hn;
         if (u + 1 < NU) {
-          ln = *(const uint2*)(vrow + (2 * u + 2) * 32);
-          hn = *(const uint2*)(vrow + (2 * u + 3) * 32);
+          ln = *(const uint2*)vaddr(2 * u + 2);
+          hn = *(const uint2*)vaddr(2 * u + 3);
         }
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], o, 0, 0, 0);

@@ -21,8 +21,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(uint16_t h) {
   return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
+// two fp32 → packed bf16x2 (lo in bits 0-15), round-to-nearest-even, in ONE instruction:
+// gfx950's v_cvt_pk_bf16_f32 (no builtin on ROCm 7.2 — guide T12).  The software f2bf above
+// costs ~6 VALU per element and was a large share of every bf16 epilogue.
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
 // LDS-DMA, 16 B per lane: lane i's 16 bytes at `gsrc` land at LDS byte address lds_base + 16*i
