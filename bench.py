@@ -31,6 +31,20 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(family="gemm"):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, written by tools/traffic_json.py); None when absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["per_launch_bytes"][family]["hbm_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(geo, sd, ids, mask, K, px_sample, budget_s, native_scores):
     """The reference loop on the host cores: per batch, image features → normalise →
     (re-)encode the K prompts → normalise → matmul → softmax → -max, all fp32 torch CPU
@@ -179,9 +193,11 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
             peak = MFMA_PEAK_TFLOPS[args.precision]
             line["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_kernel (all 49 GEMM launches/step)",
+                "bound": "mfma", "kernel": "gemm_p256_kernel family (all GEMM launches of a step)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak if ach else None, "traffic": None,
+                "frac": ach / peak if ach else None,
+                "traffic": pmc_traffic("gemm") if (args.precision == "bf16" and B == 512) else None,
+                "traffic_unit": "HBM bytes per launch = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC, profiles/",
                 "avg_launch_us": 1e3 * g["ms"] / g["launches"] if g["launches"] else None,
                 "flop_per_launch": g["flops"] / g["launches"] if g["launches"] else None,
             }

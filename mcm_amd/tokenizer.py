@@ -40,10 +40,17 @@ class HashTokenizer:
 
 
 def load_tokenizer(ckpt: str):
-    """Real CLIP BPE tokenizer when its vocabulary is available locally, else HashTokenizer."""
+    """Real CLIP BPE tokenizer when its vocabulary is available locally, else HashTokenizer.
+    transformers 5.x returns an EMPTY-vocabulary tokenizer instead of raising when the files
+    are missing (every prompt then tokenises to the same ids), so the result is validated."""
     try:
         from transformers import CLIPTokenizer
 
-        return CLIPTokenizer.from_pretrained(ckpt, local_files_only=True)
+        tok = CLIPTokenizer.from_pretrained(ckpt, local_files_only=True)
+        probe = tok(["a photo of a tench", "a photo of a goldfish"], padding=True, return_tensors="np")
+        ids = np.asarray(probe["input_ids"])
+        if len(tok) >= 49408 and ids[0, 0] == BOS and ids.max() == EOS and (ids[0] != ids[1]).any():
+            return tok
     except Exception:
-        return HashTokenizer()
+        pass
+    return HashTokenizer()

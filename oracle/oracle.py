@@ -134,9 +134,12 @@ class OracleCLIP:
                 raise RuntimeError(f"orc_set_weight({name}) rc={rc}")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def _check(self, rc):
         if rc:

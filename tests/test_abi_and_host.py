@@ -93,6 +93,18 @@ def test_tokenizer_contract():
     assert (ids[0, 1:5] == ids[1, 1:5]).all()  # same words → same ids
 
 
+def test_load_tokenizer_never_returns_degenerate_tokenizer():
+    """No vocabulary exists offline; transformers 5.x then hands back an empty tokenizer that maps
+    every prompt to the same ids — load_tokenizer must detect that and fall back."""
+    from mcm_amd.tokenizer import BOS, EOS, load_tokenizer
+
+    tok = load_tokenizer("ViT-B/16")
+    ids = np.asarray(tok([f"a photo of a concept{k:04d}" for k in range(5)], padding=True,
+                         return_tensors="np")["input_ids"])
+    assert (ids[:, 0] == BOS).all() and ids.max() == EOS
+    assert len({tuple(r) for r in ids.tolist()}) == 5
+
+
 def test_synthetic_loader_is_shard_consistent():
     from mcm_amd.synth import SyntheticImageSet, SyntheticLoader
 
