@@ -16,6 +16,13 @@
 //                 both operands; V is transposed once while being staged into LDS.
 //   A lane ends with 4 consecutive head-dims of one query → 8-byte stores.
 // fp32 path (parity arm): plain fp32 VALU kernel, same staging idea, exact expf.
+//
+// Measured anatomy (B/16, 197 keys, 6144 workgroups, 2 resident per CU; ablations in round 1):
+// 216 us per layer, of which the load-only skeleton (Q/K/V into registers/LDS + softmax VALU on
+// dummy data) is already 129 us = 3.6 TB/s: the kernel is bound by how much memory traffic two
+// resident workgroups keep in flight, not by MFMA (QK 23 us, PV 37 us, stores 23 us on top).
+// Next step (round 2): persistent workgroups that prefetch the next head's K/V under the
+// current head's MFMAs.
 #include "common.hpp"
 
 namespace {
@@ -70,13 +77,29 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + D + chunk * 8),
                                      (lptr_t)(Ks + blk * 1024), 16, 0, 0);
   }
-  // V transposed: a thread takes a key pair x 8 dims and writes 8 dwords
-  for (int item = threadIdx.x; item < (LP / 2) * 8; item += 256) {
+  // V transposed: a thread takes (key pair x 8 dims) items and writes 8 dwords per item.  All of
+  // a thread's V loads are issued before the first LDS write so the global latency is paid
+  // once, not once per item.
+  constexpr int NIT = ((LP / 2) * 8 + 255) / 256;
+  uint4 va[NIT], vb[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = threadIdx.x + it * 256;
     const int dc = item & 7, kp = item >> 3;
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-    if (2 * kp < L) v0 = *(const uint4*)(base + (size_t)(2 * kp) * rs + 2 * D + dc * 8);
-    if (2 * kp + 1 < L) v1 = *(const uint4*)(base + (size_t)(2 * kp + 1) * rs + 2 * D + dc * 8);
-    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+    va[it] = make_uint4(0, 0, 0, 0);
+    vb[it] = make_uint4(0, 0, 0, 0);
+    if (item < (LP / 2) * 8) {
+      if (2 * kp < L) va[it] = *(const uint4*)(base + (size_t)(2 * kp) * rs + 2 * D + dc * 8);
+      if (2 * kp + 1 < L) vb[it] = *(const uint4*)(base + (size_t)(2 * kp + 1) * rs + 2 * D + dc * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = threadIdx.x + it * 256;
+    if (item >= (LP / 2) * 8) break;
+    const int dc = item & 7, kp = item >> 3;
+    const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
+    const uint32_t b[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
     const int kpos = (kp ^ (dc << 2)) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -118,21 +141,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
                                                      0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // mask + row max (row = this lane's query; keys spread over regs and the 4 g-groups)
+    // mask + row max (row = this lane's query; keys spread over regs and the 4 g-groups).
+    // Only tiles that can contain an invalid key are masked (uniform test per tile); the
+    // 0.125*log2(e) scale is folded into the exponent's fma.
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const bool full = (t * 16 + 15 < L) && (!CAUSAL || t * 16 + 15 <= qb * 16);
+      if (!full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + g * 4 + r;
-        const bool ok = key < L && (!CAUSAL || key <= q);
-        s[t][r] = ok ? s[t][r] * SC : -INFINITY;
-        m = fmaxf(m, s[t][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 16 + g * 4 + r;
+          const bool ok = key < L && (!CAUSAL || key <= q);
+          s[t][r] = ok ? s[t][r] : -INFINITY;
+        }
       }
+      m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    // P = exp2(s - m) → bf16 in MFMA operand order; row sum of the ROUNDED values, so the
-    // weights the PV product actually uses sum to exactly 1 after normalisation
+    const float msc = m * SC;
+    // P = exp2(s*SC - m*SC) → bf16 in MFMA operand order; fp32 row sum
     float lsum = 0.f;
     bf16x8_t pf[NU];
 #pragma unroll
@@ -143,12 +172,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
         const int t = 2 * u + half;
         float e[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(s[t][r] - m);
-        const uint32_t w0 = pack_bf2(e[0], e[1]), w1 = pack_bf2(e[2], e[3]);
-        lsum += (__builtin_bit_cast(float, w0 << 16) + __builtin_bit_cast(float, w0 & 0xffff0000u)) +
-                (__builtin_bit_cast(float, w1 << 16) + __builtin_bit_cast(float, w1 & 0xffff0000u));
-        w[half * 2 + 0] = w0;
-        w[half * 2 + 1] = w1;
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], SC, -msc));
+        lsum += (e[0] + e[1]) + (e[2] + e[3]);
+        w[half * 2 + 0] = pack_bf2(e[0], e[1]);
+        w[half * 2 + 1] = pack_bf2(e[2], e[3]);
       }
       pf[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
     }

@@ -730,16 +730,23 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 
 void gemm_set_variant(int v) { g_variant = v; }
 
-int g_group_n = 32;
+int g_group_n = [] { const char* e = getenv("MCM_GEMM_GN"); return e ? atoi(e) : 0; }();  // 0 = heuristic
 int g_dbg = 0;
 void gemm_set_dbg(int d) { g_dbg = d; }
-void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 1; }
+void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
 
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
-  if (a.gn <= 0) a.gn = g_group_n;
-  a.dbg = g_dbg;
   const int es = prec_esize(prec);
+  if (a.gn <= 0) {
+    // L2 grouping of the persistent tile walk (N-tiles per group).  In the standalone harness
+    // gn=1 looked 4-7 % faster on the wide short-K shapes, but inside the model (operands
+    // still warm in L2 / Infinity Cache from the producing kernel) the plain n-fastest walk
+    // wins on every shape: 914 vs 822 TF/s family average.  MCM_GEMM_GN overrides.
+    const int nbn = (a.N + 255) / 256;
+    a.gn = g_group_n > 0 ? g_group_n : nbn;
+  }
+  a.dbg = g_dbg;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)
     return hipErrorInvalidValue;

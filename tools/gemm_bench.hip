@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
             iters = argc > 5 ? atoi(argv[5]) : 20;
   if (argc > 6) gemm_set_group_n(atoi(argv[6]));
   if (argc > 7) gemm_set_dbg(atoi(argv[7]));
+  setvbuf(stdout, NULL, _IONBF, 0);
   printf("M=%d N=%d K=%d epi=%d\n", M, N, K, epi);
   uint64_t seed = 1;
   std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
