@@ -15,6 +15,7 @@
 
 namespace {
 
+// generic form (any patch size, e.g. 14): one output element per thread iteration
 template <int OUT_BF16>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, void* out,
                                                        int B, int S, int P, int kpad) {
@@ -33,6 +34,34 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
     if (OUT_BF16) ((uint16_t*)out)[i] = f2bf(v);
     else ((float*)out)[i] = v;
+  }
+}
+
+// vector form for P % 8 == 0 and kpad == 3*P*P (B/16, B/32): a thread moves 8 consecutive
+// pixels of one patch row (32 B in, 16 B bf16 / 32 B fp32 out); indices are computed once per
+// 8 elements and consecutive threads walk a patch row, then the next row of the same patch
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict__ px, void* out,
+                                                        int B, int S, int P, int kpad) {
+  const int g = S / P, np = g * g, k8 = kpad / 8, p8 = P / 8;
+  const size_t total = (size_t)B * np * k8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * 256) {
+    const int kq = (int)(i % k8);            // 8-element group inside the patch row vector
+    const size_t m = i / k8;
+    const int b = (int)(m / np), p = (int)(m % np);
+    const int gy = p / g, gx = p - gy * g;
+    const int rowi = kq / p8, xq = kq - rowi * p8;   // rowi = c*P + py
+    const int c = rowi / P, py = rowi - c * P;
+    const float* src = px + (((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + xq * 8;
+    const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+    if (OUT_BF16) {
+      *(uint4*)((uint16_t*)out + i * 8) =
+          make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
+    } else {
+      *(float4*)((float*)out + i * 8) = a;
+      *(float4*)((float*)out + i * 8 + 4) = d;
+    }
   }
 }
 
@@ -73,38 +102,42 @@ __global__ __launch_bounds__(256) void cvt_weight_kernel(const float* __restrict
   }
 }
 
-// one workgroup per pooled row; D <= 1024, P <= 1024
-__global__ __launch_bounds__(256) void pool_project_kernel(
+// one workgroup (16 waves) per pooled row; D <= 1024, P <= 1024.  The projection is a chain
+// of dependent load -> fma -> cross-lane reductions per output feature, so it is spread over
+// 16 waves (32 features each at P=512) rather than 4.
+constexpr int NWP = 16;
+__global__ __launch_bounds__(NWP * 64) void pool_project_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ row_idx, int row_stride, int D,
     const float* __restrict__ g, const float* __restrict__ b, float eps,
     const float* __restrict__ proj, int P, float* __restrict__ out) {
   __shared__ float y[1024];
   __shared__ float o[1024];
-  __shared__ float red[8];
+  __shared__ float red[2 * NWP];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row = row_idx ? (size_t)row_idx[n] : (size_t)n * row_stride;
   const float* xr = x + row * D;
-  // LayerNorm (two-pass, fp32)
-  float s = 0.f;
-  for (int d = tid; d < D; d += 256) s += xr[d];
-  s = wave_sum(s);
+  // LayerNorm (two-pass, fp32); D <= 1024 = one element per thread
+  const float xv = tid < D ? xr[tid] : 0.f;
+  float s = wave_sum(xv);
   if (lane == 0) red[wave] = s;
   __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)D;
-  float q = 0.f;
-  for (int d = tid; d < D; d += 256) {
-    const float c = xr[d] - mean;
-    q += c * c;
-  }
-  q = wave_sum(q);
-  if (lane == 0) red[4 + wave] = q;
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) tot += red[i];
+  const float mean = tot / (float)D;
+  const float c = tid < D ? xv - mean : 0.f;
+  float q = wave_sum(c * c);
+  if (lane == 0) red[NWP + wave] = q;
   __syncthreads();
-  const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + eps);
-  for (int d = tid; d < D; d += 256) y[d] = (xr[d] - mean) * rstd * g[d] + b[d];
+  tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) tot += red[NWP + i];
+  const float rstd = 1.0f / sqrtf(tot / (float)D + eps);
+  if (tid < D) y[tid] = c * rstd * g[tid] + b[tid];
   __syncthreads();
   // projection: wave per output feature, lanes split D
   float sq = 0.f;  // lane 0 of each wave accumulates squares of its outputs
-  for (int p = wave; p < P; p += 4) {
+  for (int p = wave; p < P; p += NWP) {
     const float* w = proj + (size_t)p * D;
     float a = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
@@ -123,13 +156,16 @@ __global__ __launch_bounds__(256) void pool_project_kernel(
   __syncthreads();  // red[] reuse
   if (lane == 0) red[wave] = sq;
   __syncthreads();
-  const float rn = 1.0f / sqrtf(red[0] + red[1] + red[2] + red[3]);
-  for (int p = tid; p < P; p += 256) out[(size_t)n * P + p] = o[p] * rn;
+  tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) tot += red[i];
+  const float rn = 1.0f / sqrtf(tot);
+  for (int p = tid; p < P; p += NWP * 64) out[(size_t)n * P + p] = o[p] * rn;
 }
 
 inline int grid_for(size_t total) {
   size_t g = (total + 255) / 256;
-  return (int)(g > 2048 ? 2048 : (g ? g : 1));
+  return (int)(g > 4096 ? 4096 : (g ? g : 1));
 }
 
 }  // namespace
@@ -137,13 +173,20 @@ inline int grid_for(size_t total) {
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s) {
   const int g = image / patch;
-  const size_t total = (size_t)B * g * g * kpad;
-  if (prec == MCM_PREC_BF16)
-    hipLaunchKernelGGL(patchify_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, pixels, patches,
-                       B, image, patch, kpad);
-  else
-    hipLaunchKernelGGL(patchify_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, pixels, patches,
-                       B, image, patch, kpad);
+  const bool vec = patch % 8 == 0 && kpad == 3 * patch * patch && image % 4 == 0;
+  const size_t total = (size_t)B * g * g * (vec ? kpad / 8 : kpad);
+  const dim3 grid(grid_for(total)), block(256);
+  if (vec) {
+    if (prec == MCM_PREC_BF16)
+      hipLaunchKernelGGL(patchify8_kernel<1>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
+    else
+      hipLaunchKernelGGL(patchify8_kernel<0>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
+  } else {
+    if (prec == MCM_PREC_BF16)
+      hipLaunchKernelGGL(patchify_kernel<1>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
+    else
+      hipLaunchKernelGGL(patchify_kernel<0>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
+  }
   return hipGetLastError();
 }
 
@@ -177,7 +220,7 @@ hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_s
                                int D, const float* g, const float* b, float eps,
                                const float* proj, int P, float* out, hipStream_t s) {
   if (n <= 0 || D > 1024 || D % 4 || P > 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pool_project_kernel, dim3(n), dim3(256), 0, s, x, row_idx, row_stride, D, g, b,
+  hipLaunchKernelGGL(pool_project_kernel, dim3(n), dim3(NWP * 64), 0, s, x, row_idx, row_stride, D, g, b,
                      eps, proj, P, out);
   return hipGetLastError();
 }

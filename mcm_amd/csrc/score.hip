@@ -24,26 +24,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+constexpr int NWV = 16;  // waves per workgroup: the per-prompt dot products are a dependent
+                         // load -> fma -> cross-lane chain, so more waves = shorter chain
+
 __device__ __forceinline__ double block_sum_d(double v, double* red, int lane, int wave) {
   v = wave_sum_d(v);
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) t += red[i];
+  return t;
 }
 
-__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ img,
+__global__ __launch_bounds__(NWV * 64) void score_kernel(const float* __restrict__ img,
                                                     const float* __restrict__ text, int K, int P,
                                                     float T, int kind, float* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* f = (float*)smem;        // [P]
   float* sim = f + P;             // [K]
-  __shared__ double red[4];
-  __shared__ float redf[4];
+  __shared__ double red[NWV];
+  __shared__ float redf[NWV];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int d = tid; d < P; d += 256) f[d] = img[(size_t)b * P + d];
+  for (int d = tid; d < P; d += NWV * 64) f[d] = img[(size_t)b * P + d];
   __syncthreads();
-  for (int k = wave; k < K; k += 4) {
+  for (int k = wave; k < K; k += NWV) {
     const float* t = text + (size_t)k * P;
     float a = 0.f;
     for (int d = lane * 4; d < P; d += 256) {
@@ -59,18 +65,20 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ im
   }
   __syncthreads();
   float m = -INFINITY;
-  for (int k = tid; k < K; k += 256) m = fmaxf(m, sim[k]);
+  for (int k = tid; k < K; k += NWV * 64) m = fmaxf(m, sim[k]);
   m = wave_max(m);
   if (lane == 0) redf[wave] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  m = redf[0];
+#pragma unroll
+  for (int i = 1; i < NWV; ++i) m = fmaxf(m, redf[i]);
   if (kind == MCM_SCORE_MAX_LOGIT) {
     if (tid == 0) scores[b] = -m;
     return;
   }
   const float mt = m / T;
   double z = 0.0, ez = 0.0;
-  for (int k = tid; k < K; k += 256) {
+  for (int k = tid; k < K; k += NWV * 64) {
     const float u = sim[k] / T - mt;
     const float e = expf(u);
     sim[k] = e;
@@ -88,14 +96,14 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ im
   } else {                                                // variance of the fp32 softmax
     const float rz = (float)(1.0 / z);
     double s1 = 0.0;
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += NWV * 64) {
       const float p = sim[k] * rz;
       sim[k] = p;
       s1 += (double)p;
     }
     const double mean = block_sum_d(s1, red, lane, wave) / (double)K;
     double s2 = 0.0;
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += NWV * 64) {
       const double c = (double)sim[k] - mean;
       s2 += c * c;
     }
@@ -119,6 +127,6 @@ hipError_t launch_score(const float* img, int B, const float* text, int K, int P
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(score_kernel, dim3(B), dim3(256), lds, s, img, text, K, P, T, kind, scores);
+  hipLaunchKernelGGL(score_kernel, dim3(B), dim3(NWV * 64), lds, s, img, text, K, P, T, kind, scores);
   return hipGetLastError();
 }

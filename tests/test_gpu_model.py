@@ -231,3 +231,26 @@ def test_errors_match_reference_behaviour(b16):
     with pytest.raises(RuntimeError):
         b16.score_features(torch.zeros((1, 512), device="cuda"), torch.zeros((4, 512), device="cuda"),
                            T=0.0)
+
+
+@pytest.mark.parametrize("name", ["ViT-B/32", "ViT-L/14"])
+def test_other_checkpoints_vs_oracle(name):
+    """The other two --CLIP_ckpt geometries (reference eval_ood_detection.py:34-35): B/32 (50
+    tokens, 32-px patches) and L/14 (257 tokens, 14-px patches → K padded 588→640, width 1024,
+    24 layers, proj 768), bf16 features vs the fp32 oracle on 2 images / 3 prompts."""
+    from oracle import oracle as orc
+
+    geo = geometry(name)
+    sd = synth_state_dict(geo, 0)
+    o = orc.OracleCLIP(geo, sd)
+    px, _ = make_pixels(2, geo.image_size, 10, ood=False, seed=4)
+    ids, _ = make_token_ids(3, seed=5)
+    want_i, want_t = o.encode_image(px), o.encode_text(ids)
+    net = _net(name, "bf16", max_batch=4, max_prompt_tokens=1024)
+    try:
+        got_i = net.get_image_features(pixel_values=torch.from_numpy(px).cuda()).cpu().numpy()
+        got_t = net.get_text_features(input_ids=torch.from_numpy(ids)).cpu().numpy()
+    finally:
+        net.close()
+    assert got_i.shape == (2, geo.proj_dim) and got_t.shape == (3, geo.proj_dim)
+    assert _cos(got_i, want_i).min() > 0.999 and _cos(got_t, want_t).min() > 0.999
