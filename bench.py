@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def pmc_traffic(family="gemm"):
@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
     ap.add_argument("--prompts", type=int, default=1000, help="K: size of the concept bank")
     ap.add_argument("--ckpt", default="ViT-B/16")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")

@@ -48,7 +48,7 @@ def process_args(argv=None):
     p.add_argument("--max_count", default=250, type=int)
     # additive
     p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="MFMA operand precision")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="MFMA operand precision")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
     args = p.parse_args(argv)
     args.n_cls = get_num_cls(args)

@@ -46,6 +46,8 @@ extern "C" {
  * always fp32). */
 #define MCM_PREC_BF16 0   /* bf16 MFMA operands  (v_mfma_f32_16x16x32_bf16)            */
 #define MCM_PREC_F32 1    /* exact fp32 MFMA     (v_mfma_f32_16x16x4_f32) — parity arm  */
+#define MCM_PREC_F16 2    /* fp16 MFMA operands  (v_mfma_f32_16x16x32_f16): same rate as bf16,
+                           * 10-bit mantissa; BASELINE config 4 (ViT-L/14 fp16)        */
 
 /* score kinds — the epilogues of utils/detection_util.py:233-248 */
 #define MCM_SCORE_MCM 0       /* -max_k softmax(cos/T)             (:236,:248) */

@@ -14,6 +14,7 @@ from dataclasses import dataclass, asdict, replace
 ABI_VERSION = 1
 PREC_BF16 = 0
 PREC_F32 = 1
+PREC_F16 = 2
 
 SCORE_KINDS = {"MCM": 0, "max-logit": 1, "energy": 2, "entropy": 3, "var": 4}
 

@@ -36,7 +36,7 @@ __host__ __device__ constexpr int vt_stride(int LP) {  // bytes; ≡ 16 (mod 256
   return ((LP * 2 - 16 + 255) / 256) * 256 + 16;       // of 16 rows x 2 groups is conflict-free
 }
 
-template <int LP, bool CAUSAL>
+template <int PREC, int LP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv,
                                                            uint16_t* __restrict__ out, int L,
                                                            int heads, int qrows) {
@@ -122,8 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     const int qb = wave + 4 * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
-    const bf16x8_t q0 = __builtin_bit_cast(bf16x8_t, qf[i][0]);
-    const bf16x8_t q1 = __builtin_bit_cast(bf16x8_t, qf[i][1]);
+    const uint4 q0 = qf[i][0], q1 = qf[i][1];
     // S^T tiles (fragment reads software-pipelined one tile ahead; the sched_barrier stops
     // hipcc from hoisting all NT*2 ds_read_b128 up front, which spills at NT = 14/18)
     f32x4_t s[NT];
@@ -135,10 +134,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
         kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
         kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
       }
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0), q0,
-                                                     (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1), q1, s[t],
-                                                     0, 0, 0);
+      s[t] = mfma16<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+      s[t] = mfma16<PREC>(k1, q1, s[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     // mask + row max (row = this lane's query; keys spread over regs and the 4 g-groups).
@@ -163,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     const float msc = m * SC;
     // P = exp2(s*SC - m*SC) → bf16 in MFMA operand order; fp32 row sum
     float lsum = 0.f;
-    bf16x8_t pf[NU];
+    uint4 pf[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       uint32_t w[4];
@@ -174,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], SC, -msc));
         lsum += (e[0] + e[1]) + (e[2] + e[3]);
-        w[half * 2 + 0] = pack_bf2(e[0], e[1]);
-        w[half * 2 + 1] = pack_bf2(e[2], e[3]);
+        w[half * 2 + 0] = pack2<PREC>(e[0], e[1]);
+        w[half * 2 + 1] = pack2<PREC>(e[2], e[3]);
       }
-      pf[u] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+      pf[u] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
@@ -197,14 +194,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
           ln = *(const uint2*)vaddr(2 * u + 2);
           hn = *(const uint2*)vaddr(2 * u + 3);
         }
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], o, 0, 0, 0);
+        o = mfma16<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[u], o);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (q < L) {
         uint2 pk;
-        pk.x = pack_bf2(o[0] * rl, o[1] * rl);
-        pk.y = pack_bf2(o[2] * rl, o[3] * rl);
+        pk.x = pack2<PREC>(o[0] * rl, o[1] * rl);
+        pk.y = pack2<PREC>(o[2] * rl, o[3] * rl);
         *(uint2*)(out + ((size_t)seq * L + q) * D + h * 64 + dt * 16 + g * 4) = pk;
       }
     }
@@ -263,25 +259,25 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
-template <int LP>
+template <int PREC, int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
                        int qrows, hipStream_t s) {
   constexpr int lds = LP * 128 + 64 * vt_stride(LP);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<LP, false>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<PREC, LP, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_bf16_kernel<LP, true>,
+      e = hipFuncSetAttribute((const void*)attn_bf16_kernel<PREC, LP, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (causal)
-    hipLaunchKernelGGL((attn_bf16_kernel<LP, true>), dim3(nseq * heads), dim3(256), lds, s,
+    hipLaunchKernelGGL((attn_bf16_kernel<PREC, LP, true>), dim3(nseq * heads), dim3(256), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
   else
-    hipLaunchKernelGGL((attn_bf16_kernel<LP, false>), dim3(nseq * heads), dim3(256), lds, s,
+    hipLaunchKernelGGL((attn_bf16_kernel<PREC, LP, false>), dim3(nseq * heads), dim3(256), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
   return hipGetLastError();
 }
@@ -292,14 +288,19 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
                             bool causal, int qrows, hipStream_t s) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
-  if (prec == MCM_PREC_BF16) {
-    if (L <= 32) return launch_bf16<32>(qkv, out, nseq, L, heads, causal, qrows, s);
-    if (L <= 64) return launch_bf16<64>(qkv, out, nseq, L, heads, causal, qrows, s);
-    if (L <= 96) return launch_bf16<96>(qkv, out, nseq, L, heads, causal, qrows, s);
-    if (L <= 128) return launch_bf16<128>(qkv, out, nseq, L, heads, causal, qrows, s);
-    if (L <= 224) return launch_bf16<224>(qkv, out, nseq, L, heads, causal, qrows, s);
-    if (L <= 288) return launch_bf16<288>(qkv, out, nseq, L, heads, causal, qrows, s);
-    return hipErrorInvalidValue;
+  if (prec != MCM_PREC_F32) {
+#define MCM_ATTN_BY_LP(P)                                                                      \
+  do {                                                                                          \
+    if (L <= 32) return launch_bf16<P, 32>(qkv, out, nseq, L, heads, causal, qrows, s);         \
+    if (L <= 64) return launch_bf16<P, 64>(qkv, out, nseq, L, heads, causal, qrows, s);         \
+    if (L <= 96) return launch_bf16<P, 96>(qkv, out, nseq, L, heads, causal, qrows, s);         \
+    if (L <= 128) return launch_bf16<P, 128>(qkv, out, nseq, L, heads, causal, qrows, s);       \
+    if (L <= 224) return launch_bf16<P, 224>(qkv, out, nseq, L, heads, causal, qrows, s);       \
+    if (L <= 288) return launch_bf16<P, 288>(qkv, out, nseq, L, heads, causal, qrows, s);       \
+    return hipErrorInvalidValue;                                                                \
+  } while (0)
+    if (prec == MCM_PREC_F16) MCM_ATTN_BY_LP(MCM_PREC_F16);
+    MCM_ATTN_BY_LP(MCM_PREC_BF16);
   }
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;

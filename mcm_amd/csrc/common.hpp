@@ -7,6 +7,7 @@
 #include "../../include/mcm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -49,6 +50,27 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+// two fp32 → packed fp16x2, round-to-nearest-even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+// 16-bit operand modes: PREC selects the element format of MFMA operands and 16-bit outputs
+template <int PREC>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (PREC == MCM_PREC_F16) return pack_h2(lo, hi);
+  else return pack_bf2(lo, hi);
+}
+template <int PREC>
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {  // 16x16x32, fp32 acc
+  if constexpr (PREC == MCM_PREC_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // QuickGELU: x * sigmoid(1.702 x)  (transformers activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 // bf16-output form: v_exp_f32 + v_rcp_f32 (≈1 ulp each) instead of the IEEE division expansion
@@ -69,7 +91,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // element size in bytes of the MFMA operand dtype of a precision mode
-__host__ __device__ constexpr int prec_esize(int prec) { return prec == MCM_PREC_BF16 ? 2 : 4; }
+__host__ __device__ constexpr int prec_esize(int prec) { return prec == MCM_PREC_F32 ? 4 : 2; }
 
 // ---- host launchers (one per kernel family; defined in the .hip files) ----------------
 

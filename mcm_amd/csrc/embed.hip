@@ -16,7 +16,7 @@
 namespace {
 
 // generic form (any patch size, e.g. 14): one output element per thread iteration
-template <int OUT_BF16>
+template <int OUT>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, void* out,
                                                        int B, int S, int P, int kpad) {
   const int g = S / P, np = g * g, kreal = 3 * P * P;
@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       const int c = k / (P * P), rem = k % (P * P), py = rem / P, pxx = rem % P;
       v = px[(((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + pxx];
     }
-    if (OUT_BF16) ((uint16_t*)out)[i] = f2bf(v);
+    if constexpr (OUT == MCM_PREC_BF16) ((uint16_t*)out)[i] = f2bf(v);
+    else if constexpr (OUT == MCM_PREC_F16) ((_Float16*)out)[i] = (_Float16)v;
     else ((float*)out)[i] = v;
   }
 }
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // vector form for P % 8 == 0 and kpad == 3*P*P (B/16, B/32): a thread moves 8 consecutive
 // pixels of one patch row (32 B in, 16 B bf16 / 32 B fp32 out); indices are computed once per
 // 8 elements and consecutive threads walk a patch row, then the next row of the same patch
-template <int OUT_BF16>
+template <int OUT>
 __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict__ px, void* out,
                                                         int B, int S, int P, int kpad) {
   const int g = S / P, np = g * g, k8 = kpad / 8, p8 = P / 8;
@@ -55,9 +56,9 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict_
     const int c = rowi / P, py = rowi - c * P;
     const float* src = px + (((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + xq * 8;
     const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
-    if (OUT_BF16) {
+    if constexpr (OUT != MCM_PREC_F32) {
       *(uint4*)((uint16_t*)out + i * 8) =
-          make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
+          make_uint4(pack2<OUT>(a.x, a.y), pack2<OUT>(a.z, a.w), pack2<OUT>(d.x, d.y), pack2<OUT>(d.z, d.w));
     } else {
       *(float4*)((float*)out + i * 8) = a;
       *(float4*)((float*)out + i * 8 + 4) = d;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
   }
 }
 
-template <int OUT_BF16>
+template <int OUT>
 __global__ __launch_bounds__(256) void cvt_weight_kernel(const float* __restrict__ src, void* dst,
                                                          int rows, int cols, int cols_pad) {
   const size_t total = (size_t)rows * cols_pad;
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void cvt_weight_kernel(const float* __restrict
     const int c = (int)(i % cols_pad);
     const size_t r = i / cols_pad;
     const float v = c < cols ? src[r * cols + c] : 0.f;
-    if (OUT_BF16) ((uint16_t*)dst)[i] = f2bf(v);
+    if constexpr (OUT == MCM_PREC_BF16) ((uint16_t*)dst)[i] = f2bf(v);
+    else if constexpr (OUT == MCM_PREC_F16) ((_Float16*)dst)[i] = (_Float16)v;
     else ((float*)dst)[i] = v;
   }
 }
@@ -176,17 +178,14 @@ hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, 
   const bool vec = patch % 8 == 0 && kpad == 3 * patch * patch && image % 4 == 0;
   const size_t total = (size_t)B * g * g * (vec ? kpad / 8 : kpad);
   const dim3 grid(grid_for(total)), block(256);
-  if (vec) {
-    if (prec == MCM_PREC_BF16)
-      hipLaunchKernelGGL(patchify8_kernel<1>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
-    else
-      hipLaunchKernelGGL(patchify8_kernel<0>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
-  } else {
-    if (prec == MCM_PREC_BF16)
-      hipLaunchKernelGGL(patchify_kernel<1>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
-    else
-      hipLaunchKernelGGL(patchify_kernel<0>, grid, block, 0, s, pixels, patches, B, image, patch, kpad);
-  }
+#define MCM_LAUNCH_BY_PREC(KERNEL, ...)                                                         \
+  do {                                                                                           \
+    if (prec == MCM_PREC_BF16) hipLaunchKernelGGL(KERNEL<MCM_PREC_BF16>, grid, block, 0, s, __VA_ARGS__); \
+    else if (prec == MCM_PREC_F16) hipLaunchKernelGGL(KERNEL<MCM_PREC_F16>, grid, block, 0, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<MCM_PREC_F32>, grid, block, 0, s, __VA_ARGS__);               \
+  } while (0)
+  if (vec) MCM_LAUNCH_BY_PREC(patchify8_kernel, pixels, patches, B, image, patch, kpad);
+  else MCM_LAUNCH_BY_PREC(patchify_kernel, pixels, patches, B, image, patch, kpad);
   return hipGetLastError();
 }
 
@@ -207,12 +206,8 @@ hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* 
 hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, int cols,
                              int cols_pad, hipStream_t s) {
   const size_t total = (size_t)rows * cols_pad;
-  if (prec == MCM_PREC_BF16)
-    hipLaunchKernelGGL(cvt_weight_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, src, dst, rows,
-                       cols, cols_pad);
-  else
-    hipLaunchKernelGGL(cvt_weight_kernel<0>, dim3(grid_for(total)), dim3(256), 0, s, src, dst, rows,
-                       cols, cols_pad);
+  const dim3 grid(grid_for(total)), block(256);
+  MCM_LAUNCH_BY_PREC(cvt_weight_kernel, src, dst, rows, cols, cols_pad);
   return hipGetLastError();
 }
 

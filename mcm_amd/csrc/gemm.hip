@@ -64,10 +64,8 @@ __device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const
 #pragma unroll
       for (int fq = 0; fq < 4; ++fq) {
         const int fi = h * 4 + fq;
-        if constexpr (PREC == MCM_PREC_BF16) {
-          acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8_t, wf[fj]), __builtin_bit_cast(bf16x8_t, xf[fq]),
-              acc[fj][fi], 0, 0, 0);
+        if constexpr (PREC != MCM_PREC_F32) {
+          acc[fj][fi] = mfma16<PREC>(wf[fj], xf[fq], acc[fj][fi]);
         } else {
           const f32x4_t wv = __builtin_bit_cast(f32x4_t, wf[fj]);
           const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[fq]);
@@ -106,7 +104,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
       if constexpr (EPI == EPI_GELU) {  // same form in every kernel variant: results must not
 #pragma unroll                          // depend on which variant the size heuristic picks
         for (int t = 0; t < 4; ++t)
-          v[fj][t] = PREC == MCM_PREC_BF16 ? quick_gelu_fast(v[fj][t]) : quick_gelu(v[fj][t]);
+          v[fj][t] = PREC != MCM_PREC_F32 ? quick_gelu_fast(v[fj][t]) : quick_gelu(v[fj][t]);
       }
     }
     if constexpr (EPI == EPI_RESID) {
@@ -122,12 +120,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
       const f32x4_t* pr = (const f32x4_t*)(a.pos + (size_t)(1 + p) * a.N + n);
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) dst[fj] = v[fj] + pr[fj];
-    } else if constexpr (PREC == MCM_PREC_BF16) {
+    } else if constexpr (PREC != MCM_PREC_F32) {
       uint4* dst = (uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n);
-      dst[0] = make_uint4(pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]),
-                          pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3]));
-      dst[1] = make_uint4(pack_bf2(v[2][0], v[2][1]), pack_bf2(v[2][2], v[2][3]),
-                          pack_bf2(v[3][0], v[3][1]), pack_bf2(v[3][2], v[3][3]));
+      dst[0] = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
+                          pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
+      dst[1] = make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
+                          pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
     } else {
       f32x4_t* dst = (f32x4_t*)((float*)a.out + (size_t)m * a.ldo + n);
 #pragma unroll
@@ -147,7 +145,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
                                                   char* scratch) {
   const int fr = lane & 15, g = lane >> 4;
-  if constexpr (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) {
+  if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     const int rrow = lane >> 3, c8 = lane & 7;  // read-back: 8 lanes per 128-B row
     const int n = nw + c8 * 8;
 #pragma unroll
@@ -166,11 +164,11 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         }
         const int sw = row & 7;
         *(uint4*)(scratch + row * 128 + (((g * 2) ^ sw) << 4)) =
-            make_uint4(pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]),
-                       pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3]));
+            make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
+                       pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
         *(uint4*)(scratch + row * 128 + (((g * 2 + 1) ^ sw) << 4)) =
-            make_uint4(pack_bf2(v[2][0], v[2][1]), pack_bf2(v[2][2], v[2][3]),
-                       pack_bf2(v[3][0], v[3][1]), pack_bf2(v[3][2], v[3][3]));
+            make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
+                       pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 4 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) ? 8 : 16;
+  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 8 : 16;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
 
@@ -544,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 8 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC == MCM_PREC_BF16 && EPI <= EPI_GELU) ? 16 : 32;
+  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 16 : 32;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
 
@@ -750,6 +748,10 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)
     return hipErrorInvalidValue;
-  return prec == MCM_PREC_BF16 ? launch_prec<MCM_PREC_BF16>(epi, a, s)
-                               : launch_prec<MCM_PREC_F32>(epi, a, s);
+  switch (prec) {
+    case MCM_PREC_BF16: return launch_prec<MCM_PREC_BF16>(epi, a, s);
+    case MCM_PREC_F16: return launch_prec<MCM_PREC_F16>(epi, a, s);
+    case MCM_PREC_F32: return launch_prec<MCM_PREC_F32>(epi, a, s);
+  }
+  return hipErrorInvalidValue;
 }

@@ -12,7 +12,7 @@ namespace {
 
 constexpr int MAXV = 4;  // float4 per lane: D <= 64*4*4 = 1024
 
-template <int OUT_BF16>
+template <int OUT>  // OUT = MCM_PREC_F32: fp32 rows; BF16 / F16: packed 16-bit rows
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, void* y,
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
       o.y = v[i].y * rstd * gv.y + bv.y;
       o.z = v[i].z * rstd * gv.z + bv.z;
       o.w = v[i].w * rstd * gv.w + bv.w;
-      if (OUT_BF16) {
+      if constexpr (OUT != MCM_PREC_F32) {
         uint2 pk;
-        pk.x = pack_bf2(o.x, o.y);
-        pk.y = pack_bf2(o.z, o.w);
+        pk.x = pack2<OUT>(o.x, o.y);
+        pk.y = pack2<OUT>(o.z, o.w);
         *(uint2*)((uint16_t*)y + (size_t)row * ys + d) = pk;
       } else {
         *(float4*)((float*)y + (size_t)row * ys + d) = o;
@@ -76,8 +76,10 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
   if (xs % 4 || ys % 4) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
   if (prec == MCM_PREC_BF16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+  else if (prec == MCM_PREC_F16 && !out_f32)
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
   else
-    hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
   return hipGetLastError();
 }

@@ -266,7 +266,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!cfg || !out) return fail(nullptr, MCM_EINVAL, "null argument");
   if (cfg->abi_version != MCM_ABI_VERSION) return fail(nullptr, MCM_EINVAL, "ABI version mismatch");
   const mcm_config& c = *cfg;
-  if (c.precision != MCM_PREC_BF16 && c.precision != MCM_PREC_F32)
+  if (c.precision != MCM_PREC_BF16 && c.precision != MCM_PREC_F32 && c.precision != MCM_PREC_F16)
     return fail(nullptr, MCM_EINVAL, "unknown precision");
   if (c.v_heads <= 0 || c.t_heads <= 0 || c.v_width != c.v_heads * 64 || c.t_width != c.t_heads * 64)
     return fail(nullptr, MCM_EINVAL, "head_dim must be 64");

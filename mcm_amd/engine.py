@@ -23,7 +23,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .config import CConfig, ClipGeometry, PREC_BF16, PREC_F32, SCORE_KINDS, geometry
+from .config import CConfig, ClipGeometry, PREC_BF16, PREC_F16, PREC_F32, SCORE_KINDS, geometry
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcm_hip.so")
@@ -99,7 +99,8 @@ class NativeCLIP:
             raise RuntimeError("NativeCLIP needs a HIP device (no CPU fallback)")
         self.geo = geometry(geo) if isinstance(geo, str) else geo
         self.device = torch.device("cuda", device)
-        self.precision = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}[precision]
+        self.precision = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp16": PREC_F16,
+                          "f16": PREC_F16}[precision]
         self.max_batch = int(max_batch)
         self._lib = load_library()
         torch.cuda.set_device(self.device)

@@ -13,8 +13,18 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+PREC = {"bf16": 0, "fp32": 1, "fp16": 2}
+DTYPE = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}
+# relative rounding step of a 16-bit output (bf16: 8 significand bits, fp16: 11)
+OUT_TOL = {"bf16": 1.2e-2, "fp16": 2e-3}
+
+
+def _round_to(a: np.ndarray, prec: str) -> np.ndarray:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DTYPE[prec]).float().numpy()
+
+
 def _bf16_round(a: np.ndarray) -> np.ndarray:
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+    return _round_to(a, "bf16")
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +50,7 @@ def _ptr(t):
 
 
 @pytest.mark.parametrize("D", [128, 512, 768, 1024])
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 def test_layernorm(tiny_net, D, prec):
     from oracle import oracle as orc
 
@@ -50,17 +60,18 @@ def test_layernorm(tiny_net, D, prec):
     g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
     b = (0.1 * rng.standard_normal(D)).astype(np.float32)
     want = orc.layernorm(x, g, b, 1e-5)
-    p = 0 if prec == "bf16" else 1
-    y = torch.empty((M, D), device="cuda", dtype=torch.bfloat16 if p == 0 else torch.float32)
+    p = PREC[prec]
+    y = torch.empty((M, D), device="cuda", dtype=DTYPE[prec])
     xd, gd, bd = _dev(x), _dev(g), _dev(b)
     rc = tiny_net._lib.mcm_op_layernorm(tiny_net._h, p, _ptr(xd), _ptr(gd), _ptr(bd), _ptr(y), M, D,
                                         1e-5, 0, None)
     assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
     torch.cuda.synchronize()
     got = y.float().cpu().numpy()
-    if p == 0:
-        np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
-        assert np.abs(got - _bf16_round(want)).max() <= 2 ** -6  # ≤ 1 bf16 ulp at |x|<4
+    if prec != "fp32":
+        np.testing.assert_allclose(got, want, rtol=OUT_TOL[prec], atol=OUT_TOL[prec])
+        ulp = 2 ** -6 if prec == "bf16" else 2 ** -9  # one output ulp at |x| < 4
+        assert np.abs(got - _round_to(want, prec)).max() <= ulp
     else:
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
     # in-place fp32 (pre_layrnorm form)
@@ -93,7 +104,7 @@ def gemm_variant(request, tiny_net):
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
     from oracle import oracle as orc
@@ -103,11 +114,11 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
     w = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)  # asymmetric by construction
     bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
     resid0 = rng.standard_normal((M, N)).astype(np.float32)
-    p = 0 if prec == "bf16" else 1
-    if p == 0:
-        x, w = _bf16_round(x), _bf16_round(w)
+    p = PREC[prec]
+    if prec != "fp32":
+        x, w = _round_to(x, prec), _round_to(w, prec)
     lin = orc.linear(x, w, bias)
-    dt = torch.bfloat16 if p == 0 else torch.float32
+    dt = DTYPE[prec]
     xd, wd, bd = _dev(x, dt), _dev(w, dt), _dev(bias)
     y = torch.zeros((M, N), device="cuda", dtype=dt)
     rd = _dev(resid0)
@@ -121,8 +132,8 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
         got, want = y.float().cpu().numpy(), orc.quick_gelu(lin)
     else:
         got, want = rd.cpu().numpy(), resid0 + lin
-    if p == 0 and epi != 2:
-        np.testing.assert_allclose(got, want, rtol=1.2e-2, atol=1.2e-2)  # bf16 output rounding
+    if prec != "fp32" and epi != 2:
+        np.testing.assert_allclose(got, want, rtol=OUT_TOL[prec], atol=OUT_TOL[prec])  # 16-bit output rounding
     else:
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)      # fp32 accumulation order
 
@@ -132,7 +143,7 @@ ATTN_CASES = [(3, 197, 12, False), (2, 50, 12, False), (5, 17, 2, False), (4, 77
 
 
 @pytest.mark.parametrize("nseq,L,heads,causal", ATTN_CASES)
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 def test_attention(tiny_net, nseq, L, heads, causal, prec):
     from oracle import oracle as orc
 
@@ -140,19 +151,21 @@ def test_attention(tiny_net, nseq, L, heads, causal, prec):
     D = heads * 64
     qkv = rng.standard_normal((nseq * L, 3 * D)).astype(np.float32)
     qkv[:, :2 * D] *= 1.5  # O(1)-spread logits after the 0.125 scale: a non-uniform softmax
-    p = 0 if prec == "bf16" else 1
-    if p == 0:
-        qkv = _bf16_round(qkv)
+    p = PREC[prec]
+    if prec != "fp32":
+        qkv = _round_to(qkv, prec)
     want = orc.attention(qkv, nseq, L, heads, 64, causal)
-    dt = torch.bfloat16 if p == 0 else torch.float32
+    dt = DTYPE[prec]
     qd = _dev(qkv, dt)
     out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
     rc = tiny_net._lib.mcm_op_attention(tiny_net._h, p, _ptr(qd), _ptr(out), nseq, L, heads, int(causal), None)
     assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
-    if p == 0:
+    if prec == "bf16":
         np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)  # bf16 P and bf16 output
+    elif prec == "fp16":
+        np.testing.assert_allclose(got, want, rtol=3e-3, atol=3e-3)  # fp16 P and fp16 output
     else:
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
 
