@@ -132,6 +132,23 @@ int mcm_score_features(mcm_handle* h, const float* img_feat_dev, int32_t B,
 int mcm_score(mcm_handle* h, const float* pixels_dev, int32_t B, const float* text_feat_dev,
               int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
 
+/* uint8 ingest: pixels_dev is uint8 NHWC [B,image_size,image_size,3] (what a
+ * JPEG decoder + resize/crop produces); ToTensor (/255) and Normalize with the CLIP mean/std of
+ * utils/train_eval_util.py:27-33 are fused into the patch gather.  Same results as
+ * mcm_encode_image / mcm_score on the equivalent fp32 NCHW tensor. */
+int mcm_encode_image_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, float* out_dev,
+                        void* stream);
+int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const float* text_feat_dev,
+                 int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
+
+/* Prompt-ensemble bank (BASELINE config 5): feats_dev = unit-norm text
+ * features [K*T, proj_dim], class-major (row k*T + t = template t of class k), as written by
+ * mcm_encode_text; bank_dev [K, proj_dim] = normalise(mean over the T templates).  The reference
+ * ships the 80 templates (utils/imagenet_templates.py) but never calls them; this is the
+ * standard CLIP zero-shot recipe. */
+int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T, float* bank_dev,
+                    void* stream);
+
 /* ---- per-kernel timing (HIP events on the caller's stream) -------------------------
  * When enabled, every kernel launch of the encode path is bracketed by a pair of
  * pre-created hipEvents.  mcm_profile_read synchronises the stream, accumulates the

@@ -132,6 +132,10 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);
+hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, int B, int image,
+                              int patch, int kpad, const float* mean, const float* stdv,
+                              hipStream_t s);
+hipError_t launch_bank_reduce(const float* feats, int K, int T, int P, float* bank, hipStream_t s);
 hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D,
                            hipStream_t s);
 hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* pos, float* x,

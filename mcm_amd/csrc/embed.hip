@@ -66,6 +66,52 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict_
   }
 }
 
+// uint8 ingest: NHWC uint8 [B,S,S,3] -> patch matrix, fusing ToTensor (/255) and
+// Normalize ((x-mean)/std, reference utils/train_eval_util.py:27-33) into the operand gather, so
+// the H2D feed is 150 KB/image instead of 602 KB.  One thread = one pixel = its 3 channel values
+// scattered to the 3 channel planes of the patch row vector k = (c, py, px).
+template <int OUT>
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ px, void* out,
+                                                          int B, int S, int P, int kpad, float m0,
+                                                          float m1, float m2, float s0, float s1,
+                                                          float s2) {
+  const int g = S / P, np = g * g;
+  const size_t total = (size_t)B * S * S;
+  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % S), y = (int)((i / S) % S), b = (int)(i / ((size_t)S * S));
+    const int gy = y / P, py = y - gy * P, gx = x / P, pxx = x - gx * P;
+    const size_t row = ((size_t)b * np + gy * g + gx) * kpad;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // same operation order as torchvision: ToTensor = u8 / 255, Normalize = (t - mean) / std
+      const float v = ((float)px[i * 3 + c] / 255.0f - mean[c]) / stdv[c];
+      const size_t o = row + (size_t)(c * P + py) * P + pxx;
+      if constexpr (OUT == MCM_PREC_BF16) ((uint16_t*)out)[o] = f2bf(v);
+      else if constexpr (OUT == MCM_PREC_F16) ((_Float16*)out)[o] = (_Float16)v;
+      else ((float*)out)[o] = v;
+    }
+  }
+}
+
+// prompt-ensemble bank: feats [K*T, P] unit rows, class-major (row k*T + t) ->
+// bank[k] = normalise(mean_t feats[k*T + t]).  One wave per class.
+__global__ __launch_bounds__(256) void bank_reduce_kernel(const float* __restrict__ feats, int K,
+                                                          int T, int P, float* __restrict__ bank) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= K) return;
+  float sq = 0.f;
+  for (int d = lane; d < P; d += 64) {
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += feats[((size_t)k * T + t) * P + d];
+    a /= (float)T;
+    bank[(size_t)k * P + d] = a;
+    sq += a * a;
+  }
+  const float rn = 1.0f / sqrtf(wave_sum(sq));
+  for (int d = lane; d < P; d += 64) bank[(size_t)k * P + d] *= rn;
+}
+
 __global__ __launch_bounds__(256) void cls_rows_kernel(float* x, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, int B,
                                                        int ntok, int D) {
@@ -186,6 +232,27 @@ hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, 
   } while (0)
   if (vec) MCM_LAUNCH_BY_PREC(patchify8_kernel, pixels, patches, B, image, patch, kpad);
   else MCM_LAUNCH_BY_PREC(patchify_kernel, pixels, patches, B, image, patch, kpad);
+  return hipGetLastError();
+}
+
+hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, int B, int image,
+                              int patch, int kpad, const float* mean, const float* stdv,
+                              hipStream_t s) {
+  const size_t total = (size_t)B * image * image;
+  const dim3 grid(grid_for(total)), block(256);
+  if (kpad != 3 * patch * patch) {  // padded K (L/14): the pad columns must be zero
+    hipError_t e = hipMemsetAsync(patches, 0, (size_t)B * (image / patch) * (image / patch) * kpad *
+                                                   prec_esize(prec), s);
+    if (e != hipSuccess) return e;
+  }
+  MCM_LAUNCH_BY_PREC(patchify_u8_kernel, pixels, patches, B, image, patch, kpad, mean[0], mean[1],
+                     mean[2], stdv[0], stdv[1], stdv[2]);
+  return hipGetLastError();
+}
+
+hipError_t launch_bank_reduce(const float* feats, int K, int T, int P, float* bank, hipStream_t s) {
+  if (K <= 0 || T <= 0 || P <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bank_reduce_kernel, dim3((K + 3) / 4), dim3(256), 0, s, feats, K, T, P, bank);
   return hipGetLastError();
 }
 

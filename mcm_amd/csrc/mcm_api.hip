@@ -398,7 +398,15 @@ int mcm_finalize_weights(mcm_handle* h) {
   return MCM_OK;
 }
 
-int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream) {
+}  // extern "C" (re-opened below)
+
+namespace {
+// preprocess constants of the reference (utils/train_eval_util.py:27-28)
+const float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+const float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+
+int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B, float* out_dev,
+                      void* stream) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
@@ -408,8 +416,12 @@ int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* o
   const int D = c.v_width;
   {
     Scope sc(h, s, MCM_KC_PATCHIFY, 0.0);
-    HIP_TRY(h, launch_patchify(c.precision, pixels_dev, h->patches, B, c.image_size, c.patch_size,
-                               h->kpad, s));
+    if (u8)
+      HIP_TRY(h, launch_patchify_u8(c.precision, (const uint8_t*)pixels_dev, h->patches, B, c.image_size,
+                                    c.patch_size, h->kpad, kClipMean, kClipStd, s));
+    else
+      HIP_TRY(h, launch_patchify(c.precision, (const float*)pixels_dev, h->patches, B, c.image_size,
+                                 c.patch_size, h->kpad, s));
   }
   GemmArgs a{};
   a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
@@ -431,6 +443,33 @@ int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* o
                                    W(h, "vision_model.post_layernorm.bias"), c.ln_eps,
                                    W(h, "visual_projection.weight"), c.proj_dim, out_dev, s));
   }
+  return MCM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream) {
+  return encode_image_impl(h, pixels_dev, false, B, out_dev, stream);
+}
+
+int mcm_encode_image_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, float* out_dev,
+                        void* stream) {
+  return encode_image_impl(h, pixels_dev, true, B, out_dev, stream);
+}
+
+int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const float* text_feat_dev,
+                 int32_t K, float T, int32_t kind, float* scores_dev, void* stream) {
+  int rc = encode_image_impl(h, pixels_dev, true, B, h ? h->feat : nullptr, stream);
+  if (rc) return rc;
+  return mcm_score_features(h, h->feat, B, text_feat_dev, K, T, kind, scores_dev, stream);
+}
+
+int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T, float* bank_dev,
+                    void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!feats_dev || !bank_dev || K <= 0 || T <= 0) return fail(h, MCM_EINVAL, "bad argument");
+  HIP_TRY(h, launch_bank_reduce(feats_dev, K, T, h->cfg.proj_dim, bank_dev, (hipStream_t)stream));
   return MCM_OK;
 }
 

@@ -31,6 +31,26 @@ def encode_prompt_bank(args, net, test_labels):
                                  attention_mask=text_inputs["attention_mask"])
 
 
+# A small built-in template set for the prompt-ensemble bank (BASELINE config 5).  The reference
+# ships OpenAI's 80 ImageNet templates as data but never uses them; pass your own list (e.g. read
+# from that file) through `templates=` to reproduce the 80-template recipe.
+DEFAULT_TEMPLATES = ["a photo of a {c}", "a blurry photo of a {c}", "a close-up photo of a {c}",
+                     "a photo of the {c}", "a drawing of a {c}", "a bright photo of a {c}",
+                     "a cropped photo of a {c}", "a photo of a small {c}", "a photo of a large {c}"]
+
+
+def encode_prompt_ensemble(args, net, test_labels, templates=None):
+    """CLIP zero-shot ensemble bank: per class, encode every template, normalise, average,
+    re-normalise → [K,P].  Still a [K,P] bank, so the scoring path is unchanged."""
+    templates = list(templates or DEFAULT_TEMPLATES)
+    labels = list(test_labels)
+    tokenizer = load_tokenizer(getattr(args, "ckpt", ""))
+    prompts = [t.format(c=c) if "{c}" in t else t.format(c) for c in labels for t in templates]
+    tok = tokenizer(prompts, padding=True, return_tensors="pt")
+    feats = net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"])
+    return net.reduce_bank(feats, len(labels), len(templates))
+
+
 def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
     """Scores every sample of `loader` against the concept bank `test_labels`.
 
@@ -52,7 +72,10 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
     rank, ws = mdist.world()
     n_total = len(loader.dataset)
     with torch.no_grad():
-        text_features = encode_prompt_bank(args, net, test_labels)
+        if getattr(args, "templates", None):
+            text_features = encode_prompt_ensemble(args, net, test_labels, args.templates)
+        else:
+            text_features = encode_prompt_bank(args, net, test_labels)
         if ws > 1 and hasattr(loader, "shard"):
             lo, hi = mdist.shard_range(n_total, rank, ws)
             batches = loader.shard(lo, hi)

@@ -67,6 +67,9 @@ def load_library():
     L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.mcm_debug_gemm_variant.argtypes = [i32]
+    L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
+    L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
+    L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
     if L.mcm_abi_version() != 1:
         raise RuntimeError("libmcm_hip.so ABI version mismatch")
     _lib = L
@@ -77,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "mcm_abi_version", "mcm_create", "mcm_destroy", "mcm_last_error", "mcm_set_weight",
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
-    "mcm_op_attention", "mcm_debug_gemm_variant",
+    "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
+    "mcm_reduce_bank",
 ]
 
 
@@ -143,6 +147,10 @@ class NativeCLIP:
         import torch
 
         S = self.geo.image_size
+        if pixel_values.dtype == torch.uint8:  # NHWC uint8 ingest (fused /255 + normalise)
+            if pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (S, S, 3):
+                raise ValueError(f"uint8 input must be [b,{S},{S},3] NHWC, got {tuple(pixel_values.shape)}")
+            return pixel_values.to(device=self.device).contiguous()
         if pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (3, S, S):
             # HF modeling_clip.py:204-207 raises ValueError on a wrong image size
             raise ValueError(f"Input image size {tuple(pixel_values.shape)} doesn't match model (3x{S}x{S}).")
@@ -156,11 +164,11 @@ class NativeCLIP:
         import torch
 
         px = self._pixels(pixel_values)
+        fn = self._lib.mcm_encode_image_u8 if px.dtype == torch.uint8 else self._lib.mcm_encode_image
         out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
         for s in range(0, px.shape[0], self.max_batch):
             n = min(self.max_batch, px.shape[0] - s)
-            self._check(self._lib.mcm_encode_image(self._h, px[s:s + n].data_ptr(), n,
-                                                   out[s:s + n].data_ptr(), _stream_ptr()))
+            self._check(fn(self._h, px[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), _stream_ptr()))
         return out
 
     def get_text_features(self, input_ids, attention_mask=None, normalize: bool = False):
@@ -199,14 +207,24 @@ class NativeCLIP:
         import torch
 
         px = self._pixels(pixel_values)
+        fn = self._lib.mcm_score_u8 if px.dtype == torch.uint8 else self._lib.mcm_score
         t = text_features
         if out is None:
             out = torch.empty(px.shape[0], device=self.device, dtype=torch.float32)
         for s in range(0, px.shape[0], self.max_batch):
             n = min(self.max_batch, px.shape[0] - s)
-            self._check(self._lib.mcm_score(self._h, px[s:s + n].data_ptr(), n, t.data_ptr(), t.shape[0],
-                                            float(T), SCORE_KINDS[score], out[s:s + n].data_ptr(),
-                                            _stream_ptr()))
+            self._check(fn(self._h, px[s:s + n].data_ptr(), n, t.data_ptr(), t.shape[0], float(T),
+                           SCORE_KINDS[score], out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def reduce_bank(self, text_features, K: int, T: int):
+        """[K*T,P] unit-norm template features (class-major) → [K,P] ensemble bank."""
+        import torch
+
+        f = text_features.to(device=self.device, dtype=torch.float32).contiguous()
+        assert f.shape[0] == K * T
+        out = torch.empty((K, self.geo.proj_dim), device=self.device, dtype=torch.float32)
+        self._check(self._lib.mcm_reduce_bank(self._h, f.data_ptr(), K, T, out.data_ptr(), _stream_ptr()))
         return out
 
     # -- per-kernel timing -------------------------------------------------------------------

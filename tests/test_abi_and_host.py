@@ -26,7 +26,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "mcm.h")).read()
-    declared = set(re.findall(r"\b(mcm_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mcm_[a-z0-9_]+)\s*\(", header))
     declared -= {"mcm_handle", "mcm_config"}
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     for sym in declared:

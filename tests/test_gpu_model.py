@@ -257,3 +257,47 @@ def test_other_checkpoints_vs_oracle(name):
         net.close()
     assert got_i.shape == (2, geo.proj_dim) and got_t.shape == (3, geo.proj_dim)
     assert _cos(got_i, want_i).min() > 0.999 and _cos(got_t, want_t).min() > 0.999
+
+
+def test_uint8_ingest_matches_float_path():
+    """N2: uint8 NHWC + fused ToTensor/Normalize == the fp32 NCHW path on the same pixels."""
+    from oracle import oracle as orc
+
+    geo = geometry("B16-2L")
+    sd = synth_state_dict(geo, 0)
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, size=(5, geo.image_size, geo.image_size, 3), dtype=np.uint8)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    f32 = ((u8.astype(np.float32) / np.float32(255.0) - mean) / std).transpose(0, 3, 1, 2).copy()
+    want = orc.OracleCLIP(geo, sd).encode_image(f32)
+    net = _net("B16-2L", "fp32", max_batch=8, max_prompt_tokens=1024)
+    try:
+        got_u8 = net.get_image_features(pixel_values=torch.from_numpy(u8).cuda()).cpu().numpy()
+        got_f = net.get_image_features(pixel_values=torch.from_numpy(f32).cuda()).cpu().numpy()
+    finally:
+        net.close()
+    np.testing.assert_allclose(got_u8, want, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got_u8, got_f, rtol=0, atol=2e-6)
+
+
+def test_prompt_ensemble_bank():
+    """N3: bank[k] = normalise(mean_t normalise(feat[k,t])) vs numpy on the same features."""
+    from mcm_amd import detection
+
+    net = _net("tiny", "fp32", max_batch=8, max_prompt_tokens=4096)
+    try:
+        args = types.SimpleNamespace(ckpt="ViT-B/16", model="CLIP", score="MCM", T=1)
+        labels = class_names(7)
+        bank = detection.encode_prompt_ensemble(args, net, labels).cpu().numpy()
+        T = len(detection.DEFAULT_TEMPLATES)
+        tok = detection.load_tokenizer("x")
+        prompts = [t.format(c=c) for c in labels for t in detection.DEFAULT_TEMPLATES]
+        ids = tok(prompts, padding=True, return_tensors="pt")["input_ids"]
+        feats = net.get_text_features(input_ids=ids).cpu().numpy().reshape(7, T, -1)
+    finally:
+        net.close()
+    want = feats.mean(axis=1)
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    assert bank.shape == (7, 64)
+    np.testing.assert_allclose(bank, want, rtol=0, atol=1e-6)
