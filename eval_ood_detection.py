@@ -49,6 +49,8 @@ def process_args(argv=None):
     # additive
     p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="MFMA operand precision")
+    p.add_argument("--host-metrics", action="store_true",
+                   help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
     args = p.parse_args(argv)
     args.n_cls = get_num_cls(args)
@@ -105,14 +107,15 @@ def main(argv=None):
     size = net.geo.image_size
     test_loader = _loader(args, N_ID[args.in_dataset], size, ood=False)
     test_labels = get_test_labels(args, test_loader)
-    in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True)
+    on_dev = not args.host_metrics  # scores stay in HBM; only the three metrics come back
+    in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
     auroc_list, aupr_list, fpr_list = [], [], []
     for out_dataset in out_datasets:
         log.debug(f"Evaluting OOD dataset {out_dataset}")
         ood_loader = _loader(args, N_OOD[out_dataset], size, ood=True)
-        out_score = get_ood_scores_clip(args, net, ood_loader, test_labels)
+        out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
         if rank == 0:
-            get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list)
+            get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list, net=net)
     if rank == 0:
         log.debug("\n\nMean Test Results")
         print_measures(log, np.mean(auroc_list), np.mean(aupr_list), np.mean(fpr_list), method_name=args.score)

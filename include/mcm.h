@@ -149,6 +149,17 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
 int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T, float* bank_dev,
                     void* stream);
 
+/* Detection metrics on the device: replaces get_measures /
+ * fpr_and_fdr_at_recall, reference utils/detection_util.py:66-119, incl. the sklearn
+ * roc_auc_score / average_precision_score calls at :115-116.  pos_dev [n_pos] = scores of the
+ * ID set (the positive class, :112-113), neg_dev [n_neg] = scores of one OOD set, both device
+ * fp32; negate != 0 evaluates on -score, which is how the reference calls it
+ * (get_and_print_results, :255: the stored scores are negated confidences).
+ * out_host[0..2] = AUROC, AUPR, FPR at the operating point whose recall is closest to
+ * recall_level (0.95 in the reference), same tie rules as the reference.  Synchronises `stream`. */
+int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
+                 int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream);
+
 /* ---- per-kernel timing (HIP events on the caller's stream) -------------------------
  * When enabled, every kernel launch of the encode path is bracketed by a pair of
  * pre-created hipEvents.  mcm_profile_read synchronises the stream, accumulates the

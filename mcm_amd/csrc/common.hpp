@@ -150,3 +150,9 @@ hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_s
 
 hipError_t launch_score(const float* img, int B, const float* text, int K, int P, float T,
                         int kind, float* scores, hipStream_t s);
+
+// metrics.hip: AUROC / AUPR / FPR@recall of two device score vectors; results land in the first
+// 4 doubles of `workspace` (>= measures_workspace_bytes(n_pos + n_neg)), *out_dev points at them
+size_t measures_workspace_bytes(long n);
+hipError_t launch_measures(const float* pos, long n_pos, const float* neg, long n_neg, int negate,
+                           double level, void* workspace, double** out_dev, hipStream_t s);

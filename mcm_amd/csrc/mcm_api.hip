@@ -473,6 +473,26 @@ int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T,
   return MCM_OK;
 }
 
+int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
+                 int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!pos_dev || !neg_dev || !out_host) return fail(h, MCM_EINVAL, "null pointer");
+  if (n_pos <= 0 || n_neg <= 0 || n_pos + n_neg > 0x7fffffffLL)
+    return fail(h, MCM_EINVAL, "both score vectors must be non-empty");
+  if (!(recall_level >= 0.0 && recall_level <= 1.0)) return fail(h, MCM_EINVAL, "recall_level outside [0,1]");
+  hipStream_t s = (hipStream_t)stream;
+  void* ws = nullptr;
+  HIP_TRY(h, hipMalloc(&ws, measures_workspace_bytes((long)(n_pos + n_neg))));
+  double* out_dev = nullptr;
+  hipError_t e = launch_measures(pos_dev, (long)n_pos, neg_dev, (long)n_neg, negate, recall_level, ws,
+                                 &out_dev, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, out_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  HIP_TRY(h, e);
+  return MCM_OK;
+}
+
 int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S, float* out_dev,
                     void* stream) {
   int rc = check_ready(h);

@@ -51,7 +51,7 @@ def encode_prompt_ensemble(args, net, test_labels, templates=None):
     return net.reduce_bank(feats, len(labels), len(templates))
 
 
-def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
+def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_out=False):
     """Scores every sample of `loader` against the concept bank `test_labels`.
 
     Same contract as reference utils/detection_util.py:209-249: reads `args.ckpt`,
@@ -59,6 +59,8 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
     in dataset order; returns float32 ndarray `[len(loader.dataset)]` of *negated*
     confidences (lower = more ID) for MCM / max-logit / energy / var and the entropy for
     'entropy'.  `in_dist` and the labels are unused, as in the reference.
+    `device_out=True` (an addition) returns the same vector as a device tensor instead, for
+    `get_and_print_results(..., net=net)` to evaluate without a host round trip.
     """
     import torch
 
@@ -99,6 +101,8 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False):
                 full = _gather_batch_shards(local, loader, n_total, ws)
         else:
             full = local
+    if device_out:
+        return full.detach()[:n_total]
     return full.detach().cpu().numpy().astype(np.float32, copy=False)[:n_total].copy()
 
 
@@ -135,10 +139,18 @@ def print_measures(log, auroc, aupr, fpr, method_name="Ours", recall_level=0.95)
         log.debug("& {:.2f} & {:.2f} & {:.2f}".format(100 * fpr, 100 * auroc, 100 * aupr))
 
 
-def get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list):
+def get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list, net=None):
     """Reference utils/detection_util.py:253-265: the scores are negated confidences, so the
-    metrics are taken on their negation with ID as the positive class."""
-    auroc, aupr, fpr = get_measures(-in_score, -out_score)
+    metrics are taken on their negation with ID as the positive class.  Device tensors (from
+    `get_ood_scores_clip(..., device_out=True)`) are evaluated by the native metric kernels
+    of `net`; ndarrays go through the host implementation exactly like the reference."""
+    if hasattr(in_score, "is_cuda"):
+        if net is None or not hasattr(net, "measures"):
+            raise TypeError("device score tensors need net= (a NativeCLIP) for the metric kernels")
+        auroc, aupr, fpr = net.measures(in_score, out_score, negate=True)
+        in_score, out_score = in_score[:3].cpu().numpy(), out_score[:3].cpu().numpy()
+    else:
+        auroc, aupr, fpr = get_measures(-in_score, -out_score)
     print(f"in score samples (random sampled): {in_score[:3]}, out score samples: {out_score[:3]}")
     auroc_list.append(auroc)
     aupr_list.append(aupr)

@@ -70,6 +70,8 @@ def load_library():
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
+                               ctypes.POINTER(ctypes.c_double), vp]
     if L.mcm_abi_version() != 1:
         raise RuntimeError("libmcm_hip.so ABI version mismatch")
     _lib = L
@@ -81,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
     "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
-    "mcm_reduce_bank",
+    "mcm_reduce_bank", "mcm_measures",
 ]
 
 
@@ -226,6 +228,20 @@ class NativeCLIP:
         out = torch.empty((K, self.geo.proj_dim), device=self.device, dtype=torch.float32)
         self._check(self._lib.mcm_reduce_bank(self._h, f.data_ptr(), K, T, out.data_ptr(), _stream_ptr()))
         return out
+
+    def measures(self, pos_scores, neg_scores, recall_level: float = 0.95, negate: bool = False):
+        """`get_measures` (reference utils/detection_util.py:108-119) on device score vectors:
+        (auroc, aupr, fpr) with ID = positive class; `negate=True` evaluates on -score, which is
+        how `get_and_print_results` (:255) calls it."""
+        import torch
+
+        pos = pos_scores.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        neg = neg_scores.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        out = (ctypes.c_double * 3)()
+        self._check(self._lib.mcm_measures(self._h, pos.data_ptr(), pos.numel(), neg.data_ptr(),
+                                           neg.numel(), int(negate), float(recall_level), out,
+                                           _stream_ptr()))
+        return float(out[0]), float(out[1]), float(out[2])
 
     # -- per-kernel timing -------------------------------------------------------------------
     def profile(self, on: bool):
