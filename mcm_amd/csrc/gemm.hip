@@ -140,6 +140,18 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
 // wave bounces its tile through a private 4-KiB LDS window (XOR-swizzled, conflict-free both
 // ways) and writes whole rows: one store instruction = 8 full 128-B lines (bf16) or 4 x 256 B
 // (fp32).  The fp32 residual form reads the matching rows the same way, one chunk ahead.
+// 16-byte global store; `stream` adds the non-temporal hint.  A tile round of the persistent
+// kernels writes 4 MiB per XCD — the whole L2 — so write-back-allocated output lines evict the
+// X / W panels the next K-loop is about to re-read; streamed lines do not (+9 % on the QKV shape).
+template <typename V>
+__device__ __forceinline__ void store16_stream(void* p, const V& v, bool stream) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte payload");
+  const u32x4_t vv = __builtin_bit_cast(u32x4_t, v);
+  if (stream) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(vv) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(vv) : "memory");
+}
+
 template <int PREC, int EPI, int MF>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
@@ -175,7 +187,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         const int row = t * 8 + rrow;
         const uint4 v = *(const uint4*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4));
         const int m = mw + c * 32 + row;
-        if (m < a.M && n < a.N) *(uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n) = v;
+        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, v, !(a.dbg & 16));
       }
     }
   } else {
@@ -239,7 +251,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         if constexpr (ADD) v += r[t];
         bool ok;
         float* dst = row_ptr(c, t, ok);
-        if (ok) *(f32x4_t*)dst = v;
+        if (ok) store16_stream(dst, v, (a.dbg & 32) != 0);
       }
     }
   }
@@ -631,9 +643,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!(a.dbg & 4))
-        wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, lane,
+      if (!(a.dbg & 4)) {
+        // dbg 8 (harness only): fold every tile's stores onto a 64-tile region that stays in L2
+        const int em0 = (a.dbg & 8) ? (int)(blockIdx.x & 63) * BM : cm0;
+        const int en0 = (a.dbg & 8) ? 0 : cn0;
+        wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
                                         smem + 2 * STAGE_BYTES + wave * 4096);
+      }
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
       ktc = 0;
@@ -729,7 +745,7 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 void gemm_set_variant(int v) { g_variant = v; }
 
 int g_group_n = [] { const char* e = getenv("MCM_GEMM_GN"); return e ? atoi(e) : 0; }();  // 0 = heuristic
-int g_dbg = 0;
+int g_dbg = [] { const char* e = getenv("MCM_GEMM_DBG"); return e ? atoi(e) : 0; }();
 void gemm_set_dbg(int d) { g_dbg = d; }
 void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
 
