@@ -44,21 +44,19 @@ __device__ __forceinline__ int frag_off(int fr, int g, int kk) {
   return (fr >> 1) * 256 + ((((fr & 1) << 3) | (((kk * 4 + g) ^ (fr >> 1)) & 7)) << 4);
 }
 
-// one K-step of a (MF*16)x64 wave tile: MF x 4 fragments, operands at xs / ws (+ f*2048 per
-// 16 rows); x fragments are consumed four at a time to bound live registers
+// one 32-wide K half (kk = 0 / 1) of a K-step of a (MF*16)x64 wave tile: MF x 4 fragments,
+// operands at xs / ws (+ f*2048 per 16 rows); x fragments are consumed four at a time to bound
+// live registers
 template <int PREC, int MF>
-__device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const int (&foff)[2],
-                                           f32x4_t (&acc)[4][MF]) {
+__device__ __forceinline__ void wave_khalf(const char* xs, const char* ws, int foff, f32x4_t (&acc)[4][MF]) {
+  uint4 wf[4];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    uint4 wf[4];
+  for (int f = 0; f < 4; ++f) wf[f] = *(const uint4*)(ws + f * 2048 + foff);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) wf[f] = *(const uint4*)(ws + f * 2048 + foff[kk]);
-#pragma unroll
-    for (int h = 0; h < MF / 4; ++h) {
+  for (int h = 0; h < MF / 4; ++h) {
     uint4 xf[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) xf[f] = *(const uint4*)(xs + (h * 4 + f) * 2048 + foff[kk]);
+    for (int f = 0; f < 4; ++f) xf[f] = *(const uint4*)(xs + (h * 4 + f) * 2048 + foff);
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj)
 #pragma unroll
@@ -74,8 +72,13 @@ __device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const
             acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], acc[fj][fi], 0, 0, 0);
         }
       }
-    }
   }
+}
+template <int PREC, int MF>
+__device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const int (&foff)[2],
+                                           f32x4_t (&acc)[4][MF]) {
+  wave_khalf<PREC, MF>(xs, ws, foff[0], acc);
+  wave_khalf<PREC, MF>(xs, ws, foff[1], acc);
 }
 
 // W rows are staged into LDS in a permuted order (perm_n below) so that, after the MFMAs, a
@@ -144,12 +147,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
 // kernels writes 4 MiB per XCD — the whole L2 — so write-back-allocated output lines evict the
 // X / W panels the next K-loop is about to re-read; streamed lines do not (+9 % on the QKV shape).
 template <typename V>
-__device__ __forceinline__ void store16_stream(void* p, const V& v, bool stream) {
+__device__ __forceinline__ void store16_stream(void* p, const V& v) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   static_assert(sizeof(V) == 16, "16-byte payload");
   const u32x4_t vv = __builtin_bit_cast(u32x4_t, v);
-  if (stream) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(vv) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(vv) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(vv) : "memory");
 }
 
 template <int PREC, int EPI, int MF>
@@ -187,7 +189,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         const int row = t * 8 + rrow;
         const uint4 v = *(const uint4*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4));
         const int m = mw + c * 32 + row;
-        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, v, !(a.dbg & 16));
+        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, v);
       }
     }
   } else {
@@ -251,7 +253,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         if constexpr (ADD) v += r[t];
         bool ok;
         float* dst = row_ptr(c, t, ok);
-        if (ok) store16_stream(dst, v, (a.dbg & 32) != 0);
+        if (ok) *(f32x4_t*)dst = v;  // fp32 / residual rows: streaming them measured no gain
       }
     }
   }
@@ -548,6 +550,18 @@ constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 KiB epilogue window per wave
 }  // namespace p256
 
+#ifdef MCM_GEMM_TRACE  // harness-only cycle stamps (tools/gemm_bench.hip): a.pos = uint64 buffer
+#define TRACE(k)                                                                                   \
+  do {                                                                                             \
+    if ((a.dbg & 128) && s < 64 && lane == 0) {                                                    \
+      const uint64_t t = __builtin_amdgcn_s_memtime();                                             \
+      ((uint64_t*)a.pos)[(((size_t)blockIdx.x * 8 + wave) * 64 + s) * 8 + (k)] = t;               \
+    }                                                                                              \
+  } while (0)
+#else
+#define TRACE(k)
+#endif
+
 template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   using namespace p256;
@@ -600,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   };
 
   const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
+  const bool late = wave >= 4;
   const int fr = lane & 15, g = lane >> 4;
   const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
   const int xbase = wr * 128 * ROWB;
@@ -623,22 +638,36 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     cn0 = nt * BN;
   }
   bool stores_pending = false;
+  if (late) __builtin_amdgcn_s_setprio(1);  // the younger half would otherwise lose every arbitration
   for (int s = 0; s < total; ++s) {
     // VMEM issue order: step e (tile end): [DMA stage e+1] ... [stores E]; step e+1:
     // [bias 4] [DMA stage e+2].  Stage s is the youngest DMA at this point, so only the
     // previous tile's stores may stay in flight.
+    TRACE(0);
     if (COUNT_STORES && stores_pending) wait_vmcnt<STORES_PER_EPI>();
     else wait_vmcnt<0>();
+    TRACE(1);
     stores_pending = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    TRACE(2);
     if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
-    if (issued < total) {
-      if (!(a.dbg & 1)) issue(issued & 1);
-      ++issued;
-    }
+    // The two waves of a SIMD (w and w+4) take turns: an LDS-DMA instruction blocks its wave for
+    // 70-155 cycles while the TA takes the 64 addresses (cycle stamps, MCM_GEMM_TRACE), so if both
+    // waves refill at the top of the step the matrix pipe idles through 8 of them and then both
+    // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
+    // priority 1) compute the first K half, refill, compute the second.
+    const bool refill = issued < total;
+    if (refill && !late && !(a.dbg & 1)) issue(issued & 1);
+    TRACE(3);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
-    if (!(a.dbg & 2)) wave_kstep<PREC, 8>(sb + xbase, sb + wbase, foff, acc);
+    if (!(a.dbg & 2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
+    TRACE(4);
+    if (refill && late && !(a.dbg & 1)) issue(issued & 1);
+    if (refill) ++issued;
+    TRACE(5);
+    if (!(a.dbg & 2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
+    TRACE(6);
     if (++ktc == nk) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll

@@ -123,6 +123,43 @@ int main(int argc, char** argv) {
       if (tf > best[v]) best[v] = tf;
       printf("  round %d variant %d: %9.1f us  %7.1f TFLOP/s\n", round, v, us, tf);
     }
+#ifdef MCM_GEMM_TRACE
+  {  // per-step cycle stamps of the persistent 256x256 kernel (variant 3), blocks 0 and 77
+    const size_t words = (size_t)256 * 8 * 64 * 8;
+    uint64_t* dt;
+    CK(hipMalloc(&dt, words * 8));
+    CK(hipMemset(dt, 0, words * 8));
+    GemmArgs b = a;
+    b.pos = (const float*)dt;
+    gemm_set_variant(3);
+    gemm_set_dbg((argc > 7 ? atoi(argv[7]) : 0) | 128);
+    CK(launch_gemm(MCM_PREC_BF16, epi, b, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<uint64_t> ht(words);
+    CK(hipMemcpy(ht.data(), dt, words * 8, hipMemcpyDeviceToHost));
+    const int nk = K / 64;
+    for (int blk : {0, 77}) for (int w : {0, 4}) {
+      double d[8] = {0};
+      int cnt = 0;
+      for (int st = nk; st < 4 * nk && st < 63; ++st) {
+        const uint64_t* r = &ht[(((size_t)blk * 8 + w) * 64 + st) * 8];
+        const uint64_t* rn = r + 8;
+        for (int k = 0; k < 6; ++k) d[k] += (double)(r[k + 1] - r[k]);
+        d[6] += (double)(rn[0] - r[6]);
+        d[7] += (double)(rn[0] - r[0]);
+        ++cnt;
+      }
+      printf("TRACE blk %3d wave %d (avg over %d steps, incl. tile ends): vmwait %.0f  barrier %.0f  issueA %.0f  half0 %.0f  issueB %.0f  half1 %.0f  tail %.0f | step %.0f cyc\n",
+             blk, w, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, d[6] / cnt, d[7] / cnt);
+      // one mid-tile step in full
+      const int st = nk + 3;
+      const uint64_t* r = &ht[(((size_t)blk * 8 + w) * 64 + st) * 8];
+      printf("      step %d:", st);
+      for (int k = 0; k < 6; ++k) printf(" %llu", (unsigned long long)(r[k + 1] - r[k]));
+      printf(" | next %llu\n", (unsigned long long)(r[8] - r[6]));
+    }
+  }
+#endif
   printf("BEST M=%d N=%d K=%d epi=%d:", M, N, K, epi);
   for (int v = 0; v < nvar; ++v) printf(" v%d=%.1f", v, best[v]);
   printf(" TFLOP/s\n");
