@@ -151,7 +151,10 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   static_assert(sizeof(V) == 16, "16-byte payload");
   const u32x4_t vv = __builtin_bit_cast(u32x4_t, v);
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(vv) : "memory");
+  // s_nop 1: a store of more than 64 bits must be 2 wait states away from a VALU write of its data
+  // registers on gfx940+; hipcc pads its own stores but cannot see inside this asm (without the
+  // pad, rows of garbage appeared whenever the TA was slow to pick the data up)
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
 }
 
 template <int PREC, int EPI, int MF>
@@ -160,37 +163,56 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
                                                   char* scratch) {
   const int fr = lane & 15, g = lane >> 4;
   if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
+    // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
+    // written while unit u-1 is read back and stored, so the LDS round trip and the store issue
+    // (a 1-KiB store blocks its wave like an LDS-DMA piece does) overlap the next unit's VALU work.
     const int rrow = lane >> 3, c8 = lane & 7;  // read-back: 8 lanes per 128-B row
     const int n = nw + c8 * 8;
+    auto write_unit = [&](int u) {
+      f32x4_t v[4];
 #pragma unroll
-    for (int c = 0; c < MF / 2; ++c) {
+      for (int fj = 0; fj < 4; ++fj) {
+        v[fj] = acc[fj][u] + bv[fj];
+        if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int fi = 2 * c + h, row = h * 16 + fr;
-        f32x4_t v[4];
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-          v[fj] = acc[fj][fi] + bv[fj];
-          if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
-          }
+          for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
         }
-        const int sw = row & 7;
-        *(uint4*)(scratch + row * 128 + (((g * 2) ^ sw) << 4)) =
-            make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
-                       pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
-        *(uint4*)(scratch + row * 128 + (((g * 2 + 1) ^ sw) << 4)) =
-            make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
-                       pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
       }
+      char* w = scratch + (u & 1) * 2048 + fr * 128;
+      const int sw = fr & 7;
+      *(uint4*)(w + (((g * 2) ^ sw) << 4)) =
+          make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
+                     pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
+      *(uint4*)(w + (((g * 2 + 1) ^ sw) << 4)) =
+          make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
+                     pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
+    };
+    auto read_unit = [&](int u, uint4 (&r)[2]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 2; ++t) {
         const int row = t * 8 + rrow;
-        const uint4 v = *(const uint4*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4));
-        const int m = mw + c * 32 + row;
-        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, v);
+        r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 128 + ((c8 ^ (row & 7)) << 4));
       }
+    };
+    auto store_unit = [&](int u, const uint4 (&r)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int m = mw + u * 16 + t * 8 + rrow;
+        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, r[t]);
+      }
+    };
+    write_unit(0);
+#pragma unroll
+    for (int u = 1; u < MF; ++u) {
+      uint4 r[2];
+      read_unit(u - 1, r);
+      write_unit(u);
+      store_unit(u - 1, r);
+    }
+    {
+      uint4 r[2];
+      read_unit(MF - 1, r);
+      store_unit(MF - 1, r);
     }
   } else {
     // fp32 rows: chunk = 16 rows x 256 B, 16 lanes per row

@@ -151,12 +151,14 @@ int main(int argc, char** argv) {
       }
       printf("TRACE blk %3d wave %d (avg over %d steps, incl. tile ends): vmwait %.0f  barrier %.0f  issueA %.0f  half0 %.0f  issueB %.0f  half1 %.0f  tail %.0f | step %.0f cyc\n",
              blk, w, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, d[6] / cnt, d[7] / cnt);
-      // one mid-tile step in full
-      const int st = nk + 3;
-      const uint64_t* r = &ht[(((size_t)blk * 8 + w) * 64 + st) * 8];
-      printf("      step %d:", st);
-      for (int k = 0; k < 6; ++k) printf(" %llu", (unsigned long long)(r[k + 1] - r[k]));
-      printf(" | next %llu\n", (unsigned long long)(r[8] - r[6]));
+      // a few steps in full: mid-tile, the tile's last step (tail = epilogue) and the two after it
+      for (int st : {nk + 3, 2 * nk - 2, 2 * nk - 1, 2 * nk, 2 * nk + 1}) {
+        if (st >= 62) continue;
+        const uint64_t* r = &ht[(((size_t)blk * 8 + w) * 64 + st) * 8];
+        printf("      step %2d:", st);
+        for (int k = 0; k < 6; ++k) printf(" %5llu", (unsigned long long)(r[k + 1] - r[k]));
+        printf(" | tail %llu\n", (unsigned long long)(r[8] - r[6]));
+      }
     }
   }
 #endif
