@@ -138,6 +138,42 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)      # fp32 accumulation order
 
 
+@pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 2), (768, 768, 2)])
+def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi):
+    """The four GEMM shapes of a B/16 layer at batch 512 (M = 512*197): the persistent 256x256 kernel
+    (both wait forms) against the one-workgroup-per-tile kernel, bit for bit, three launches each.
+    Full-size runs are what exposes timing-dependent faults (missed hazards, DMA/LDS ordering) that
+    the small oracle-checked shapes above cannot: the tile kernel shares the fragment and epilogue
+    arithmetic but none of the persistent kernel's pipelining."""
+    M = 512 * 197
+    g = torch.Generator(device="cuda").manual_seed(N + K + epi)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
+
+    def run(variant):
+        assert tiny_net._lib.mcm_debug_gemm_variant(variant) == 0
+        y = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+        rd = resid0.clone() if epi == 2 else y
+        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC["bf16"], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                         _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+        torch.cuda.synchronize()
+        return rd if epi == 2 else y
+
+    try:
+        ref = run(0)
+        assert torch.isfinite(ref.float()).all()
+        for variant in (3, 4):
+            for _ in range(3):
+                got = run(variant)
+                assert torch.equal(got.view(torch.int16 if epi != 2 else torch.int32),
+                                   ref.view(torch.int16 if epi != 2 else torch.int32)), f"variant {variant}"
+    finally:
+        tiny_net._lib.mcm_debug_gemm_variant(-1)
+
+
 ATTN_CASES = [(3, 197, 12, False), (2, 50, 12, False), (5, 17, 2, False), (4, 77, 8, True),
               (6, 16, 8, True), (2, 257, 16, False), (3, 33, 2, True)]
 
