@@ -610,14 +610,44 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   const char* gx[4];
   const char* gw[4];
   int ji = 0, kti = 0;
-  auto set_issue_tile = [&](int i) {
-    int mtl, nt;
-    tile_of(jx + i * G8, nmt_x, nbn, a.gn, mtl, nt);
-    const int m0 = (mtl * 8 + xcd) * BM, n0 = nt * BN;
+  // Tile walk.  With the default plain n-fastest order (gn >= nbn) the next tile of this workgroup
+  // is G8 tiles further on, so (m-tile, n-tile) advance by a fixed (G8 / nbn, G8 % nbn) with one
+  // carry: no division on the tile switch, which sits on the refill path of waves 0-3.  Interior
+  // tiles take their 8 row pointers from per-lane bases plus a uniform offset (no clamps, no
+  // 64-bit multiplies per pointer).
+  const bool plain = a.gn >= nbn;
+  const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
+  struct Cursor { int mtl, nt; };
+  auto cursor_init = [&](Cursor& c) { tile_of(jx, nmt_x, nbn, a.gn, c.mtl, c.nt); };
+  auto cursor_next = [&](Cursor& c, int i) {
+    if (plain) {
+      c.mtl += dmt;
+      c.nt += dnt;
+      if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
+    } else {
+      tile_of(jx + i * G8, nmt_x, nbn, a.gn, c.mtl, c.nt);
+    }
+  };
+  const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
+  const char* xlane = (const char*)a.x + (size_t)r0 * sx + chunk * 16;
+  const char* wlane = (const char*)a.w + (size_t)perm_n(r0) * sw + chunk * 16;
+  Cursor ci;
+  auto set_issue_tile = [&]() {
+    const int m0 = (ci.mtl * 8 + xcd) * BM, n0 = ci.nt * BN;
+    if (m0 + BM <= a.M && n0 + BN <= a.N) {
+      const char* xb = xlane + (size_t)m0 * sx;
+      const char* wb = wlane + (size_t)n0 * sw;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
-      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * a.K) * ES + chunk * 16;
+      for (int p = 0; p < 4; ++p) {
+        gx[p] = xb + (size_t)(p * 64) * sx;
+        gw[p] = wb + (size_t)(p * 64) * sw;
+      }
+    } else {  // edge tile: rows past the end re-read the last row (their results are never stored)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        gx[p] = (const char*)a.x + (size_t)min(m0 + p * 64 + r0, a.M - 1) * sx + chunk * 16;
+        gw[p] = (const char*)a.w + (size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * sw + chunk * 16;
+      }
     }
   };
   const uint32_t lds0 = lds_addr(smem);
@@ -631,7 +661,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     }
     if (++kti == nk) {
       kti = 0;
-      if (++ji < ntl) set_issue_tile(ji);
+      if (++ji < ntl) {
+        cursor_next(ci, ji);
+        set_issue_tile();
+      }
     }
   };
 
@@ -648,17 +681,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  set_issue_tile(0);
+  cursor_init(ci);
+  set_issue_tile();
   issue(0);
   int issued = 1;
   int jc = 0, ktc = 0;
-  int cm0, cn0;
-  {
-    int mtl, nt;
-    tile_of(jx, nmt_x, nbn, a.gn, mtl, nt);
-    cm0 = (mtl * 8 + xcd) * BM;
-    cn0 = nt * BN;
-  }
+  Cursor cc;
+  cursor_init(cc);
+  int cm0 = (cc.mtl * 8 + xcd) * BM, cn0 = cc.nt * BN;
   bool stores_pending = false;
   if (late) __builtin_amdgcn_s_setprio(1);  // the younger half would otherwise lose every arbitration
   for (int s = 0; s < total; ++s) {
@@ -705,10 +735,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
       ktc = 0;
       if (++jc < ntl) {
-        int mtl, nt;
-        tile_of(jx + jc * G8, nmt_x, nbn, a.gn, mtl, nt);
-        cm0 = (mtl * 8 + xcd) * BM;
-        cn0 = nt * BN;
+        cursor_next(cc, jc);
+        cm0 = (cc.mtl * 8 + xcd) * BM;
+        cn0 = cc.nt * BN;
       }
     }
   }
