@@ -141,6 +141,17 @@ int mcm_encode_image_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, flo
 int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const float* text_feat_dev,
                  int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
 
+/* Resize(S) + CenterCrop(S), S = cfg.image_size, on the device: the first two
+ * steps of the reference's loader transform, utils/train_eval_util.py:27-33 (transforms.Resize(224),
+ * transforms.CenterCrop(224) on the PIL image; torchvision's size / crop rules around Pillow's
+ * antialiased BILINEAR Image.resize).  Bit-exact against Pillow (tests/golden/preprocess.npz).
+ * src_dev_ptrs / heights / widths are HOST arrays of length B: device pointers to [H_i, W_i, 3]
+ * uint8 RGB images and their sizes.  dst_dev [B, S, S, 3] uint8 is the layout mcm_score_u8 and
+ * mcm_encode_image_u8 take.  MCM_ERANGE: B > max_batch, or a scale factor above 31 (more filter
+ * taps than the kernel holds).  Synchronises `stream` before reusing its staging buffer. */
+int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const int32_t* heights,
+                       const int32_t* widths, int32_t B, uint8_t* dst_dev, void* stream);
+
 /* Prompt-ensemble bank (BASELINE config 5): feats_dev = unit-norm text
  * features [K*T, proj_dim], class-major (row k*T + t = template t of class k), as written by
  * mcm_encode_text; bank_dev [K, proj_dim] = normalise(mean over the T templates).  The reference

@@ -156,3 +156,14 @@ hipError_t launch_score(const float* img, int B, const float* text, int K, int P
 size_t measures_workspace_bytes(long n);
 hipError_t launch_measures(const float* pos, long n_pos, const float* neg, long n_neg, int negate,
                            double level, void* workspace, double** out_dev, hipStream_t s);
+
+// preprocess.hip: Resize(S) + CenterCrop(S) of uint8 RGB images; geometry (resized size, crop
+// origin) is computed by the caller, one PrepImage per image
+struct PrepImage {
+  const uint8_t* src;  // [H, W, 3] uint8 RGB on the device
+  int32_t H, W;        // source size
+  int32_t nh, nw;      // size after Resize(S)
+  int32_t top, left;   // CenterCrop origin inside the resized image
+};
+int prep_max_taps();
+hipError_t launch_resize_crop(const PrepImage* meta_dev, int B, int S, uint8_t* dst, hipStream_t s);

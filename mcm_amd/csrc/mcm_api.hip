@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include <math.h>
+
 #include "common.hpp"
 
 namespace {
@@ -57,6 +59,7 @@ struct mcm_handle {
   float* feat = nullptr;          // [max_batch, proj_dim] scratch for mcm_score
   int32_t *ids_dev = nullptr, *rowidx_dev = nullptr;
   int32_t *ids_pin = nullptr, *rowidx_pin = nullptr;
+  PrepImage *prep_pin = nullptr, *prep_dev = nullptr;  // mcm_resize_crop_u8 geometry, max_batch entries
   int64_t max_rows = 0;
   std::vector<void*> owned;       // every hipMalloc'd pointer
   // profiling
@@ -340,6 +343,9 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc ids");
   if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc rowidx");
+  if (!rc) rc = dev_alloc(h, (void**)&h->prep_dev, (size_t)c.max_batch * sizeof(PrepImage));
+  if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)c.max_batch * sizeof(PrepImage)) != hipSuccess)
+    rc = fail(h, MCM_ENOMEM, "hipHostMalloc prep");
   if (rc) {
     g_create_err = h->err;
     mcm_destroy(h);
@@ -355,6 +361,7 @@ void mcm_destroy(mcm_handle* h) {
   for (void* p : h->owned) (void)hipFree(p);
   if (h->ids_pin) (void)hipHostFree(h->ids_pin);
   if (h->rowidx_pin) (void)hipHostFree(h->rowidx_pin);
+  if (h->prep_pin) (void)hipHostFree(h->prep_pin);
   for (auto& e : h->ev_pool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -463,6 +470,59 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
   int rc = encode_image_impl(h, pixels_dev, true, B, h ? h->feat : nullptr, stream);
   if (rc) return rc;
   return mcm_score_features(h, h->feat, B, text_feat_dev, K, T, kind, scores_dev, stream);
+}
+
+namespace {
+// torchvision's Resize(int) and CenterCrop arithmetic (see preprocess.hip): resized size and crop
+// origin of an H x W image for a square target S
+bool prep_geometry(int32_t H, int32_t W, int32_t S, PrepImage& g) {
+  const int32_t shrt = W <= H ? W : H, lng = W <= H ? H : W;
+  g.H = H;
+  g.W = W;
+  if (shrt == S) {
+    g.nh = H;
+    g.nw = W;
+  } else {
+    const int32_t nl = (int32_t)((double)S * (double)lng / (double)shrt);  // int(size * long / short)
+    g.nw = W <= H ? S : nl;
+    g.nh = W <= H ? nl : S;
+  }
+  if (g.nh < S || g.nw < S) return false;
+  auto round_half_even = [](double v) {  // Python 3 round() on the x.0 / x.5 values that occur here
+    const double f = floor(v), d = v - f;
+    if (d < 0.5) return (int32_t)f;
+    if (d > 0.5) return (int32_t)f + 1;
+    return ((int64_t)f % 2 == 0) ? (int32_t)f : (int32_t)f + 1;
+  };
+  g.top = round_half_even((g.nh - S) / 2.0);
+  g.left = round_half_even((g.nw - S) / 2.0);
+  return true;
+}
+}  // namespace
+
+int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const int32_t* heights,
+                       const int32_t* widths, int32_t B, uint8_t* dst_dev, void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!src_dev_ptrs || !heights || !widths || !dst_dev) return fail(h, MCM_EINVAL, "null pointer");
+  if (B <= 0) return fail(h, MCM_EINVAL, "B must be positive");
+  if (B > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds max_batch");
+  const int32_t S = h->cfg.image_size;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(h, hipStreamSynchronize(s));  // the pinned geometry buffer is reused
+  for (int32_t b = 0; b < B; ++b) {
+    PrepImage& g = h->prep_pin[b];
+    if (!src_dev_ptrs[b] || heights[b] <= 0 || widths[b] <= 0) return fail(h, MCM_EINVAL, "bad image");
+    g.src = src_dev_ptrs[b];
+    if (!prep_geometry(heights[b], widths[b], S, g)) return fail(h, MCM_EINVAL, "image smaller than the crop");
+    const int taps_x = g.nw != g.W ? 2 * (int)ceil(fmax((double)g.W / g.nw, 1.0)) + 1 : 1;
+    const int taps_y = g.nh != g.H ? 2 * (int)ceil(fmax((double)g.H / g.nh, 1.0)) + 1 : 1;
+    if (taps_x > prep_max_taps() || taps_y > prep_max_taps())
+      return fail(h, MCM_ERANGE, "downscale factor above 31 is not supported");
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->prep_dev, h->prep_pin, (size_t)B * sizeof(PrepImage), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, launch_resize_crop(h->prep_dev, B, S, dst_dev, s));
+  return MCM_OK;
 }
 
 int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T, float* bank_dev,

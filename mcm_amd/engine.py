@@ -70,6 +70,7 @@ def load_library():
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.mcm_resize_crop_u8.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), i32, vp, vp]
     L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
                                ctypes.POINTER(ctypes.c_double), vp]
     if L.mcm_abi_version() != 1:
@@ -83,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
     "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
-    "mcm_reduce_bank", "mcm_measures",
+    "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8",
 ]
 
 
@@ -227,6 +228,24 @@ class NativeCLIP:
         assert f.shape[0] == K * T
         out = torch.empty((K, self.geo.proj_dim), device=self.device, dtype=torch.float32)
         self._check(self._lib.mcm_reduce_bank(self._h, f.data_ptr(), K, T, out.data_ptr(), _stream_ptr()))
+        return out
+
+    def resize_crop(self, images):
+        """Resize(S) + CenterCrop(S) of the reference's loader transform (utils/train_eval_util.py:27-33)
+        on the device: `images` = sequence of uint8 [H_i, W_i, 3] RGB tensors → uint8 [B, S, S, 3], the
+        input layout of `score_images` / `get_image_features`.  Bit-exact against Pillow."""
+        import torch
+
+        imgs = [im.to(device=self.device, dtype=torch.uint8).contiguous() for im in images]
+        B, S = len(imgs), self.geo.image_size
+        for im in imgs:
+            if im.dim() != 3 or im.shape[2] != 3:
+                raise ValueError("images must be uint8 [H, W, 3] RGB")
+        ptrs = (ctypes.c_void_p * B)(*[im.data_ptr() for im in imgs])
+        hs = (ctypes.c_int32 * B)(*[im.shape[0] for im in imgs])
+        ws = (ctypes.c_int32 * B)(*[im.shape[1] for im in imgs])
+        out = torch.empty((B, S, S, 3), device=self.device, dtype=torch.uint8)
+        self._check(self._lib.mcm_resize_crop_u8(self._h, ptrs, hs, ws, B, out.data_ptr(), _stream_ptr()))
         return out
 
     def measures(self, pos_scores, neg_scores, recall_level: float = 0.95, negate: bool = False):

@@ -472,3 +472,107 @@ int orc_score_features(const float* img, int32_t B, const float* text, int32_t K
   }
   return MCM_OK;
 }
+
+/* ---- image preprocessing: Resize(S) + CenterCrop(S) on uint8 RGB ----------
+ * Restates what the reference's loader transform does before ToTensor/Normalize
+ * (reference utils/train_eval_util.py:27-33: transforms.Resize(224), transforms.CenterCrop(224)
+ * on the PIL image ImageFolder hands out).  Both steps live in third-party code that is not
+ * under /root/reference:
+ *   - torchvision.transforms (not installed in this image; the reference does not pin a version):
+ *     Resize(int) scales the SHORT side to S, long side = int(S * long / short), default
+ *     interpolation BILINEAR, and returns the image untouched when short == S; CenterCrop takes
+ *     top = round((h - S) / 2), left = round((w - S) / 2) with Python's round-half-to-even.
+ *   - Pillow (12.2.0 here) Image.resize(..., BILINEAR) = ImagingResample in src/libImaging/
+ *     Resample.c: separable, antialiased (support = max(scale, 1)), horizontal pass first, each
+ *     pass in 22-bit fixed point with the result rounded back to uint8.
+ * Pinned by tests/golden/preprocess.npz, generated with Pillow itself (tests/golden/make_golden.py).
+ * Integer arithmetic after the double-precision coefficient set-up: parity is bit-exact. */
+#define ORC_PBITS 22
+#define ORC_KMAX 160 /* taps per output coordinate: 2*ceil(scale)+1, i.e. scale factors up to 79 */
+
+static int resample_coeffs(int in_size, int out_size, int xx, int32_t* kk, int* xmin_out) {
+  /* Resample.c precompute_coeffs + normalize_coeffs_8bpc for one output coordinate */
+  const double scale = (double)in_size / (double)out_size;
+  const double fs = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * fs; /* bilinear filter support = 1 */
+  const double center = (xx + 0.5) * scale;
+  const double ss = 1.0 / fs;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  const int n = xmax - xmin;
+  double k[ORC_KMAX], ww = 0.0;
+  if (n > ORC_KMAX) return -1;
+  for (int x = 0; x < n; ++x) {
+    double v = (x + xmin - center + 0.5) * ss;
+    if (v < 0.0) v = -v;
+    const double w = v < 1.0 ? 1.0 - v : 0.0;
+    k[x] = w;
+    ww += w;
+  }
+  for (int x = 0; x < n; ++x) {
+    if (ww != 0.0) k[x] /= ww;
+    kk[x] = k[x] < 0 ? (int32_t)(-0.5 + k[x] * (1 << ORC_PBITS)) : (int32_t)(0.5 + k[x] * (1 << ORC_PBITS));
+  }
+  *xmin_out = xmin;
+  return n;
+}
+
+static inline uint8_t clip8(int32_t v) {
+  v >>= ORC_PBITS;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+static long round_half_even(double v) { /* Python 3 round() on x.0 / x.5 values */
+  const double f = floor(v);
+  const double d = v - f;
+  if (d < 0.5) return (long)f;
+  if (d > 0.5) return (long)f + 1;
+  return ((long)f % 2 == 0) ? (long)f : (long)f + 1;
+}
+
+void orc_resized_size(int32_t H, int32_t W, int32_t S, int32_t* nh, int32_t* nw) {
+  const int32_t shrt = W <= H ? W : H, lng = W <= H ? H : W;
+  if (shrt == S) { *nh = H; *nw = W; return; }
+  const int32_t nl = (int32_t)((double)S * (double)lng / (double)shrt); /* int(size * long / short) */
+  if (W <= H) { *nw = S; *nh = nl; } else { *nw = nl; *nh = S; }
+}
+
+/* src [H,W,3] uint8 RGB -> dst [S,S,3]; returns 0, or -1 when the image is smaller than the crop
+ * after resizing (cannot happen for Resize(S)+CenterCrop(S)) or the scale exceeds ORC_KMAX taps */
+int orc_resize_crop_u8(const uint8_t* src, int32_t H, int32_t W, int32_t S, uint8_t* dst) {
+  int32_t nh, nw;
+  orc_resized_size(H, W, S, &nh, &nw);
+  if (nh < S || nw < S) return -1;
+  const int top = (int)round_half_even((nh - S) / 2.0), left = (int)round_half_even((nw - S) / 2.0);
+  const int rx = nw != W, ry = nh != H; /* Pillow skips a pass whose size does not change */
+  int32_t kx[ORC_KMAX], ky[ORC_KMAX];
+  for (int yy = 0; yy < S; ++yy) {
+    int ymin = top + yy, ny = 1;
+    ky[0] = 1 << ORC_PBITS;
+    if (ry && (ny = resample_coeffs(H, nh, top + yy, ky, &ymin)) < 0) return -1;
+    for (int xx = 0; xx < S; ++xx) {
+      int xmin = left + xx, nx = 1;
+      kx[0] = 1 << ORC_PBITS;
+      if (rx && (nx = resample_coeffs(W, nw, left + xx, kx, &xmin)) < 0) return -1;
+      for (int c = 0; c < 3; ++c) {
+        int32_t v = 1 << (ORC_PBITS - 1);
+        for (int y = 0; y < ny; ++y) {
+          const uint8_t* row = src + ((size_t)(ymin + y) * W + xmin) * 3 + c;
+          uint8_t hpx;
+          if (rx) {
+            int32_t hacc = 1 << (ORC_PBITS - 1);
+            for (int x = 0; x < nx; ++x) hacc += (int32_t)row[x * 3] * kx[x];
+            hpx = clip8(hacc);
+          } else {
+            hpx = row[0];
+          }
+          v += (int32_t)hpx * ky[y];
+        }
+        dst[((size_t)yy * S + xx) * 3 + c] = ry ? clip8(v) : (uint8_t)((v - (1 << (ORC_PBITS - 1))) >> ORC_PBITS);
+      }
+    }
+  }
+  return 0;
+}

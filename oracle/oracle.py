@@ -57,6 +57,10 @@ def lib():
         L.orc_text_hidden.argtypes = [vp, i32p, i32, i32, i32, f32p]
         L.orc_encode_text.argtypes = [vp, i32p, i32, i32, f32p, i32]
         L.orc_score_features.argtypes = [f32p, i32, f32p, i32, i32, f32, i32, f32p]
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.orc_resize_crop_u8.argtypes = [u8p, i32, i32, i32, u8p]
+        L.orc_resized_size.argtypes = [i32, i32, i32, i32p, i32p]
+        L.orc_resized_size.restype = None
         _lib = L
     return _lib
 
@@ -111,6 +115,19 @@ def score_features(img, text, T=1.0, kind=0):
     rc = lib().orc_score_features(_f(img), B, _f(text), K, Pd, float(T), int(kind), _f(out))
     if rc:
         raise RuntimeError(f"orc_score_features rc={rc}")
+    return out
+
+
+def resize_crop_u8(img, size=224):
+    """[H,W,3] uint8 RGB -> [size,size,3]: Resize(size) + CenterCrop(size) of the reference's loader."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, C = img.shape
+    assert C == 3
+    out = np.empty((size, size, 3), dtype=np.uint8)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    rc = lib().orc_resize_crop_u8(img.ctypes.data_as(u8p), H, W, size, out.ctypes.data_as(u8p))
+    if rc:
+        raise RuntimeError(f"orc_resize_crop_u8 rc={rc}")
     return out
 
 

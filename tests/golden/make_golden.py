@@ -198,6 +198,42 @@ def capture_measures(ref):
     np.savez_compressed(os.path.join(HERE, "measures.npz"), **out)
 
 
+PREPROCESS_CASES = [(375, 500), (500, 333), (64, 48), (224, 300), (1000, 760), (231, 517), (224, 224),
+                    (225, 224), (3000, 2000), (299, 299)]
+
+
+def preprocess_input(h, w):
+    """The test re-creates the inputs from this seed; only outputs are stored."""
+    return np.random.default_rng(h * 10007 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def capture_preprocess(size=224):
+    """Resize(224) + CenterCrop(224) exactly as the reference's loader transform applies them
+    (utils/train_eval_util.py:27-33) to a PIL image: torchvision's size / crop arithmetic
+    (torchvision itself is not installed; its two formulas are restated here) around Pillow's
+    own Image.resize(BILINEAR) and Image.crop."""
+    import hashlib
+
+    from PIL import Image
+
+    out = {"cases": np.array(PREPROCESS_CASES, dtype=np.int32)}
+    for h, w in PREPROCESS_CASES:
+        img = Image.fromarray(preprocess_input(h, w))
+        short, long_ = (w, h) if w <= h else (h, w)
+        if short != size:  # torchvision.transforms.functional.resize with an int size
+            new_short, new_long = size, int(size * long_ / short)
+            nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+            img = img.resize((nw, nh), Image.BILINEAR)
+        nw, nh = img.size
+        top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))  # center_crop
+        arr = np.asarray(img.crop((left, top, left + size, top + size)))
+        assert arr.shape == (size, size, 3)
+        out[f"sha256_{h}x{w}"] = np.frombuffer(hashlib.sha256(arr.tobytes()).digest(), dtype=np.uint8)
+        out[f"patch_{h}x{w}"] = arr[:24, :24].copy()       # a corner, for diagnostics on mismatch
+        out[f"rowsum_{h}x{w}"] = arr.astype(np.int64).sum(axis=(1, 2))
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+
+
 if __name__ == "__main__":
     ref = load_reference_detection_util()
     capture_measures(ref)
@@ -205,3 +241,4 @@ if __name__ == "__main__":
     capture_scores(ref, m, geo)
     capture_clip("B16-2L", n_img=2, n_txt=4, sample_rows=[0, 1, 57, 196])
     capture_clip("ViT-B/16", n_img=2, n_txt=4, sample_rows=[0, 196])
+    capture_preprocess()
