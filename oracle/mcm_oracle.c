@@ -490,6 +490,9 @@ int orc_score_features(const float* img, int32_t B, const float* text, int32_t K
 #define ORC_PBITS 22
 #define ORC_KMAX 160 /* taps per output coordinate: 2*ceil(scale)+1, i.e. scale factors up to 79 */
 
+/* no fused multiply-add here: Pillow's wheels are built for baseline x86-64, and a contracted
+ * (xx + 0.5) * scale ... would not round like theirs */
+__attribute__((optimize("fp-contract=off")))
 static int resample_coeffs(int in_size, int out_size, int xx, int32_t* kk, int* xmin_out) {
   /* Resample.c precompute_coeffs + normalize_coeffs_8bpc for one output coordinate */
   const double scale = (double)in_size / (double)out_size;
