@@ -171,6 +171,22 @@ int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T,
 int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
                  int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream);
 
+/* ---- CLIP byte-level BPE tokenizer, host side --------------------------------
+ * Replaces CLIPTokenizer.from_pretrained(args.ckpt) + tokenizer(list[str], padding=True,
+ * return_tensors="pt") of reference utils/detection_util.py:216,228.  vocab.json / merges.txt are the
+ * checkpoint's tokenizer files.  Pure host code: usable without a GPU. */
+typedef struct mcm_tokenizer mcm_tokenizer;
+int mcm_tokenizer_create(const char* vocab_json_path, const char* merges_txt_path, mcm_tokenizer** out);
+void mcm_tokenizer_destroy(mcm_tokenizer* t);
+const char* mcm_tokenizer_last_error(const mcm_tokenizer* t); /* t == NULL: the last create error */
+int32_t mcm_tokenizer_vocab_size(const mcm_tokenizer* t);
+/* n prompts (UTF-8, NUL-terminated) -> ids_out / mask_out [n, *seq_len_out] int32, row-major,
+ * *seq_len_out = longest prompt incl. BOS/EOS; shorter rows are padded with the pad token
+ * (<|endoftext|>) and mask 0.  capacity = row capacity of the output buffers (e.g. 77);
+ * MCM_ERANGE (with *seq_len_out set) when the longest prompt needs more. mask_out may be NULL. */
+int mcm_tokenizer_encode(mcm_tokenizer* t, const char* const* texts, int32_t n, int32_t capacity,
+                         int32_t* ids_out, int32_t* mask_out, int32_t* seq_len_out);
+
 /* ---- per-kernel timing (HIP events on the caller's stream) -------------------------
  * When enabled, every kernel launch of the encode path is bracketed by a pair of
  * pre-created hipEvents.  mcm_profile_read synchronises the stream, accumulates the

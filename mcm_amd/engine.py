@@ -71,6 +71,14 @@ def load_library():
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mcm_resize_crop_u8.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), i32, vp, vp]
+    L.mcm_tokenizer_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.mcm_tokenizer_destroy.argtypes = [vp]
+    L.mcm_tokenizer_destroy.restype = None
+    L.mcm_tokenizer_last_error.argtypes = [vp]
+    L.mcm_tokenizer_last_error.restype = ctypes.c_char_p
+    L.mcm_tokenizer_vocab_size.argtypes = [vp]
+    L.mcm_tokenizer_vocab_size.restype = i32
+    L.mcm_tokenizer_encode.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, i32, vp, vp, ctypes.POINTER(i32)]
     L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
                                ctypes.POINTER(ctypes.c_double), vp]
     if L.mcm_abi_version() != 1:
@@ -84,7 +92,8 @@ EXPORTED_SYMBOLS = [
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
     "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
-    "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8",
+    "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8", "mcm_tokenizer_create",
+    "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
 ]
 
 

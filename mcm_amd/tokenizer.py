@@ -39,10 +39,72 @@ class HashTokenizer:
         return {"input_ids": ids, "attention_mask": mask}
 
 
+class NativeBPETokenizer:
+    """The library's C++ CLIP BPE (mcm_amd/csrc/tokenizer.cpp) behind the call contract the
+    reference uses: `tok(list[str], padding=True, return_tensors="pt")` → input_ids, attention_mask."""
+    max_len = 77
+
+    def __init__(self, vocab_json: str, merges_txt: str):
+        import ctypes
+
+        from .engine import load_library
+
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.mcm_tokenizer_create(vocab_json.encode(), merges_txt.encode(), ctypes.byref(self._h))
+        if rc:
+            raise RuntimeError(f"mcm_tokenizer_create rc={rc}: {self._lib.mcm_tokenizer_last_error(None).decode()}")
+
+    def __len__(self):
+        return int(self._lib.mcm_tokenizer_vocab_size(self._h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.mcm_tokenizer_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+    def __call__(self, texts: List[str], padding: bool = True, return_tensors: str = "pt",
+                 capacity: int = 4096) -> Dict:
+        import ctypes
+
+        if isinstance(texts, str):
+            texts = [texts]
+        n = len(texts)
+        arr = (ctypes.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        ids = np.empty((n, capacity), dtype=np.int32)
+        mask = np.empty((n, capacity), dtype=np.int32)
+        S = ctypes.c_int32()
+        rc = self._lib.mcm_tokenizer_encode(self._h, arr, n, capacity, ids.ctypes.data, mask.ctypes.data,
+                                            ctypes.byref(S))
+        if rc:
+            raise RuntimeError(f"mcm_tokenizer_encode rc={rc}: {self._lib.mcm_tokenizer_last_error(self._h).decode()}")
+        S = S.value  # the C side writes rows of length S contiguously
+        ids = ids.reshape(-1)[: n * S].reshape(n, S).astype(np.int64)
+        mask = mask.reshape(-1)[: n * S].reshape(n, S).astype(np.int64)
+        if not padding:
+            return {"input_ids": [r[m.astype(bool)].tolist() for r, m in zip(ids, mask)],
+                    "attention_mask": [m[m.astype(bool)].tolist() for m in mask]}
+        if return_tensors == "pt":
+            import torch
+
+            return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+        return {"input_ids": ids, "attention_mask": mask}
+
+
 def load_tokenizer(ckpt: str):
-    """Real CLIP BPE tokenizer when its vocabulary is available locally, else HashTokenizer.
+    """The native BPE when `ckpt` is a directory holding the checkpoint's vocab.json + merges.txt;
+    else HF's CLIP tokenizer when its vocabulary is available locally; else HashTokenizer.
     transformers 5.x returns an EMPTY-vocabulary tokenizer instead of raising when the files
     are missing (every prompt then tokenises to the same ids), so the result is validated."""
+    import os
+
+    if ckpt and os.path.isdir(ckpt):
+        v, m = os.path.join(ckpt, "vocab.json"), os.path.join(ckpt, "merges.txt")
+        if os.path.exists(v) and os.path.exists(m):
+            return NativeBPETokenizer(v, m)
     try:
         from transformers import CLIPTokenizer
 
