@@ -23,15 +23,19 @@
 // MFMA operand order is swapped (W fragment as A, X fragment as B) so each lane ends up
 // with 4 consecutive output columns of one row: 16-B fp32 / 8-B bf16 epilogue accesses.
 //
-// Two kernels share the fragment/epilogue code:
+// Three kernels share the fragment/epilogue code and are bit-identical on the same inputs:
 //   gemm_tile_kernel     128x128 tile, 4 waves, 2 LDS stages, one workgroup per tile,
-//                        2 workgroups/CU.  Small problems (text tower, tests).
-//   gemm_persist_kernel  256x128 tile, 8 waves (4x2), 3 LDS stages (144 KiB), ONE
-//                        persistent workgroup per CU walking its tiles; the LDS-DMA stream
-//                        runs two K-steps ahead with counted vmcnt and keeps running across
-//                        tile boundaries, so the next tile's operands land under the
-//                        current tile's epilogue.  Tiles are dealt XCD-first (an XCD's 32
-//                        CUs share X row panels in their private L2).
+//                        2 workgroups/CU.  Small problems (text tower, CLS-only last layer, tests).
+//   gemm_persist_kernel  256x128 tile, 8 waves (4x2), 3 LDS stages (144 KiB), ONE persistent
+//                        workgroup per CU walking its tiles; the LDS-DMA stream runs two K-steps
+//                        ahead with counted vmcnt and keeps running across tile boundaries.  Bound
+//                        by the L1->LDS DMA path; kept as an A/B arm.
+//   gemm_p256_kernel     256x256 tile, 8 waves (2x4, 128x64 wave tiles), two 64-KiB stages + a
+//                        4-KiB epilogue window per wave (160 KiB); the default for large problems.
+//                        Tiles are dealt XCD-first (an XCD's 32 CUs share X row panels in their
+//                        private L2), the two waves of a SIMD take turns refilling, whole-row
+//                        epilogue stores are streamed (nt).  Measurements and what bounds it:
+//                        DESIGN.md sections 4.1 and 5.1.
 #include <stdlib.h>
 
 #include "common.hpp"
