@@ -155,6 +155,8 @@ def main():
         if not args.no_profile and i == args.warmup - 1:
             net.profile(True)  # creates the event pool outside the timed region
         net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[0])
+    if ws > 1:  # warm the collective too (RCCL builds its rings on first use)
+        mdist.all_gather_scores(scores[0], ws * B)
     torch.cuda.synchronize()
     if not args.no_profile:
         net.profile_read()  # drop the warm-up samples
