@@ -50,10 +50,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// two fp32 → packed fp16x2, round-to-nearest-even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+// two fp32 → packed fp16x2, round-to-nearest-even: one v_cvt_pk_f16_f32 on gfx950 (the vector
+// conversion selects it; two scalar casts cost v_cvt_f16_f32 x2 + v_pack_b32_f16)
 __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
-  const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
 }
 // 16-bit operand modes: PREC selects the element format of MFMA operands and 16-bit outputs
 template <int PREC>
