@@ -39,7 +39,7 @@ __host__ __device__ constexpr int vt_stride(int LP) {  // bytes; ≡ 16 (mod 256
 template <int PREC, int LP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv,
                                                            uint16_t* __restrict__ out, int L,
-                                                           int heads, int qrows) {
+                                                           int heads, int qrows, int rev) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = LP / 16;       // key tiles
   constexpr int NU = LP / 32;       // key tile pairs (PV k-steps)
@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int seq = bid / heads, h = bid - seq * heads;
   const int D = heads * 64;
   const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
   const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 template <int PREC, int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
-                       int qrows, hipStream_t s) {
+                       int qrows, hipStream_t s, int rev) {
   constexpr int lds = LP * 128 + 64 * vt_stride(LP);
   static bool attr_set = false;
   if (!attr_set) {
@@ -275,28 +276,28 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
   }
   if (causal)
     hipLaunchKernelGGL((attn_bf16_kernel<PREC, LP, true>), dim3(nseq * heads), dim3(256), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
   else
     hipLaunchKernelGGL((attn_bf16_kernel<PREC, LP, false>), dim3(nseq * heads), dim3(256), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s) {
+                            bool causal, int qrows, hipStream_t s, bool reverse) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
   if (prec != MCM_PREC_F32) {
 #define MCM_ATTN_BY_LP(P)                                                                      \
   do {                                                                                          \
-    if (L <= 32) return launch_bf16<P, 32>(qkv, out, nseq, L, heads, causal, qrows, s);         \
-    if (L <= 64) return launch_bf16<P, 64>(qkv, out, nseq, L, heads, causal, qrows, s);         \
-    if (L <= 96) return launch_bf16<P, 96>(qkv, out, nseq, L, heads, causal, qrows, s);         \
-    if (L <= 128) return launch_bf16<P, 128>(qkv, out, nseq, L, heads, causal, qrows, s);       \
-    if (L <= 224) return launch_bf16<P, 224>(qkv, out, nseq, L, heads, causal, qrows, s);       \
-    if (L <= 288) return launch_bf16<P, 288>(qkv, out, nseq, L, heads, causal, qrows, s);       \
+    if (L <= 32) return launch_bf16<P, 32>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);         \
+    if (L <= 64) return launch_bf16<P, 64>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);         \
+    if (L <= 96) return launch_bf16<P, 96>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);         \
+    if (L <= 128) return launch_bf16<P, 128>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);       \
+    if (L <= 224) return launch_bf16<P, 224>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);       \
+    if (L <= 288) return launch_bf16<P, 288>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);       \
     return hipErrorInvalidValue;                                                                \
   } while (0)
     if (prec == MCM_PREC_F16) MCM_ATTN_BY_LP(MCM_PREC_F16);

@@ -117,6 +117,7 @@ struct GemmArgs {
   int ldo;            // elements (row stride of out / resid)
   int np;             // EPI_PATCH: patches per image
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
+  int rev;            // persistent kernel: walk the M tiles from the last to the first
   int dbg;            // ablation bits (bench harness only): 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
@@ -127,11 +128,11 @@ void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persis
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s,
-                            size_t x_stride = 0, size_t y_stride = 0);
+                            size_t x_stride = 0, size_t y_stride = 0, bool reverse = false);
 
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s);
+                            bool causal, int qrows, hipStream_t s, bool reverse = false);
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);

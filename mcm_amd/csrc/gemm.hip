@@ -635,9 +635,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
   const char* xlane = (const char*)a.x + (size_t)r0 * sx + chunk * 16;
   const char* wlane = (const char*)a.w + (size_t)perm_n(r0) * sw + chunk * 16;
+  // a.rev: walk this XCD's M tiles from the last to the first (the producer of X wrote its highest
+  // rows last, so they are the ones still in L2 / Infinity Cache)
+  auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
   Cursor ci;
   auto set_issue_tile = [&]() {
-    const int m0 = (ci.mtl * 8 + xcd) * BM, n0 = ci.nt * BN;
+    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
     if (m0 + BM <= a.M && n0 + BN <= a.N) {
       const char* xb = xlane + (size_t)m0 * sx;
       const char* wb = wlane + (size_t)n0 * sw;
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   int jc = 0, ktc = 0;
   Cursor cc;
   cursor_init(cc);
-  int cm0 = (cc.mtl * 8 + xcd) * BM, cn0 = cc.nt * BN;
+  int cm0 = (mt_of(cc.mtl) * 8 + xcd) * BM, cn0 = cc.nt * BN;
   bool stores_pending = false;
   if (late) __builtin_amdgcn_s_setprio(1);  // the younger half would otherwise lose every arbitration
   for (int s = 0; s < total; ++s) {
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       ktc = 0;
       if (++jc < ntl) {
         cursor_next(cc, jc);
-        cm0 = (cc.mtl * 8 + xcd) * BM;
+        cm0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
         cn0 = cc.nt * BN;
       }
     }

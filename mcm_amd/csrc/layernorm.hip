@@ -17,10 +17,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, void* y,
                                                         int M, int D, float eps, size_t xs,
-                                                        size_t ys) {
+                                                        size_t ys, int rev) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (rev) row = M - 1 - row;
   const float* xr = x + (size_t)row * xs;
   float4 v[MAXV];
   float s = 0.f;
@@ -70,16 +71,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,
-                            size_t y_stride) {
+                            size_t y_stride, bool reverse) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
   const size_t xs = x_stride ? x_stride : (size_t)D, ys = y_stride ? y_stride : (size_t)D;
   if (xs % 4 || ys % 4) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
+  const int rev = reverse ? 1 : 0;
   if (prec == MCM_PREC_BF16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev);
   else if (prec == MCM_PREC_F16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev);
   else
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev);
   return hipGetLastError();
 }
