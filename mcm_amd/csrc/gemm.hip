@@ -805,9 +805,12 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   int v = variant();
-  if (v < 0) {  // auto: persistent 256x256 kernel once every CU gets >= 4 tiles, else tile kernel
+  if (v < 0) {  // auto: the persistent 256x256 kernel once its tiles cover most of the CUs, else the
+                // one-workgroup-per-tile kernel (text tower, CLS-only last layer).  Measured with
+                // bench.py --batch 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 %
+                // end to end against the old >= 1024 rule).
     const long tiles = (long)((a.M + p256::BM - 1) / p256::BM) * ((a.N + p256::BN - 1) / p256::BN);
-    v = tiles >= 1024 ? 3 : 0;
+    v = tiles >= 192 ? 3 : 0;
   }
   if (v == 0) return launch_tile<PREC, EPI>(a, s);
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
