@@ -241,4 +241,6 @@ if __name__ == "__main__":
     capture_scores(ref, m, geo)
     capture_clip("B16-2L", n_img=2, n_txt=4, sample_rows=[0, 1, 57, 196])
     capture_clip("ViT-B/16", n_img=2, n_txt=4, sample_rows=[0, 196])
+    capture_clip("ViT-L/14", n_img=1, n_txt=2, sample_rows=[0, 256])   # BASELINE config 4's checkpoint
+    capture_clip("ViT-B/32", n_img=2, n_txt=2, sample_rows=[0, 49])
     capture_preprocess()

@@ -42,7 +42,9 @@ def _cos(a, b):
 
 @pytest.mark.parametrize("name,fixture,n_extra", [("tiny", "clip_tiny.npz", 29),
                                                   ("B16-2L", "clip_B16-2L.npz", 3),
-                                                  ("ViT-B/16", "clip_ViT-B_16.npz", 0)])
+                                                  ("ViT-B/16", "clip_ViT-B_16.npz", 0),
+                                                  ("ViT-B/32", "clip_ViT-B_32.npz", 0),
+                                                  ("ViT-L/14", "clip_ViT-L_14.npz", 0)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_towers_vs_hf_fixture(golden_dir, name, fixture, n_extra, precision):
     g = np.load(os.path.join(golden_dir, fixture))

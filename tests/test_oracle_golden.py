@@ -55,7 +55,9 @@ def test_tiny_text_hidden_states(golden_dir, tiny):
 
 
 @pytest.mark.parametrize("name,fixture", [("B16-2L", "clip_B16-2L.npz"),
-                                          ("ViT-B/16", "clip_ViT-B_16.npz")])
+                                          ("ViT-B/16", "clip_ViT-B_16.npz"),
+                                          ("ViT-B/32", "clip_ViT-B_32.npz"),
+                                          ("ViT-L/14", "clip_ViT-L_14.npz")])
 def test_full_width_towers(golden_dir, name, fixture):
     geo = geometry(name)
     o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
