@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
           s[t][r] = ok ? s[t][r] : -INFINITY;
         }
       }
-      m = fmaxf(m, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+      m = fmaxf(fmaxf(fmaxf(fmaxf(m, s[t][0]), s[t][1]), s[t][2]), s[t][3]);  // two v_max3_f32
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
