@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 from utils.common import get_num_cls, get_test_labels, setup_seed
-from utils.detection_util import get_and_print_results, get_ood_scores_clip, print_measures
+from utils.detection_util import (get_and_print_results, get_Mahalanobis_score, get_mean_prec,
+                                  get_ood_scores_clip, print_measures)
 
 # dataset sizes (external knowledge, as in the reference's loaders)
 N_ID = {"ImageNet": 50000, "ImageNet10": 500, "ImageNet20": 1000, "ImageNet100": 5000,
@@ -39,7 +40,7 @@ def process_args(argv=None):
                    help="which pretrained img encoder to use")
     p.add_argument("--score", default="MCM", type=str,
                    choices=["MCM", "energy", "max-logit", "entropy", "var", "maha"], help="score options")
-    # Mahalanobis flags are accepted for CLI parity; the maha baseline is out of scope
+    # Mahalanobis baseline (--score maha), reference eval_ood_detection.py:38-44
     p.add_argument("--feat_dim", type=int, default=512)
     p.add_argument("--normalize", type=bool, default=False)
     p.add_argument("--generate", type=bool, default=True)
@@ -71,12 +72,13 @@ def setup_log(args):
     return log
 
 
-def _loader(args, n, size, ood):
+def _loader(args, n, size, ood, seed=None):
     from mcm_amd.synth import SyntheticImageSet, SyntheticLoader
 
     if args.synthetic_n:
         n = min(n, args.synthetic_n)
-    return SyntheticLoader(SyntheticImageSet(n, size, args.n_cls, ood, seed=1 + int(ood)), args.batch_size)
+    seed = 1 + int(ood) if seed is None else seed
+    return SyntheticLoader(SyntheticImageSet(n, size, args.n_cls, ood, seed=seed), args.batch_size)
 
 
 def main(argv=None):
@@ -86,8 +88,6 @@ def main(argv=None):
     from mcm_amd.engine import build_model
 
     args = process_args(argv)
-    if args.score == "maha":
-        raise SystemExit("--score maha is a baseline outside the MCM hot path (not implemented here)")
     setup_seed(args.seed)
     rank, ws, local = mdist.init_from_env()
     log = setup_log(args)
@@ -107,13 +107,25 @@ def main(argv=None):
     size = net.geo.image_size
     test_loader = _loader(args, N_ID[args.in_dataset], size, ood=False)
     test_labels = get_test_labels(args, test_loader)
-    on_dev = not args.host_metrics  # scores stay in HBM; only the three metrics come back
-    in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
+    on_dev = not args.host_metrics and args.score != "maha"  # scores stay in HBM; three metrics come back
+    if args.score == "maha":  # reference eval_ood_detection.py:72-79
+        if ws > 1:
+            raise SystemExit("--score maha runs on one GPU (the baseline's fit is a host-side step)")
+        args.feat_dim = net.geo.proj_dim
+        n_train = min(N_ID[args.in_dataset], args.max_count * args.n_cls) if args.subset else N_ID[args.in_dataset]
+        train_loader = _loader(args, n_train, size, ood=False, seed=7)
+        classwise_mean, precision = get_mean_prec(args, net, train_loader)
+        in_score = get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True)
+    else:
+        in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
     auroc_list, aupr_list, fpr_list = [], [], []
     for out_dataset in out_datasets:
         log.debug(f"Evaluting OOD dataset {out_dataset}")
         ood_loader = _loader(args, N_OOD[out_dataset], size, ood=True)
-        out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
+        if args.score == "maha":
+            out_score = get_Mahalanobis_score(args, net, ood_loader, classwise_mean, precision, in_dist=False)
+        else:
+            out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
         if rank == 0:
             get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list, net=net)
     if rank == 0:

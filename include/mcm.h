@@ -171,6 +171,22 @@ int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T,
 int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
                  int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream);
 
+/* ---- Mahalanobis baseline (--score maha) ---------------------------------------
+ * mcm_encode_image_raw: HF get_image_features WITHOUT the reference's `/= norm` — what
+ * get_mean_prec / get_Mahalanobis_score consume when args.normalize is False (their default),
+ * reference utils/detection_util.py:158-161,187-190.
+ * mcm_maha_prepare + mcm_maha_score_features replace the per-class loop of get_Mahalanobis_score
+ * (:191-198): means_dev [C, proj_dim] fp32 and prec_dev [proj_dim, proj_dim] fp32 are
+ * get_mean_prec's classwise_mean and precision; w_dev [C, proj_dim] and k_dev [C] (fp64) are
+ * scratch the caller provides, filled by prepare and read by score; scores_dev [B] receives
+ * min_c 0.5 (f - mu_c) P (f - mu_c)^T, the value the reference returns per sample. */
+int mcm_encode_image_raw(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream);
+int mcm_maha_prepare(mcm_handle* h, const float* means_dev, const float* prec_dev, int32_t C,
+                     double* w_dev, double* k_dev, void* stream);
+int mcm_maha_score_features(mcm_handle* h, const float* feats_dev, int32_t B, const float* prec_dev,
+                            const double* w_dev, const double* k_dev, int32_t C, float* scores_dev,
+                            void* stream);
+
 /* ---- CLIP byte-level BPE tokenizer, host side --------------------------------
  * Replaces CLIPTokenizer.from_pretrained(args.ckpt) + tokenizer(list[str], padding=True,
  * return_tensors="pt") of reference utils/detection_util.py:216,228.  vocab.json / merges.txt are the

@@ -150,7 +150,13 @@ hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, in
 // pooled row → LayerNorm → projection (no bias) → L2 normalise; out fp32 [n, P]
 hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_stride, int n,
                                int D, const float* g, const float* b, float eps,
-                               const float* proj, int P, float* out, hipStream_t s);
+                               const float* proj, int P, float* out, hipStream_t s,
+                               bool normalize = true);
+// score.hip: Mahalanobis baseline (reference utils/detection_util.py:146-207)
+hipError_t launch_maha_prepare(const float* means, const float* prec, int C, int P, double* w, double* c,
+                               hipStream_t s);
+hipError_t launch_maha_score(const float* feats, int B, const float* prec, const double* w, const double* c,
+                             int C, int P, float* scores, hipStream_t s);
 
 hipError_t launch_score(const float* img, int B, const float* text, int K, int P, float T,
                         int kind, float* scores, hipStream_t s);

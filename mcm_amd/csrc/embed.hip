@@ -157,7 +157,7 @@ constexpr int NWP = 16;
 __global__ __launch_bounds__(NWP * 64) void pool_project_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ row_idx, int row_stride, int D,
     const float* __restrict__ g, const float* __restrict__ b, float eps,
-    const float* __restrict__ proj, int P, float* __restrict__ out) {
+    const float* __restrict__ proj, int P, float* __restrict__ out, int normalize) {
   __shared__ float y[1024];
   __shared__ float o[1024];
   __shared__ float red[2 * NWP];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NWP * 64) void pool_project_kernel(
   tot = 0.f;
 #pragma unroll
   for (int i = 0; i < NWP; ++i) tot += red[i];
-  const float rn = 1.0f / sqrtf(tot);
+  const float rn = normalize ? 1.0f / sqrtf(tot) : 1.0f;  // raw = what HF get_image_features returns
   for (int p = tid; p < P; p += NWP * 64) out[(size_t)n * P + p] = o[p] * rn;
 }
 
@@ -280,9 +280,9 @@ hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, in
 
 hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_stride, int n,
                                int D, const float* g, const float* b, float eps,
-                               const float* proj, int P, float* out, hipStream_t s) {
+                               const float* proj, int P, float* out, hipStream_t s, bool normalize) {
   if (n <= 0 || D > 1024 || D % 4 || P > 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pool_project_kernel, dim3(n), dim3(NWP * 64), 0, s, x, row_idx, row_stride, D, g, b,
-                     eps, proj, P, out);
+                     eps, proj, P, out, normalize ? 1 : 0);
   return hipGetLastError();
 }

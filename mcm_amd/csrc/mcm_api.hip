@@ -427,7 +427,7 @@ const float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
 const float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
 int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B, float* out_dev,
-                      void* stream) {
+                      void* stream, bool normalize = true) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
@@ -462,7 +462,7 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
     HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,
                                    W(h, "vision_model.post_layernorm.weight"),
                                    W(h, "vision_model.post_layernorm.bias"), c.ln_eps,
-                                   W(h, "visual_projection.weight"), c.proj_dim, out_dev, s));
+                                   W(h, "visual_projection.weight"), c.proj_dim, out_dev, s, normalize));
   }
   return MCM_OK;
 }
@@ -472,6 +472,29 @@ extern "C" {
 
 int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream) {
   return encode_image_impl(h, pixels_dev, false, B, out_dev, stream);
+}
+
+int mcm_encode_image_raw(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev, void* stream) {
+  return encode_image_impl(h, pixels_dev, false, B, out_dev, stream, false);
+}
+
+int mcm_maha_prepare(mcm_handle* h, const float* means_dev, const float* prec_dev, int32_t C,
+                     double* w_dev, double* k_dev, void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!means_dev || !prec_dev || !w_dev || !k_dev || C <= 0) return fail(h, MCM_EINVAL, "bad argument");
+  HIP_TRY(h, launch_maha_prepare(means_dev, prec_dev, C, h->cfg.proj_dim, w_dev, k_dev, (hipStream_t)stream));
+  return MCM_OK;
+}
+
+int mcm_maha_score_features(mcm_handle* h, const float* feats_dev, int32_t B, const float* prec_dev,
+                            const double* w_dev, const double* k_dev, int32_t C, float* scores_dev,
+                            void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!feats_dev || !prec_dev || !w_dev || !k_dev || !scores_dev || B <= 0 || C <= 0)
+    return fail(h, MCM_EINVAL, "bad argument");
+  HIP_TRY(h, launch_maha_score(feats_dev, B, prec_dev, w_dev, k_dev, C, h->cfg.proj_dim, scores_dev,
+                               (hipStream_t)stream));
+  return MCM_OK;
 }
 
 int mcm_encode_image_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, float* out_dev,

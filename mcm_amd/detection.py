@@ -106,6 +106,74 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
     return full.detach().cpu().numpy().astype(np.float32, copy=False)[:n_total].copy()
 
 
+def get_mean_prec(args, net, train_loader):
+    """Class-wise means and the shared inverse covariance for the Mahalanobis baseline: same signature,
+    results and side effects as reference utils/detection_util.py:146-174, including two behaviours
+    one would not guess from its docstring and that any drop-in must keep:
+      * `classwise_idx[label].append(idx)` stores the BATCH index of a sample, and those batch indices
+        are then used as row indices into the concatenated feature matrix (:159-160,164-165);
+      * the covariance is taken over all features at once (`torch.cov(all_features.T.double())`), not
+        per class, and inverted in float64 before the cast to float32 (:168-169).
+    Features come from the native tower (raw, or L2-normalised with args.normalize, :158-160); the
+    statistics are host-side float64 torch exactly like the reference's.  Saves the two .pt files the
+    reference saves (:171-172) and returns (classwise_mean [n_cls, feat_dim], precision)."""
+    import os
+    from collections import defaultdict
+
+    import torch
+
+    classwise_mean = torch.empty(args.n_cls, args.feat_dim)
+    all_features = []
+    classwise_idx = defaultdict(list)
+    with torch.no_grad():
+        for idx, (images, labels) in enumerate(train_loader):
+            if getattr(args, "model", "CLIP") == "CLIP":
+                features = net.get_image_features_raw(images).float()
+            if args.normalize:
+                features /= features.norm(dim=-1, keepdim=True)
+            for label in labels:
+                classwise_idx[int(label)].append(idx)
+            all_features.append(features.cpu())
+    all_features = torch.cat(all_features)
+    for cls in range(args.n_cls):
+        classwise_mean[cls] = torch.mean(all_features[classwise_idx[cls]].float(), dim=0)
+        if args.normalize:
+            classwise_mean[cls] /= classwise_mean[cls].norm(dim=-1, keepdim=True)
+    cov = torch.cov(all_features.T.double())
+    precision = torch.linalg.inv(cov).float()
+    print(f"cond number: {torch.linalg.cond(precision)}")
+    tdir = getattr(args, "template_dir", None)
+    if tdir:
+        os.makedirs(tdir, exist_ok=True)
+        tag = f"{args.in_dataset}_{args.max_count}_{args.normalize}"
+        torch.save(classwise_mean, os.path.join(tdir, f"{args.model}_classwise_mean_{tag}.pt"))
+        torch.save(precision, os.path.join(tdir, f"{args.model}_precision_{tag}.pt"))
+    return classwise_mean, precision
+
+
+def get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True):
+    """`--score maha`: per sample min_c 0.5 (f - mu_c) P (f - mu_c)^T — what reference
+    utils/detection_util.py:176-207 returns (the negated max of -0.5 d_c) — with the per-class loop of
+    torch.mm pairs replaced by the native kernels (one quadratic form + C dot products per image).
+    Keeps the reference's loop rule that for OOD sets (`in_dist=False`) iteration stops at batch
+    `len(dataset) // batch_size`, i.e. a trailing partial batch is NOT scored (:185-186)."""
+    import torch
+
+    state = net.maha_prepare(classwise_mean, precision)
+    total_len = len(test_loader.dataset)
+    out = []
+    with torch.no_grad():
+        for batch_idx, (images, _labels) in enumerate(test_loader):
+            if (batch_idx >= total_len // args.batch_size) and in_dist is False:
+                break
+            features = net.get_image_features_raw(images)
+            if args.normalize:
+                features = features / features.norm(dim=-1, keepdim=True)
+            out.append(net.maha_scores(features, state))
+    res = torch.cat(out) if out else torch.empty(0)
+    return res.cpu().numpy().astype(np.float32)
+
+
 def _gather_batch_shards(local, loader, n_total, ws):
     import torch
     import torch.distributed as dist

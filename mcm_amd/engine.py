@@ -79,6 +79,9 @@ def load_library():
     L.mcm_tokenizer_vocab_size.argtypes = [vp]
     L.mcm_tokenizer_vocab_size.restype = i32
     L.mcm_tokenizer_encode.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, i32, vp, vp, ctypes.POINTER(i32)]
+    L.mcm_encode_image_raw.argtypes = [vp, vp, i32, vp, vp]
+    L.mcm_maha_prepare.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.mcm_maha_score_features.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
     L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
                                ctypes.POINTER(ctypes.c_double), vp]
     if L.mcm_abi_version() != 1:
@@ -94,6 +97,7 @@ EXPORTED_SYMBOLS = [
     "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
     "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8", "mcm_tokenizer_create",
     "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
+    "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
 ]
 
 
@@ -181,6 +185,46 @@ class NativeCLIP:
         for s in range(0, px.shape[0], self.max_batch):
             n = min(self.max_batch, px.shape[0] - s)
             self._check(fn(self._h, px[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def get_image_features_raw(self, pixel_values):
+        """[b,3,S,S] fp32 → [b,P] fp32 exactly as HF `get_image_features` returns them (no L2
+        normalisation): the Mahalanobis baseline's input (reference utils/detection_util.py:158,187)."""
+        import torch
+
+        px = self._pixels(pixel_values)
+        if px.dtype == torch.uint8:
+            raise ValueError("raw features take the fp32 NCHW input")
+        out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
+        for s in range(0, px.shape[0], self.max_batch):
+            n = min(self.max_batch, px.shape[0] - s)
+            self._check(self._lib.mcm_encode_image_raw(self._h, px[s:s + n].data_ptr(), n,
+                                                       out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def maha_prepare(self, classwise_mean, precision):
+        """(means [C,P], precision [P,P]) → opaque state for `maha_scores`."""
+        import torch
+
+        mu = classwise_mean.to(device=self.device, dtype=torch.float32).contiguous()
+        pr = precision.to(device=self.device, dtype=torch.float32).contiguous()
+        C, P = mu.shape
+        assert P == self.geo.proj_dim and pr.shape == (P, P)
+        w = torch.empty((C, P), device=self.device, dtype=torch.float64)
+        k = torch.empty((C,), device=self.device, dtype=torch.float64)
+        self._check(self._lib.mcm_maha_prepare(self._h, mu.data_ptr(), pr.data_ptr(), C, w.data_ptr(),
+                                               k.data_ptr(), _stream_ptr()))
+        return {"prec": pr, "w": w, "k": k, "C": C}
+
+    def maha_scores(self, features, state):
+        """features [B,P] fp32 (device) → [B] fp32: min_c 0.5 (f-mu_c) P (f-mu_c)^T."""
+        import torch
+
+        f = features.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(f.shape[0], device=self.device, dtype=torch.float32)
+        self._check(self._lib.mcm_maha_score_features(self._h, f.data_ptr(), f.shape[0], state["prec"].data_ptr(),
+                                                      state["w"].data_ptr(), state["k"].data_ptr(), state["C"],
+                                                      out.data_ptr(), _stream_ptr()))
         return out
 
     def get_text_features(self, input_ids, attention_mask=None, normalize: bool = False):

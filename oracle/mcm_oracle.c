@@ -579,3 +579,34 @@ int orc_resize_crop_u8(const uint8_t* src, int32_t H, int32_t W, int32_t S, uint
   }
   return 0;
 }
+
+/* ---- Mahalanobis baseline (--score maha) -------------------------------------------------------
+ * Restates the scoring loop of get_Mahalanobis_score, reference utils/detection_util.py:191-199:
+ * per class, zero_f = features - class_mean; -0.5 * diag(zero_f @ precision @ zero_f^T); max over
+ * classes; the function returns the negation.  fp32 like the reference (two matrix products per
+ * class, then the diagonal).  feats [B,P], means [C,P], prec [P,P] -> out [B]. */
+void orc_maha_scores(const float* feats, int32_t B, const float* means, int32_t C, const float* prec,
+                     int32_t P, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int32_t b = 0; b < B; ++b) {
+    float* z = (float*)malloc((size_t)P * sizeof(float));
+    float* zp = (float*)malloc((size_t)P * sizeof(float));
+    float best = -INFINITY;
+    for (int32_t c = 0; c < C; ++c) {
+      for (int32_t i = 0; i < P; ++i) z[i] = feats[(size_t)b * P + i] - means[(size_t)c * P + i];
+      for (int32_t j = 0; j < P; ++j) zp[j] = 0.f;
+      for (int32_t i = 0; i < P; ++i) { /* zero_f @ precision */
+        const float zi = z[i];
+        const float* pr = prec + (size_t)i * P;
+        for (int32_t j = 0; j < P; ++j) zp[j] += zi * pr[j];
+      }
+      float d = 0.f;
+      for (int32_t j = 0; j < P; ++j) d += zp[j] * z[j];
+      const float sc = -0.5f * d;
+      if (sc > best) best = sc;
+    }
+    out[b] = -best;
+    free(z);
+    free(zp);
+  }
+}

@@ -61,6 +61,8 @@ def lib():
         L.orc_resize_crop_u8.argtypes = [u8p, i32, i32, i32, u8p]
         L.orc_resized_size.argtypes = [i32, i32, i32, i32p, i32p]
         L.orc_resized_size.restype = None
+        L.orc_maha_scores.argtypes = [f32p, i32, f32p, i32, f32p, i32, f32p]
+        L.orc_maha_scores.restype = None
         _lib = L
     return _lib
 
@@ -128,6 +130,15 @@ def resize_crop_u8(img, size=224):
     rc = lib().orc_resize_crop_u8(img.ctypes.data_as(u8p), H, W, size, out.ctypes.data_as(u8p))
     if rc:
         raise RuntimeError(f"orc_resize_crop_u8 rc={rc}")
+    return out
+
+
+def maha_scores(feats, means, prec):
+    """get_Mahalanobis_score's per-sample value for features [B,P], class means [C,P], precision [P,P]."""
+    feats = _c32(feats); means = _c32(means); prec = _c32(prec)
+    B, Pd = feats.shape
+    out = np.empty(B, dtype=np.float32)
+    lib().orc_maha_scores(_f(feats), B, _f(means), means.shape[0], _f(prec), Pd, _f(out))
     return out
 
 

@@ -176,6 +176,63 @@ def capture_scores(ref, m, geo):
     print("scores", {k: (v.shape, v.dtype) for k, v in out.items() if v.ndim})
 
 
+def capture_maha(ref, m, geo):
+    """The reference's own get_mean_prec / get_Mahalanobis_score (utils/detection_util.py:146-207) on
+    the tiny model: class means, precision, and the scores of an ID set and an OOD set (the OOD call
+    drops the trailing partial batch, as the reference's loop does).  `tqdm` wraps the loaders in the
+    reference; it is importable here."""
+    import tempfile
+
+    n_cls, n_train, n_id, n_ood, bs = 6, 192, 40, 37, 16
+    torch.Tensor.cuda = lambda self, *a, **k: self  # shim (2): no GPU here
+
+    class DS:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    class Loader:
+        def __init__(self, n, ood, seed):
+            self.dataset, self.ood, self.seed = DS(n), ood, seed
+
+        def __len__(self):
+            return -(-self.dataset.n // bs)
+
+        def __iter__(self):
+            for s in range(0, self.dataset.n, bs):
+                n = min(bs, self.dataset.n - s)
+                px, lab = make_pixels(n, geo.image_size, n_cls, ood=self.ood, seed=self.seed, start=s)
+                yield torch.from_numpy(px), torch.from_numpy(lab)
+
+    net = Net4x(m)
+    out = {"n_cls": np.array(n_cls), "n_train": np.array(n_train), "n_id": np.array(n_id),
+           "n_ood": np.array(n_ood), "batch": np.array(bs)}
+    for normalize in (False, True):
+        with tempfile.TemporaryDirectory() as td:
+            args = types.SimpleNamespace(n_cls=n_cls, feat_dim=geo.proj_dim, gpu="cpu", model="CLIP",
+                                         normalize=normalize, template_dir=td, in_dataset="ImageNet10",
+                                         max_count=250, batch_size=bs)
+            mean, prec = ref.get_mean_prec(args, net, Loader(n_train, False, 7))
+            s_in = ref.get_Mahalanobis_score(args, net, Loader(n_id, False, 1), mean, prec, in_dist=True)
+            s_out = ref.get_Mahalanobis_score(args, net, Loader(n_ood, True, 2), mean, prec, in_dist=False)
+        tag = "norm" if normalize else "raw"
+        out[f"mean_{tag}"] = mean.numpy()
+        out[f"prec_{tag}"] = prec.numpy()
+        out[f"in_{tag}"] = np.asarray(s_in)
+        out[f"out_{tag}"] = np.asarray(s_out)
+        # the features the scores were computed from, so the scoring kernel can be checked alone
+        with torch.no_grad():
+            feats = []
+            for px, _ in Loader(n_id, False, 1):
+                f = net.get_image_features(pixel_values=px).float()
+                feats.append(f / f.norm(dim=-1, keepdim=True) if normalize else f)
+        out[f"feat_in_{tag}"] = torch.cat(feats).numpy()
+    np.savez_compressed(os.path.join(HERE, "maha_tiny.npz"), **out)
+    print("maha", {k: (v.shape, v.dtype) for k, v in out.items() if v.ndim})
+
+
 def capture_measures(ref):
     rng = np.random.Generator(np.random.Philox(key=7))
     cases = {}
@@ -239,6 +296,7 @@ if __name__ == "__main__":
     capture_measures(ref)
     m, geo = capture_clip("tiny", n_img=4, n_txt=6)
     capture_scores(ref, m, geo)
+    capture_maha(ref, m, geo)
     capture_clip("B16-2L", n_img=2, n_txt=4, sample_rows=[0, 1, 57, 196])
     capture_clip("ViT-B/16", n_img=2, n_txt=4, sample_rows=[0, 196])
     capture_clip("ViT-L/14", n_img=1, n_txt=2, sample_rows=[0, 256])   # BASELINE config 4's checkpoint
