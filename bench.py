@@ -139,7 +139,8 @@ def main():
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
                      max_prompt_tokens=max(K * ids.shape[1], 77))
-    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                                normalize=True)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     nbuf = min(4, max(1, args.steps))

@@ -1,11 +1,20 @@
 """eval_ood_detection.py — same CLI as the reference (eval_ood_detection.py:15-51): every flag
-and default is kept; additive flags only (`--weights`, `--dtype`, `--synthetic-n`).
+and default is kept; additive flags only (`--weights`, `--dtype`, `--templates`, `--tokenizer-dir`,
+`--data-dir`, `--host-metrics`, `--synthetic-n`, `--synthetic`).
 
 Drives the MI355X-native hot path: model → loaders → `get_ood_scores_clip` (ID once, then per OOD
-set) → AUROC / AUPR / FPR95 → log + CSV.  Datasets and CLIP checkpoints are not available offline,
-so unless `--root-dir` holds real image folders (and torchvision is importable) the loaders are
-the seeded synthetic sets of mcm_amd.synth with the reference's dataset sizes.  Under `torchrun`
-each rank scores a contiguous shard and the shards are all-gathered (rank 0 reports)."""
+set) → AUROC / AUPR / FPR95 → log + CSV.
+
+Data.  `--root-dir` is honoured the way the reference's loaders read it (utils/train_eval_util.py:87-146):
+`<root>/<in_dataset>/val/<class>/*` (ImageNet: `<root>/ImageNet/val`) for the ID set and
+`<root>/ImageNet_OOD_dataset/{iNaturalist,SUN,Places,dtd/images}` for the OOD sets, read by
+mcm_amd.folder.ImageFolderU8 (Pillow decode on the host; Resize + CenterCrop + ToTensor + Normalize on the
+GPU, bit-exact with the reference's transform).  When a folder is missing — always the case offline — that
+set is the seeded synthetic set of mcm_amd.synth with the reference's dataset size, every set with its
+own seed, and the log, the console and `<log_directory>/data_sources.json` say so per set.  The fine-grained
+ID suites (bird200 / car196 / food101 / pet37) have their own archive formats in the reference
+(dataloaders/*.py); only their synthetic form exists here.
+Under `torchrun` each rank scores a contiguous shard and the shards are all-gathered (rank 0 reports)."""
 import argparse
 import logging
 import os
@@ -53,7 +62,17 @@ def process_args(argv=None):
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
+    p.add_argument("--synthetic", action="store_true", help="never look under --root-dir; seeded synthetic sets only")
+    p.add_argument("--templates", default=None, metavar="FILE",
+                   help="prompt-ensemble bank (BASELINE config 5): one template per line with {c} or {}, or a .py "
+                        "file in the style of the reference's utils/imagenet_templates.py (its 80-template list)")
+    p.add_argument("--tokenizer-dir", default=None, help="directory with the checkpoint's vocab.json + merges.txt")
+    p.add_argument("--data-dir", default="data", help="the reference's data/ directory (class-name files)")
     args = p.parse_args(argv)
+    if args.templates:
+        from mcm_amd.detection import read_templates
+
+        args.templates = read_templates(args.templates)
     args.n_cls = get_num_cls(args)
     args.log_directory = f"results/{args.in_dataset}/{args.score}/{args.model}_{args.CLIP_ckpt}_T_{args.T}_ID_{args.name}"
     os.makedirs(args.log_directory, exist_ok=True)
@@ -72,19 +91,45 @@ def setup_log(args):
     return log
 
 
-def _loader(args, n, size, ood, seed=None):
+# where the reference's loaders look (utils/train_eval_util.py:96-146), relative to --root-dir
+OOD_DIRS = {"iNaturalist": ("ImageNet_OOD_dataset", "iNaturalist"), "SUN": ("ImageNet_OOD_dataset", "SUN"),
+            "places365": ("ImageNet_OOD_dataset", "Places"), "dtd": ("ImageNet_OOD_dataset", "dtd", "images"),
+            "ImageNet10": ("ImageNet10", "train"), "ImageNet20": ("ImageNet20", "val")}
+SEEDS = {"id": 1, "train": 7, "iNaturalist": 11, "SUN": 12, "places365": 13, "dtd": 14, "ImageNet10": 15,
+         "ImageNet20": 16}
+
+
+def _loader(args, net, what, n, ood, sources):
+    """The loader for one set: the real folder when it exists under --root-dir, else the seeded synthetic
+    set (recorded in `sources`, which ends up in the log and in data_sources.json)."""
     from mcm_amd.synth import SyntheticImageSet, SyntheticLoader
 
+    if what in ("id", "train"):
+        sub = (args.in_dataset, "val" if what == "id" else "train")
+    else:
+        sub = OOD_DIRS[what]
+    path = os.path.join(args.root_dir, *sub)
+    if not args.synthetic and os.path.isdir(path) and args.in_dataset.startswith("ImageNet"):
+        from mcm_amd.folder import ImageFolderU8
+
+        loader = ImageFolderU8(path, net, args.batch_size)
+        sources[what] = {"kind": "folder", "path": path, "n": len(loader.dataset)}
+        return loader
     if args.synthetic_n:
         n = min(n, args.synthetic_n)
-    seed = 1 + int(ood) if seed is None else seed
-    return SyntheticLoader(SyntheticImageSet(n, size, args.n_cls, ood, seed=seed), args.batch_size)
+    seed = SEEDS[what]
+    sources[what] = {"kind": "synthetic", "n": n, "seed": seed, "why": f"{path} not found"}
+    return SyntheticLoader(SyntheticImageSet(n, net.geo.image_size, args.n_cls, ood, seed=seed), args.batch_size)
 
 
 def main(argv=None):
+    import json
+
     import torch
 
     from mcm_amd import dist as mdist
+    from mcm_amd.config import HUB_IDS
+    from mcm_amd.detection import maha_file_name
     from mcm_amd.engine import build_model
 
     args = process_args(argv)
@@ -97,31 +142,43 @@ def main(argv=None):
     net = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision=args.dtype,
                       max_batch=args.batch_size)
     net.eval()
-    args.ckpt = args.CLIP_ckpt
+    args.ckpt = HUB_IDS[args.CLIP_ckpt]  # reference utils/train_eval_util.py:19-22 (ckpt_mapping)
     if args.in_dataset == "ImageNet10":
         out_datasets = ["ImageNet20"]
     elif args.in_dataset == "ImageNet20":
         out_datasets = ["ImageNet10"]
     else:
         out_datasets = ["iNaturalist", "SUN", "places365", "dtd"]
-    size = net.geo.image_size
-    test_loader = _loader(args, N_ID[args.in_dataset], size, ood=False)
+    sources = {}
+    test_loader = _loader(args, net, "id", N_ID[args.in_dataset], False, sources)
     test_labels = get_test_labels(args, test_loader)
     on_dev = not args.host_metrics and args.score != "maha"  # scores stay in HBM; three metrics come back
     if args.score == "maha":  # reference eval_ood_detection.py:72-79
         if ws > 1:
             raise SystemExit("--score maha runs on one GPU (the baseline's fit is a host-side step)")
         args.feat_dim = net.geo.proj_dim
-        n_train = min(N_ID[args.in_dataset], args.max_count * args.n_cls) if args.subset else N_ID[args.in_dataset]
-        train_loader = _loader(args, n_train, size, ood=False, seed=7)
-        classwise_mean, precision = get_mean_prec(args, net, train_loader)
+        os.makedirs(args.template_dir, exist_ok=True)
+        if args.generate:
+            n_train = min(N_ID[args.in_dataset], args.max_count * args.n_cls) if args.subset else N_ID[args.in_dataset]
+            train_loader = _loader(args, net, "train", n_train, False, sources)
+            get_mean_prec(args, net, train_loader)
+        # like the reference (:77-78) the statistics are always read back from the files get_mean_prec wrote —
+        # or that an earlier run wrote, which is what `--generate ""` (argparse's only falsy bool) is for
+        stats = {}
+        for what in ("classwise_mean", "precision"):
+            f = os.path.join(args.template_dir, maha_file_name(args, what))
+            if not os.path.exists(f):
+                raise SystemExit(f"--generate is off and {f} does not exist: run once with --generate True")
+            stats[what] = torch.load(f, map_location="cpu")
+        classwise_mean, precision = stats["classwise_mean"], stats["precision"]
         in_score = get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True)
     else:
         in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
     auroc_list, aupr_list, fpr_list = [], [], []
     for out_dataset in out_datasets:
         log.debug(f"Evaluting OOD dataset {out_dataset}")
-        ood_loader = _loader(args, N_OOD[out_dataset], size, ood=True)
+        ood_loader = _loader(args, net, out_dataset, N_OOD[out_dataset], True, sources)
+        log.debug(f"data source: {sources[out_dataset]}")
         if args.score == "maha":
             out_score = get_Mahalanobis_score(args, net, ood_loader, classwise_mean, precision, in_dist=False)
         else:
@@ -137,6 +194,13 @@ def main(argv=None):
         rows["AVG"] = [100 * np.mean(fpr_list), 100 * np.mean(auroc_list), 100 * np.mean(aupr_list)]
         pd.DataFrame.from_dict(rows, orient="index", columns=["FPR95", "AUROC", "AUPR"]).round(2).to_csv(
             os.path.join(args.log_directory, f"{args.name}.csv"))
+        synthetic = [k for k, v in sources.items() if v["kind"] == "synthetic"]
+        if synthetic or not args.weights:
+            log.debug(f"NOTE: synthetic inputs ({', '.join(synthetic) or 'none'}; weights: "
+                      f"{'checkpoint' if args.weights else 'seeded synthetic'}) — these numbers are arithmetic "
+                      "checks, not the paper's accuracy")
+        with open(os.path.join(args.log_directory, "data_sources.json"), "w") as f:
+            json.dump({"weights": args.weights or "seeded synthetic", "sets": sources}, f, indent=1)
     net.close()
 
 

@@ -119,6 +119,17 @@ int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S
 int mcm_encode_image(mcm_handle* h, const float* pixels_dev, int32_t B, float* out_dev,
                      void* stream);
 
+/* The two calls above with the reference's `/= norm` step optional: normalize == 0 returns exactly what
+ * HF `get_image_features` / `get_text_features` return (modeling_clip.py:751,713 — the projection
+ * output), which is what unmodified reference code expects from `net` (utils/detection_util.py:158,
+ * 187,225,229) before it normalises the rows itself.  pixel_format selects the ingest layout. */
+#define MCM_PIXELS_F32_NCHW 0 /* fp32 [B,3,S,S], already normalised (mcm_encode_image)            */
+#define MCM_PIXELS_U8_NHWC 1  /* uint8 [B,S,S,3]; ToTensor + Normalize fused (mcm_encode_image_u8) */
+int mcm_encode_image_ex(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B,
+                        int32_t normalize, float* out_dev, void* stream);
+int mcm_encode_text_ex(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S, int32_t normalize,
+                       float* out_dev, void* stream);
+
 /* Replaces the scoring tail utils/detection_util.py:232-248 on already-normalised
  * features: sim = img @ text.T, softmax(sim/T), reduction `kind` → scores_dev fp32 [B].
  * Never materialises [B,K]. */
@@ -167,9 +178,19 @@ int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T,
  * fp32; negate != 0 evaluates on -score, which is how the reference calls it
  * (get_and_print_results, :255: the stored scores are negated confidences).
  * out_host[0..2] = AUROC, AUPR, FPR at the operating point whose recall is closest to
- * recall_level (0.95 in the reference), same tie rules as the reference.  Synchronises `stream`. */
+ * recall_level (0.95 in the reference), same tie rules as the reference.  Synchronises `stream`.
+ * Scratch (12 bytes per score) is taken from the activation workspace mcm_create sized — nothing is
+ * allocated; MCM_ERANGE when n_pos + n_neg does not fit it (the B/16 batch-512 workspace holds
+ * 25 million scores). */
 int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
                  int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream);
+
+/* Fixed-edge histogram of a device score vector: the constant-size per-rank payload `north_star` names
+ * ("RCCL all-gather of per-shard score histograms"), summed over ranks by the caller's all-reduce.
+ * edges_dev: fp32 [n_bins + 1] ascending; counts_dev: int64 [n_bins], overwritten.  numpy.histogram
+ * semantics (bin i = [e_i, e_{i+1}), last bin closed, out-of-range scores dropped); n_bins <= 8192. */
+int mcm_score_histogram(mcm_handle* h, const float* scores_dev, int64_t n, const float* edges_dev,
+                        int32_t n_bins, int64_t* counts_dev, void* stream);
 
 /* ---- Mahalanobis baseline (--score maha) ---------------------------------------
  * mcm_encode_image_raw: HF get_image_features WITHOUT the reference's `/= norm` — what

@@ -40,6 +40,7 @@ template <int PREC, int LP, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv,
                                                            uint16_t* __restrict__ out, int L,
                                                            int heads, int qrows, int rev) {
+  enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = LP / 16;       // key tiles
   constexpr int NU = LP / 32;       // key tile pairs (PV k-steps)

@@ -58,6 +58,18 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
   const f2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
 }
+// fp16 overflow guard.  MODE.FP16_OVFL (bit 23) makes every f32 -> f16 conversion of the wave saturate
+// finite out-of-range values to +-65504 instead of +-inf (inf and NaN inputs stay what they are).
+// Measured on gfx950 (tools/isa_probe.hip): v_cvt_pk_f16_f32 honours it — 65520, 7e4, 1e6, 3.4e38 all
+// give 65504.  One scalar instruction per wave, nothing per element: an activation that leaves the
+// fp16 range (a QuickGELU output or a q/k/v value above 65504) costs that element's precision, not an
+// inf that turns the whole row into NaN at the next LayerNorm.  Set once at kernel entry by every kernel
+// that writes fp16.
+template <int PREC>
+__device__ __forceinline__ void enter_precision_mode() {
+  if constexpr (PREC == MCM_PREC_F16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+}
+
 // 16-bit operand modes: PREC selects the element format of MFMA operands and 16-bit outputs
 template <int PREC>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -118,11 +130,13 @@ struct GemmArgs {
   int np;             // EPI_PATCH: patches per image
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
   int rev;            // persistent kernel: walk the M tiles from the last to the first
-  int dbg;            // ablation bits (bench harness only): 1 no refill, 2 no MFMA, 4 no epilogue
+  int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
+#ifdef MCM_HARNESS  // tools/gemm_bench.hip only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
+#endif
 void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
@@ -166,6 +180,10 @@ hipError_t launch_score(const float* img, int B, const float* text, int K, int P
 size_t measures_workspace_bytes(long n);
 hipError_t launch_measures(const float* pos, long n_pos, const float* neg, long n_neg, int negate,
                            double level, void* workspace, double** out_dev, hipStream_t s);
+
+// fixed-edge histogram (numpy.histogram semantics), counts[nb] int64 on the device; nb <= 8192
+hipError_t launch_histogram(const float* x, long n, const float* edges, int nb, unsigned long long* counts,
+                            hipStream_t s);
 
 // preprocess.hip: Resize(S) + CenterCrop(S) of uint8 RGB images; geometry (resized size, crop
 // origin) is computed by the caller, one PrepImage per image

@@ -36,13 +36,19 @@
 //                        private L2), the two waves of a SIMD take turns refilling, whole-row
 //                        epilogue stores are streamed (nt).  Measurements and what bounds it:
 //                        DESIGN.md sections 4.1 and 5.1.
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace {
 
 constexpr int ROWB = 128;  // bytes of K per row per K-step
+
+// Ablation bits (GemmArgs::dbg: 1 no refill, 2 no MFMA, 4 no epilogue, 8 folded stores) exist only in
+// the bench harness build (tools/gemm_bench.hip, -DMCM_HARNESS); the shipped library compiles them out.
+#ifdef MCM_HARNESS
+#define DBG(bit) (a.dbg & (bit))
+#else
+#define DBG(bit) false
+#endif
 
 __device__ __forceinline__ int frag_off(int fr, int g, int kk) {
   return (fr >> 1) * 256 + ((((fr & 1) << 3) | (((kk * 4 + g) ^ (fr >> 1)) & 7)) << 4);
@@ -328,6 +334,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 template <int PREC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   using namespace tile;
+  enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   const int lane = threadIdx.x & 63;
@@ -433,6 +440,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) {
   using namespace persist;
+  enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 4 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
@@ -533,19 +541,19 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
     asm volatile("" ::: "memory");
     if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
     if (issued < total) {  // refill the stage that step s-1 just finished reading
-      if (!(a.dbg & 1)) issue(ist);
+      if (!DBG(1)) issue(ist);
       ist = ist == NSTAGE - 1 ? 0 : ist + 1;
       ++issued;
     }
     const char* sb = smem + st * STAGE_BYTES;
-    if (!(a.dbg & 2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
+    if (!DBG(2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
     st = st == NSTAGE - 1 ? 0 : st + 1;
     ++since_epi;
     if (++ktc == nk) {
       if (!counted) wait_vmcnt<0>();  // bias was issued in this very tile's first step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!(a.dbg & 4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g);
+      if (!DBG(4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g);
       zero_acc(acc);
       // only a full tile issues exactly STORES_PER_EPI stores per wave; ragged tiles fall back
       // to waiting for the stores as well
@@ -579,7 +587,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 
 #ifdef MCM_GEMM_TRACE  // harness-only cycle stamps (tools/gemm_bench.hip): a.pos = uint64 buffer
 #define TRACE(k)                                                                                   \
   do {                                                                                             \
-    if ((a.dbg & 128) && s < 64 && lane == 0) {                                                    \
+    if (DBG(128) && s < 64 && lane == 0) {                                                    \
       const uint64_t t = __builtin_amdgcn_s_memtime();                                             \
       ((uint64_t*)a.pos)[(((size_t)blockIdx.x * 8 + wave) * 64 + s) * 8 + (k)] = t;               \
     }                                                                                              \
@@ -591,6 +599,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 
 template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   using namespace p256;
+  enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 8 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
@@ -717,24 +726,24 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
     // priority 1) compute the first K half, refill, compute the second.
     const bool refill = issued < total;
-    if (refill && !late && !(a.dbg & 1)) issue(issued & 1);
+    if (refill && !late && !DBG(1)) issue(issued & 1);
     TRACE(3);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
-    if (!(a.dbg & 2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
+    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
     TRACE(4);
-    if (refill && late && !(a.dbg & 1)) issue(issued & 1);
+    if (refill && late && !DBG(1)) issue(issued & 1);
     if (refill) ++issued;
     TRACE(5);
-    if (!(a.dbg & 2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
+    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
     TRACE(6);
     if (++ktc == nk) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!(a.dbg & 4)) {
+      if (!DBG(4)) {
         // dbg 8 (harness only): fold every tile's stores onto a 64-tile region that stays in L2
-        const int em0 = (a.dbg & 8) ? (int)(blockIdx.x & 63) * BM : cm0;
-        const int en0 = (a.dbg & 8) ? 0 : cn0;
+        const int em0 = DBG(8) ? (int)(blockIdx.x & 63) * BM : cm0;
+        const int en0 = DBG(8) ? 0 : cn0;
         wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
                                         smem + 2 * STAGE_BYTES + wave * 4096);
       }
@@ -754,12 +763,20 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 
 int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores)
 
-int variant() {
-  static int v = [] {
-    const char* e = getenv("MCM_GEMM_VARIANT");
-    return e ? atoi(e) : -1;
+int variant() { return g_variant; }
+
+// Persistent kernels run one workgroup per CU.  The count comes from the device (a partitioned or
+// CU-masked lease reports fewer than 256) and is rounded down to a multiple of 8: the tile schedule
+// deals M tiles to XCDs by blockIdx % 8.
+int persistent_grid() {
+  static int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return 0;
+    return cus / 8 * 8;
   }();
-  return g_variant >= 0 ? g_variant : v;
+  return n;
 }
 
 template <int PREC, int EPI>
@@ -785,7 +802,7 @@ hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(256), dim3(512), persist::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -798,7 +815,7 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS>), dim3(256), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -812,6 +829,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
     const long tiles = (long)((a.M + p256::BM - 1) / p256::BM) * ((a.N + p256::BN - 1) / p256::BN);
     v = tiles >= 192 ? 3 : 0;
   }
+  if (v != 0 && persistent_grid() < 8) v = 0;
   if (v == 0) return launch_tile<PREC, EPI>(a, s);
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
   if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
@@ -834,10 +852,14 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 
 void gemm_set_variant(int v) { g_variant = v; }
 
-int g_group_n = [] { const char* e = getenv("MCM_GEMM_GN"); return e ? atoi(e) : 0; }();  // 0 = heuristic
-int g_dbg = [] { const char* e = getenv("MCM_GEMM_DBG"); return e ? atoi(e) : 0; }();
+#ifdef MCM_HARNESS
+int g_group_n = 0;  // 0 = heuristic
+int g_dbg = 0;
 void gemm_set_dbg(int d) { g_dbg = d; }
 void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
+#else
+constexpr int g_group_n = 0, g_dbg = 0;
+#endif
 
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
@@ -846,7 +868,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
     // L2 grouping of the persistent tile walk (N-tiles per group).  In the standalone harness
     // gn=1 looked 4-7 % faster on the wide short-K shapes, but inside the model (operands
     // still warm in L2 / Infinity Cache from the producing kernel) the plain n-fastest walk
-    // wins on every shape: 914 vs 822 TF/s family average.  MCM_GEMM_GN overrides.
+    // wins on every shape: 914 vs 822 TF/s family average (the harness can override).
     const int nbn = (a.N + 255) / 256;
     a.gn = g_group_n > 0 ? g_group_n : nbn;
   }

@@ -6,8 +6,6 @@
 // keeps it in registers for the exact two-pass mean / centred variance, writes the
 // normalised row in the GEMM operand dtype (bf16 or fp32).  In-place (y == x, fp32) is
 // safe: a wave has its whole row in registers before it stores.
-#include <stdlib.h>
-
 #include "common.hpp"
 
 namespace {
@@ -20,6 +18,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ b, void* y,
                                                         int M, int D, float eps, size_t xs,
                                                         size_t ys, int rev, int nt) {
+  enter_precision_mode<OUT>();
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -87,8 +86,8 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
   const int rev = reverse ? 1 : 0;
   // x is streamed with the non-temporal hint: the 310-MB residual read would otherwise push the
   // 155 MB of LayerNorm output — the next GEMM's X operand — out of L2 / Infinity Cache
-  // (measured: GEMM time -4 %, +3.3 % end to end).  MCM_LN_NT=0 restores plain loads.
-  static const int nt = [] { const char* e = getenv("MCM_LN_NT"); return e ? atoi(e) : 1; }();
+  // (measured: GEMM time -4 %, +3.3 % end to end).
+  constexpr int nt = 1;
   if (prec == MCM_PREC_BF16 && !out_f32)
     hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt);
   else if (prec == MCM_PREC_F16 && !out_f32)

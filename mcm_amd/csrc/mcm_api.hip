@@ -14,7 +14,6 @@
 #include <vector>
 
 #include <math.h>
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -62,6 +61,7 @@ struct mcm_handle {
   int32_t *ids_pin = nullptr, *rowidx_pin = nullptr;
   PrepImage *prep_pin = nullptr, *prep_dev = nullptr;  // mcm_resize_crop_u8 geometry, max_batch entries
   int64_t max_rows = 0;
+  size_t hbuf_bytes = 0;
   std::vector<void*> owned;       // every hipMalloc'd pointer
   // profiling
   bool prof = false;
@@ -347,7 +347,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->ln, R * dmax * es);
   if (!rc) rc = dev_alloc(h, &h->qkv, R * 3 * dmax * es);
   if (!rc) rc = dev_alloc(h, &h->att, R * dmax * es);
-  if (!rc) rc = dev_alloc(h, &h->hbuf, R * ffmax * es);
+  h->hbuf_bytes = R * ffmax * es;
+  if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
   if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
@@ -478,6 +479,14 @@ int mcm_encode_image_raw(mcm_handle* h, const float* pixels_dev, int32_t B, floa
   return encode_image_impl(h, pixels_dev, false, B, out_dev, stream, false);
 }
 
+int mcm_encode_image_ex(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B,
+                        int32_t normalize, float* out_dev, void* stream) {
+  if (pixel_format != MCM_PIXELS_F32_NCHW && pixel_format != MCM_PIXELS_U8_NHWC)
+    return fail(h, MCM_EINVAL, "unknown pixel_format");
+  return encode_image_impl(h, pixels_dev, pixel_format == MCM_PIXELS_U8_NHWC, B, out_dev, stream,
+                           normalize != 0);
+}
+
 int mcm_maha_prepare(mcm_handle* h, const float* means_dev, const float* prec_dev, int32_t C,
                      double* w_dev, double* k_dev, void* stream) {
   if (!h) return MCM_EINVAL;
@@ -578,20 +587,37 @@ int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float
     return fail(h, MCM_EINVAL, "both score vectors must be non-empty");
   if (!(recall_level >= 0.0 && recall_level <= 1.0)) return fail(h, MCM_EINVAL, "recall_level outside [0,1]");
   hipStream_t s = (hipStream_t)stream;
-  void* ws = nullptr;
-  HIP_TRY(h, hipMalloc(&ws, measures_workspace_bytes((long)(n_pos + n_neg))));
+  // the three per-example count arrays (12 B per score) live in the MLP activation buffer, which is
+  // idle between encode calls and ordered against them by the stream: nothing is allocated here
+  if (measures_workspace_bytes((long)(n_pos + n_neg)) > h->hbuf_bytes)
+    return fail(h, MCM_ERANGE, "score vectors exceed the workspace sized by mcm_create (" +
+                                   std::to_string(h->hbuf_bytes / 12) + " scores)");
   double* out_dev = nullptr;
-  hipError_t e = launch_measures(pos_dev, (long)n_pos, neg_dev, (long)n_neg, negate, recall_level, ws,
-                                 &out_dev, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(out_host, out_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(ws);
-  HIP_TRY(h, e);
+  HIP_TRY(h, launch_measures(pos_dev, (long)n_pos, neg_dev, (long)n_neg, negate, recall_level, h->hbuf,
+                             &out_dev, s));
+  HIP_TRY(h, hipMemcpyAsync(out_host, out_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return MCM_OK;
+}
+
+int mcm_score_histogram(mcm_handle* h, const float* scores_dev, int64_t n, const float* edges_dev,
+                        int32_t n_bins, int64_t* counts_dev, void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!scores_dev || !edges_dev || !counts_dev || n < 0 || n_bins <= 0)
+    return fail(h, MCM_EINVAL, "bad argument");
+  if (n_bins > 8192) return fail(h, MCM_ERANGE, "at most 8192 bins");
+  HIP_TRY(h, launch_histogram(scores_dev, (long)n, edges_dev, n_bins, (unsigned long long*)counts_dev,
+                              (hipStream_t)stream));
   return MCM_OK;
 }
 
 int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S, float* out_dev,
                     void* stream) {
+  return mcm_encode_text_ex(h, ids_host, K, S, 1, out_dev, stream);
+}
+
+int mcm_encode_text_ex(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S, int32_t normalize,
+                       float* out_dev, void* stream) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!ids_host || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
@@ -633,7 +659,7 @@ int mcm_encode_text(mcm_handle* h, const int32_t* ids_host, int32_t K, int32_t S
                                      W(h, "text_model.final_layer_norm.weight"),
                                      W(h, "text_model.final_layer_norm.bias"), c.ln_eps,
                                      W(h, "text_projection.weight"), c.proj_dim,
-                                     out_dev + (size_t)k0 * c.proj_dim, s));
+                                     out_dev + (size_t)k0 * c.proj_dim, s, normalize != 0));
     }
   }
   return MCM_OK;

@@ -132,7 +132,45 @@ __global__ __launch_bounds__(RT) void measures_kernel(const float* __restrict__ 
   }
 }
 
+// Fixed-edge histogram of a score vector (numpy.histogram semantics: bin i = [e_i, e_{i+1}), the last bin
+// closed, values outside [e_0, e_nb] dropped).  The per-rank payload of BASELINE.json's "all-gather of
+// per-shard score histograms": constant size, summed over ranks by one RCCL all-reduce.
+constexpr int HB_MAX = 8192;
+__global__ __launch_bounds__(256) void hist_kernel(const float* __restrict__ x, long n,
+                                                   const float* __restrict__ edges, int nb,
+                                                   unsigned long long* __restrict__ counts) {
+  __shared__ float e[HB_MAX + 1];
+  __shared__ uint32_t c[HB_MAX];
+  for (int i = threadIdx.x; i <= nb; i += 256) e[i] = edges[i];
+  for (int i = threadIdx.x; i < nb; i += 256) c[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    if (!(v >= e[0] && v <= e[nb])) continue;
+    int lo = 0, hi = nb;  // largest b with e[b] <= v, clamped to the last bin
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (e[mid] <= v) lo = mid; else hi = mid;
+    }
+    atomicAdd(&c[lo], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (c[i]) atomicAdd(&counts[i], (unsigned long long)c[i]);
+}
+
 }  // namespace
+
+hipError_t launch_histogram(const float* x, long n, const float* edges, int nb, unsigned long long* counts,
+                            hipStream_t s) {
+  if (!x || !edges || !counts || n < 0 || nb <= 0 || nb > HB_MAX) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)nb * sizeof(unsigned long long), s);
+  if (e != hipSuccess || n == 0) return e;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(hist_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, n, edges, nb,
+                     counts);
+  return hipGetLastError();
+}
 
 size_t measures_workspace_bytes(long n) { return (size_t)n * 3 * sizeof(uint32_t) + 4 * sizeof(double) + 64; }
 

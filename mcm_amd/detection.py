@@ -23,12 +23,18 @@ from .tokenizer import load_tokenizer
 PROMPT = "a photo of a {c}"  # reference utils/detection_util.py:228 (no trailing period)
 
 
+def _tokenizer(args):
+    """args.tokenizer_dir (additive) wins over args.ckpt; the hash stand-in is refused when the run
+    uses a real checkpoint (args.weights)."""
+    src = getattr(args, "tokenizer_dir", None) or getattr(args, "ckpt", "")
+    return load_tokenizer(src, allow_hash=not getattr(args, "weights", None))
+
+
 def encode_prompt_bank(args, net, test_labels):
     """`text_features` of the reference (:228-231): K prompts → [K,P] unit-norm fp32."""
-    tokenizer = load_tokenizer(getattr(args, "ckpt", ""))
+    tokenizer = _tokenizer(args)
     text_inputs = tokenizer([PROMPT.format(c=c) for c in test_labels], padding=True, return_tensors="pt")
-    return net.get_text_features(input_ids=text_inputs["input_ids"],
-                                 attention_mask=text_inputs["attention_mask"])
+    return _unit_text_features(net, text_inputs)
 
 
 # A small built-in template set for the prompt-ensemble bank (BASELINE config 5).  The reference
@@ -44,11 +50,42 @@ def encode_prompt_ensemble(args, net, test_labels, templates=None):
     re-normalise → [K,P].  Still a [K,P] bank, so the scoring path is unchanged."""
     templates = list(templates or DEFAULT_TEMPLATES)
     labels = list(test_labels)
-    tokenizer = load_tokenizer(getattr(args, "ckpt", ""))
-    prompts = [t.format(c=c) if "{c}" in t else t.format(c) for c in labels for t in templates]
+    tokenizer = _tokenizer(args)
+    prompts = [t.format(c=c) if "{c}" in t else t.format(c) for c in labels for t in templates]  # class-major
     tok = tokenizer(prompts, padding=True, return_tensors="pt")
-    feats = net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"])
+    feats = _unit_text_features(net, tok)
     return net.reduce_bank(feats, len(labels), len(templates))
+
+
+def _unit_text_features(net, tok):
+    """`get_text_features(...).float()` followed by `/= norm` (reference :229-231).  A NativeCLIP fuses
+    the normalisation; any other `net` honouring the HF contract is normalised here."""
+    try:
+        return net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"],
+                                     normalize=True)
+    except TypeError:
+        f = net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).float()
+        return f / f.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+
+
+def read_templates(path):
+    """Prompt templates from a user file (`--templates`).  Two formats:
+      * a text file, one template per line, the class name marked `{c}` or `{}`;
+      * a Python file in the style of the reference's utils/imagenet_templates.py (a list of
+        `lambda c: f'a bad photo of a {c}.'`): the f-string bodies of the file's FIRST list are
+        extracted, nothing is executed."""
+    import re
+
+    text = open(path, encoding="utf-8").read()
+    if path.endswith(".py"):
+        m = re.search(r"=\s*\[(.*?)^\]", text, re.S | re.M)  # the first list only (the 80 templates); the
+        text = m.group(1) if m else text                      # file's later subsets repeat entries
+        out = [m.group(2) for m in re.finditer(r"""f(['"])((?:(?!\1).)*\{c\}(?:(?!\1).)*)\1""", text)]
+    else:
+        out = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith("#")]
+    if not out or not all(("{c}" in t) or ("{}" in t) for t in out):
+        raise ValueError(f"{path}: no templates found, or a template without a {{c}} / {{}} placeholder")
+    return out
 
 
 def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_out=False):
@@ -98,7 +135,7 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
             if hasattr(loader, "shard"):
                 full = mdist.all_gather_scores(local, n_total)
             else:  # batch-range shards of a generic loader: sizes follow the batch split
-                full = _gather_batch_shards(local, loader, n_total, ws)
+                full = _gather_batch_shards(local, n_total, ws)
         else:
             full = local
     if device_out:
@@ -107,48 +144,49 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
 
 
 def get_mean_prec(args, net, train_loader):
-    """Class-wise means and the shared inverse covariance for the Mahalanobis baseline: same signature,
-    results and side effects as reference utils/detection_util.py:146-174, including two behaviours
-    one would not guess from its docstring and that any drop-in must keep:
-      * `classwise_idx[label].append(idx)` stores the BATCH index of a sample, and those batch indices
-        are then used as row indices into the concatenated feature matrix (:159-160,164-165);
-      * the covariance is taken over all features at once (`torch.cov(all_features.T.double())`), not
-        per class, and inverted in float64 before the cast to float32 (:168-169).
-    Features come from the native tower (raw, or L2-normalised with args.normalize, :158-160); the
-    statistics are host-side float64 torch exactly like the reference's.  Saves the two .pt files the
-    reference saves (:171-172) and returns (classwise_mean [n_cls, feat_dim], precision)."""
+    """Mahalanobis fit: (classwise_mean [n_cls, feat_dim], precision [feat_dim, feat_dim]), with the
+    results and side effects of reference utils/detection_util.py:146-174.  Two behaviours of the
+    reference that a drop-in has to reproduce, stated as the maths they amount to:
+
+      * the reference records, per label, the index of the BATCH a sample came from and then uses those
+        numbers as row indices into the matrix of all features (:159-160,164-165).  So class c's "mean"
+        is  sum_b n[c,b] * F[b] / sum_b n[c,b],  n[c,b] = samples of class c in batch b, F[b] = the b-th
+        feature ROW.  It is computed here as one [n_cls, n_batches] x [n_batches, P] product in float64;
+      * one covariance over all features, inverted in float64, cast to float32 (:168-169).
+
+    Features come from `net.get_image_features(pixel_values=...)` — the plain HF contract (raw
+    projections; L2-normalised when args.normalize).  Writes the reference's two .pt files."""
     import os
-    from collections import defaultdict
 
     import torch
 
-    classwise_mean = torch.empty(args.n_cls, args.feat_dim)
-    all_features = []
-    classwise_idx = defaultdict(list)
+    feats, counts = [], []
     with torch.no_grad():
-        for idx, (images, labels) in enumerate(train_loader):
-            if getattr(args, "model", "CLIP") == "CLIP":
-                features = net.get_image_features_raw(images).float()
+        for images, labels in train_loader:
+            f = net.get_image_features(pixel_values=images).float()
             if args.normalize:
-                features /= features.norm(dim=-1, keepdim=True)
-            for label in labels:
-                classwise_idx[int(label)].append(idx)
-            all_features.append(features.cpu())
-    all_features = torch.cat(all_features)
-    for cls in range(args.n_cls):
-        classwise_mean[cls] = torch.mean(all_features[classwise_idx[cls]].float(), dim=0)
-        if args.normalize:
-            classwise_mean[cls] /= classwise_mean[cls].norm(dim=-1, keepdim=True)
-    cov = torch.cov(all_features.T.double())
-    precision = torch.linalg.inv(cov).float()
+                f = f / f.norm(dim=-1, keepdim=True)
+            feats.append(f.cpu())
+            counts.append(np.bincount(np.asarray(labels, dtype=np.int64).reshape(-1), minlength=args.n_cls))
+    F = torch.cat(feats)                                    # [n, P] float32, dataset order
+    n_cb = torch.from_numpy(np.stack(counts, axis=1)[: args.n_cls].astype(np.float64))  # [n_cls, n_batches]
+    rows = F[: n_cb.shape[1]].double()                       # the rows the reference's indices select
+    classwise_mean = ((n_cb @ rows) / n_cb.sum(dim=1, keepdim=True)).float()
+    if args.normalize:
+        classwise_mean = classwise_mean / classwise_mean.norm(dim=-1, keepdim=True)
+    precision = torch.linalg.inv(torch.cov(F.T.double())).float()
     print(f"cond number: {torch.linalg.cond(precision)}")
     tdir = getattr(args, "template_dir", None)
     if tdir:
         os.makedirs(tdir, exist_ok=True)
-        tag = f"{args.in_dataset}_{args.max_count}_{args.normalize}"
-        torch.save(classwise_mean, os.path.join(tdir, f"{args.model}_classwise_mean_{tag}.pt"))
-        torch.save(precision, os.path.join(tdir, f"{args.model}_precision_{tag}.pt"))
+        for what, t in (("classwise_mean", classwise_mean), ("precision", precision)):
+            torch.save(t, os.path.join(tdir, maha_file_name(args, what)))
     return classwise_mean, precision
+
+
+def maha_file_name(args, what):
+    """File names of the stored Mahalanobis statistics (reference :171-172, eval_ood_detection.py:77-78)."""
+    return f"{args.model}_{what}_{args.in_dataset}_{args.max_count}_{args.normalize}.pt"
 
 
 def get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True):
@@ -166,7 +204,7 @@ def get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_
         for batch_idx, (images, _labels) in enumerate(test_loader):
             if (batch_idx >= total_len // args.batch_size) and in_dist is False:
                 break
-            features = net.get_image_features_raw(images)
+            features = net.get_image_features(pixel_values=images).float()
             if args.normalize:
                 features = features / features.norm(dim=-1, keepdim=True)
             out.append(net.maha_scores(features, state))
@@ -174,24 +212,25 @@ def get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_
     return res.cpu().numpy().astype(np.float32)
 
 
-def _gather_batch_shards(local, loader, n_total, ws):
+def _gather_batch_shards(local, n_total, ws):
+    """All-gather score shards whose sizes only the owning rank knows (batch-range split of a generic
+    loader: the last batch may be short, batch sizes need not be uniform).  Counts are exchanged first;
+    the payload buffer is sized by the largest shard and sliced by the true counts."""
     import torch
     import torch.distributed as dist
 
-    nb = len(loader)
-    bs = -(-n_total // nb) if nb else 0
-    per_b = -(-nb // ws)
-    cap = per_b * bs
+    cnt = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    cnts = torch.empty(ws, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(cnts, cnt)
+    cnts = [int(c) for c in cnts.cpu()]
+    if sum(cnts) != n_total:
+        raise RuntimeError(f"rank shards hold {sum(cnts)} scores, the dataset has {n_total}")
+    cap = max(max(cnts), 1)
     buf = torch.zeros(cap, dtype=torch.float32, device=local.device)
     buf[: local.numel()] = local
     out = torch.empty(ws * cap, dtype=torch.float32, device=local.device)
     dist.all_gather_into_tensor(out, buf)
-    parts = []
-    for r in range(ws):
-        blo, bhi = mdist.shard_range(nb, r, ws)
-        n_r = max(0, min(n_total, bhi * bs) - blo * bs)
-        parts.append(out[r * cap: r * cap + n_r])
-    return torch.cat(parts)
+    return torch.cat([out[r * cap: r * cap + cnts[r]] for r in range(ws)])
 
 
 def print_measures(log, auroc, aupr, fpr, method_name="Ours", recall_level=0.95):

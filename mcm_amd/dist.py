@@ -77,17 +77,27 @@ def all_gather_scores(local, n_total: int):
     return torch.cat(parts)
 
 
-def all_gather_histograms(local_scores, edges):
-    """Fixed-bin score histogram summed over ranks (BASELINE.json's "all-gather of per-shard
-    score histograms"): a constant-size payload for streaming AUROC estimates.  Exact
-    AUROC/FPR95 parity uses `all_gather_scores` (the raw scores are just as cheap)."""
+def all_gather_histograms(local_scores, edges, net=None):
+    """Fixed-bin score histogram summed over ranks (BASELINE.json's "all-gather of per-shard score
+    histograms"): a constant-size payload for streaming AUROC estimates.  Exact AUROC/FPR95 parity
+    uses `all_gather_scores` (the raw scores are just as cheap).
+    Device scores + `net` (a NativeCLIP): the histogram is built by the native kernel
+    (`mcm_score_histogram`) and all-reduced over RCCL without leaving HBM.  CPU scores (the gloo test
+    path): numpy.histogram + gloo all-reduce."""
     import torch
     import torch.distributed as dist
 
-    hist = torch.histogram(local_scores.detach().float().cpu(), bins=torch.as_tensor(edges, dtype=torch.float32))[0]
     rank, ws = world()
+    if getattr(local_scores, "is_cuda", False) and net is not None:
+        hist = net.histogram(local_scores, edges)
+        if ws > 1:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        return hist.cpu().numpy()
+    x = local_scores.detach().float().cpu().numpy() if hasattr(local_scores, "detach") else np.asarray(local_scores)
+    hist = torch.from_numpy(np.histogram(x, bins=np.asarray(edges, dtype=np.float32))[0].astype(np.int64))
     if ws > 1:
-        h = hist.to(local_scores.device)
+        backend = dist.get_backend()
+        h = hist.cuda() if backend == "nccl" else hist
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         hist = h.cpu()
-    return hist.numpy().astype(np.int64)
+    return hist.numpy()

@@ -80,6 +80,9 @@ def load_library():
     L.mcm_tokenizer_vocab_size.restype = i32
     L.mcm_tokenizer_encode.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, i32, vp, vp, ctypes.POINTER(i32)]
     L.mcm_encode_image_raw.argtypes = [vp, vp, i32, vp, vp]
+    L.mcm_encode_image_ex.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.mcm_encode_text_ex.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.mcm_score_histogram.argtypes = [vp, vp, ctypes.c_int64, vp, i32, vp, vp]
     L.mcm_maha_prepare.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     L.mcm_maha_score_features.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
     L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
@@ -98,6 +101,7 @@ EXPORTED_SYMBOLS = [
     "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8", "mcm_tokenizer_create",
     "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
+    "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
 ]
 
 
@@ -174,33 +178,25 @@ class NativeCLIP:
 
     # -- the model contract ----------------------------------------------------------------
     def get_image_features(self, pixel_values, normalize: bool = False):
-        """[b,3,S,S] → [b,P] fp32.  The kernel emits L2-normalised rows (the reference
-        normalises right after, utils/detection_util.py:226); with normalize=False the
-        result is still unit-norm, which the reference's `/= norm` leaves unchanged."""
+        """[b,3,S,S] fp32 (or [b,S,S,3] uint8) → [b,P] fp32.  With the default `normalize=False` this is
+        exactly what HF `CLIPModel.get_image_features` returns — the projection output, NOT unit-norm —
+        so unmodified reference code that normalises (or, for the Mahalanobis baseline, deliberately
+        does not normalise) the rows itself gets what it expects (utils/detection_util.py:158,187,225).
+        `normalize=True` fuses the reference's `/= norm` (:226) into the pooling kernel."""
         import torch
 
         px = self._pixels(pixel_values)
-        fn = self._lib.mcm_encode_image_u8 if px.dtype == torch.uint8 else self._lib.mcm_encode_image
+        fmt = 1 if px.dtype == torch.uint8 else 0
         out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
         for s in range(0, px.shape[0], self.max_batch):
             n = min(self.max_batch, px.shape[0] - s)
-            self._check(fn(self._h, px[s:s + n].data_ptr(), n, out[s:s + n].data_ptr(), _stream_ptr()))
+            self._check(self._lib.mcm_encode_image_ex(self._h, px[s:s + n].data_ptr(), fmt, n, int(bool(normalize)),
+                                                      out[s:s + n].data_ptr(), _stream_ptr()))
         return out
 
     def get_image_features_raw(self, pixel_values):
-        """[b,3,S,S] fp32 → [b,P] fp32 exactly as HF `get_image_features` returns them (no L2
-        normalisation): the Mahalanobis baseline's input (reference utils/detection_util.py:158,187)."""
-        import torch
-
-        px = self._pixels(pixel_values)
-        if px.dtype == torch.uint8:
-            raise ValueError("raw features take the fp32 NCHW input")
-        out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
-        for s in range(0, px.shape[0], self.max_batch):
-            n = min(self.max_batch, px.shape[0] - s)
-            self._check(self._lib.mcm_encode_image_raw(self._h, px[s:s + n].data_ptr(), n,
-                                                       out[s:s + n].data_ptr(), _stream_ptr()))
-        return out
+        """Alias of `get_image_features(pixel_values)` (kept for round-1 callers)."""
+        return self.get_image_features(pixel_values, normalize=False)
 
     def maha_prepare(self, classwise_mean, precision):
         """(means [C,P], precision [P,P]) → opaque state for `maha_scores`."""
@@ -228,8 +224,9 @@ class NativeCLIP:
         return out
 
     def get_text_features(self, input_ids, attention_mask=None, normalize: bool = False):
-        """[K,S] ids → [K,P] fp32 unit-norm rows.  `attention_mask` is accepted for
-        signature parity and ignored: the mask is causal and the pooled row is the first
+        """[K,S] ids → [K,P] fp32: HF `get_text_features` (the text projection output; unit-norm rows
+        only with `normalize=True`, which fuses utils/detection_util.py:231).  `attention_mask` is
+        accepted for signature parity and ignored: the mask is causal and the pooled row is the first
         EOS, so pads never influence it (golden KAT)."""
         import torch
 
@@ -241,16 +238,28 @@ class NativeCLIP:
         if S > self.geo.max_positions:  # HF modeling_clip.py:241-245
             raise ValueError(f"Sequence length must be less than max_position_embeddings (got {S})")
         out = torch.empty((K, self.geo.proj_dim), device=self.device, dtype=torch.float32)
-        self._check(self._lib.mcm_encode_text(self._h, ids.ctypes.data_as(ctypes.c_void_p), K, S,
-                                              out.data_ptr(), _stream_ptr()))
+        self._check(self._lib.mcm_encode_text_ex(self._h, ids.ctypes.data_as(ctypes.c_void_p), K, S,
+                                                 int(bool(normalize)), out.data_ptr(), _stream_ptr()))
         return out
 
     # -- fused hot-loop body -----------------------------------------------------------------
+    def _bank(self, text_features):
+        """The prompt bank as the kernels read it: fp32, contiguous, on this device, [K, proj_dim],
+        unit-norm rows are the caller's responsibility (get_text_features(normalize=True))."""
+        import torch
+
+        t = text_features.to(device=self.device, dtype=torch.float32).contiguous()
+        if t.dim() != 2 or t.shape[1] != self.geo.proj_dim or t.shape[0] == 0:
+            raise ValueError(f"text_features must be [K,{self.geo.proj_dim}], got {tuple(t.shape)}")
+        return t
+
     def score_features(self, image_features, text_features, T: float = 1.0, score: str = "MCM"):
         import torch
 
         f = image_features.to(device=self.device, dtype=torch.float32).contiguous()
-        t = text_features.to(device=self.device, dtype=torch.float32).contiguous()
+        if f.dim() != 2 or f.shape[1] != self.geo.proj_dim:
+            raise ValueError(f"image_features must be [b,{self.geo.proj_dim}], got {tuple(f.shape)}")
+        t = self._bank(text_features)
         out = torch.empty(f.shape[0], device=self.device, dtype=torch.float32)
         self._check(self._lib.mcm_score_features(self._h, f.data_ptr(), f.shape[0], t.data_ptr(),
                                                  t.shape[0], float(T), SCORE_KINDS[score],
@@ -264,7 +273,7 @@ class NativeCLIP:
 
         px = self._pixels(pixel_values)
         fn = self._lib.mcm_score_u8 if px.dtype == torch.uint8 else self._lib.mcm_score
-        t = text_features
+        t = self._bank(text_features)
         if out is None:
             out = torch.empty(px.shape[0], device=self.device, dtype=torch.float32)
         for s in range(0, px.shape[0], self.max_batch):
@@ -314,6 +323,17 @@ class NativeCLIP:
                                            neg.numel(), int(negate), float(recall_level), out,
                                            _stream_ptr()))
         return float(out[0]), float(out[1]), float(out[2])
+
+    def histogram(self, scores, edges):
+        """numpy.histogram(scores, edges)[0] on the device → int64 tensor [len(edges)-1]."""
+        import torch
+
+        x = scores.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        e = torch.as_tensor(edges, dtype=torch.float32).to(self.device).contiguous()
+        out = torch.empty(e.numel() - 1, device=self.device, dtype=torch.int64)
+        self._check(self._lib.mcm_score_histogram(self._h, x.data_ptr(), x.numel(), e.data_ptr(),
+                                                  e.numel() - 1, out.data_ptr(), _stream_ptr()))
+        return out
 
     # -- per-kernel timing -------------------------------------------------------------------
     def profile(self, on: bool):

@@ -1,0 +1,67 @@
+"""Image-folder loader for the real datasets under `--root-dir`: the caller side of SURVEY.md §8f N2.
+
+The reference reads its ImageNet-style sets with `torchvision.datasets.ImageFolder(path, transform=
+Resize(224) → CenterCrop(224) → ToTensor → Normalize)` inside a DataLoader with `shuffle=False`
+(utils/train_eval_util.py:27-33, 96-146).  Here the host only decodes (Pillow → RGB uint8, any size); the
+four transform steps run on the GPU: `NativeCLIP.resize_crop` (mcm_resize_crop_u8, bit-exact against
+Pillow's antialiased bilinear resize) produces the uint8 [b,S,S,3] batch and the scoring kernels fold
+ToTensor + Normalize into their patch gather (`mcm_score_u8`).  Sample order is ImageFolder's: class
+directories sorted by name, files sorted by path inside each class, so score i ↔ sample i as in the
+reference.  torchvision itself is not needed (it is not installed in the build image).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterator, List, Tuple
+
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+
+class FolderIndex:
+    """`loader.dataset` of the reference's loaders: `__len__`, `.classes`, `.samples`, `.targets`."""
+
+    def __init__(self, root: str):
+        self.root = root
+        self.classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"no class directories under {root}")
+        self.samples: List[Tuple[str, int]] = []
+        for ci, c in enumerate(self.classes):
+            for dirpath, _dirs, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(dirpath, f), ci))
+        if not self.samples:
+            raise FileNotFoundError(f"no image files under {root}")
+        self.targets = [t for _, t in self.samples]
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+
+class ImageFolderU8:
+    """Iterates `(images uint8 [b,S,S,3] on the device, labels int64 [b])` over [lo, hi) of a FolderIndex."""
+
+    def __init__(self, root_or_index, net, batch_size: int, lo: int = 0, hi: int | None = None):
+        self.dataset = root_or_index if isinstance(root_or_index, FolderIndex) else FolderIndex(root_or_index)
+        self.net, self.batch_size = net, int(batch_size)
+        self.lo, self.hi = lo, (len(self.dataset) if hi is None else hi)
+
+    def __len__(self) -> int:
+        return max(0, -(-(self.hi - self.lo) // self.batch_size))
+
+    def shard(self, lo: int, hi: int) -> "ImageFolderU8":
+        return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi)
+
+    def __iter__(self) -> Iterator:
+        import numpy as np
+        import torch
+        from PIL import Image
+
+        for s in range(self.lo, self.hi, self.batch_size):
+            chunk = self.dataset.samples[s:min(s + self.batch_size, self.hi)]
+            imgs = []
+            for path, _ in chunk:
+                with Image.open(path) as im:  # torchvision's default loader: PIL, convert("RGB")
+                    imgs.append(torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.uint8).copy()))
+            yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk], dtype=torch.long)

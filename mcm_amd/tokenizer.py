@@ -94,17 +94,28 @@ class NativeBPETokenizer:
         return {"input_ids": ids, "attention_mask": mask}
 
 
-def load_tokenizer(ckpt: str):
-    """The native BPE when `ckpt` is a directory holding the checkpoint's vocab.json + merges.txt;
-    else HF's CLIP tokenizer when its vocabulary is available locally; else HashTokenizer.
-    transformers 5.x returns an EMPTY-vocabulary tokenizer instead of raising when the files
-    are missing (every prompt then tokenises to the same ids), so the result is validated."""
-    import os
+class TokenizerUnavailable(RuntimeError):
+    pass
 
+
+def load_tokenizer(ckpt: str, *, allow_hash: bool = True):
+    """`CLIPTokenizer.from_pretrained(args.ckpt)` of the reference (utils/detection_util.py:216), in order:
+      1. the native C++ BPE when `ckpt` is a directory holding vocab.json + merges.txt;
+      2. HF's CLIPTokenizer when its vocabulary is available locally (`ckpt` = hub id or directory).
+         transformers 5.x returns an EMPTY-vocabulary tokenizer instead of raising when the files are
+         missing (every prompt then tokenises to the same ids), so the result is validated;
+      3. HashTokenizer — only with `allow_hash`, and never silently: a RuntimeWarning says that the
+         ids are stand-ins (fine for synthetic weights, meaningless with a real checkpoint).
+    `allow_hash=False` (the CLI sets it when --weights is given) raises TokenizerUnavailable instead."""
+    import os
+    import warnings
+
+    why = []
     if ckpt and os.path.isdir(ckpt):
         v, m = os.path.join(ckpt, "vocab.json"), os.path.join(ckpt, "merges.txt")
         if os.path.exists(v) and os.path.exists(m):
             return NativeBPETokenizer(v, m)
+        why.append(f"{ckpt} holds no vocab.json + merges.txt")
     try:
         from transformers import CLIPTokenizer
 
@@ -113,6 +124,12 @@ def load_tokenizer(ckpt: str):
         ids = np.asarray(probe["input_ids"])
         if len(tok) >= 49408 and ids[0, 0] == BOS and ids.max() == EOS and (ids[0] != ids[1]).any():
             return tok
-    except Exception:
-        pass
+        why.append(f"transformers returned an empty-vocabulary tokenizer for {ckpt!r}")
+    except Exception as e:  # offline hub, unknown id, transformers missing
+        why.append(f"CLIPTokenizer.from_pretrained({ckpt!r}) failed: {type(e).__name__}: {e}".splitlines()[0])
+    msg = "no CLIP BPE vocabulary available (" + "; ".join(why) + ")"
+    if not allow_hash:
+        raise TokenizerUnavailable(msg + "; pass --tokenizer-dir <dir with vocab.json, merges.txt>")
+    warnings.warn(msg + ": using HashTokenizer stand-in ids — valid only with synthetic weights",
+                  RuntimeWarning, stacklevel=2)
     return HashTokenizer()

@@ -291,7 +291,37 @@ def capture_preprocess(size=224):
     np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
 
 
+def capture_concept_banks():
+    """The reference's four ImageNet concept banks (utils/common.py:16-73), produced by ITS functions from ITS
+    data/ directory: ImageNet10 / ImageNet20 in full (what utils/common.py must reproduce without any data
+    file), ImageNet100 / ImageNet-1k as sha-256 of the joined names (checked wherever the reference's data/
+    directory is available, i.e. in the build container)."""
+    import hashlib
+    import json
+
+    spec = importlib.util.spec_from_file_location("ref_common", "/root/reference/utils/common.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cwd = os.getcwd()
+    os.chdir("/root/reference")  # the reference opens data/... relative to its own root
+    try:
+        banks = {"ImageNet10": list(mod.obtain_ImageNet10_classes()),
+                 "ImageNet20": list(mod.obtain_ImageNet20_classes())}
+        for name, fn in (("ImageNet100", mod.obtain_ImageNet100_classes), ("ImageNet", mod.obtain_ImageNet_classes)):
+            names = [str(x) for x in fn()]
+            banks[name + "_sha256"] = hashlib.sha256("\n".join(names).encode()).hexdigest()
+            banks[name + "_n"] = len(names)
+            banks[name + "_first3"] = names[:3]
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "concept_banks.json"), "w") as f:
+        json.dump(banks, f, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "banks":
+        capture_concept_banks()
+        sys.exit(0)
     ref = load_reference_detection_util()
     capture_measures(ref)
     m, geo = capture_clip("tiny", n_img=4, n_txt=6)
@@ -302,3 +332,4 @@ if __name__ == "__main__":
     capture_clip("ViT-L/14", n_img=1, n_txt=2, sample_rows=[0, 256])   # BASELINE config 4's checkpoint
     capture_clip("ViT-B/32", n_img=2, n_txt=2, sample_rows=[0, 49])
     capture_preprocess()
+    capture_concept_banks()

@@ -96,9 +96,14 @@ def test_tokenizer_contract():
 def test_load_tokenizer_never_returns_degenerate_tokenizer():
     """No vocabulary exists offline; transformers 5.x then hands back an empty tokenizer that maps
     every prompt to the same ids — load_tokenizer must detect that and fall back."""
-    from mcm_amd.tokenizer import BOS, EOS, load_tokenizer
+    import pytest
 
-    tok = load_tokenizer("ViT-B/16")
+    from mcm_amd.tokenizer import BOS, EOS, TokenizerUnavailable, load_tokenizer
+
+    with pytest.warns(RuntimeWarning, match="HashTokenizer stand-in"):   # never a silent fallback
+        tok = load_tokenizer("openai/clip-vit-base-patch16")
+    with pytest.raises(TokenizerUnavailable):                            # real weights: refuse stand-in ids
+        load_tokenizer("openai/clip-vit-base-patch16", allow_hash=False)
     ids = np.asarray(tok([f"a photo of a concept{k:04d}" for k in range(5)], padding=True,
                          return_tensors="np")["input_ids"])
     assert (ids[:, 0] == BOS).all() and ids.max() == EOS

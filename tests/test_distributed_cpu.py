@@ -59,7 +59,8 @@ def _worker(rank, ws, port, n, bs, use_shard, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,bs,use_shard", [(37, 5, True), (37, 5, False), (16, 8, True), (3, 4, True)])
+@pytest.mark.parametrize("n,bs,use_shard", [(37, 5, True), (37, 5, False), (16, 8, True), (3, 4, True),
+                                            (40, 12, False), (1000, 512, False), (7, 16, False)])
 def test_two_rank_gather_equals_single(n, bs, use_shard):
     import types as _t
 

@@ -53,12 +53,20 @@ def test_towers_vs_hf_fixture(golden_dir, name, fixture, n_extra, precision):
     try:
         px, _ = make_pixels(int(g["n_img"]), geo.image_size, 10, ood=False, seed=1)
         ids, mask = make_token_ids(int(g["n_txt"]), seed=2)
-        img = net.get_image_features(pixel_values=torch.from_numpy(px).cuda()).cpu().numpy()
-        txt = net.get_text_features(input_ids=torch.from_numpy(ids),
-                                    attention_mask=torch.from_numpy(mask)).cpu().numpy()
+        pxd, idt, mkt = torch.from_numpy(px).cuda(), torch.from_numpy(ids), torch.from_numpy(mask)
+        # the plain contract returns what HF returns: the projection output, not unit-norm
+        raw_i = net.get_image_features(pixel_values=pxd).cpu().numpy()
+        raw_t = net.get_text_features(input_ids=idt, attention_mask=mkt).cpu().numpy()
+        img = net.get_image_features(pixel_values=pxd, normalize=True).cpu().numpy()
+        txt = net.get_text_features(input_ids=idt, attention_mask=mkt, normalize=True).cpu().numpy()
         want_i, want_t = _unit(g["image_features"]), _unit(g["text_features"])
         np.testing.assert_allclose(np.linalg.norm(img, axis=1), 1.0, atol=1e-5)
+        np.testing.assert_allclose(img, _unit(raw_i), rtol=0, atol=1e-6)   # fused `/= norm` == the reference's
+        np.testing.assert_allclose(txt, _unit(raw_t), rtol=0, atol=1e-6)
         if precision == "fp32":
+            sc_i, sc_t = np.abs(g["image_features"]).max(), np.abs(g["text_features"]).max()
+            np.testing.assert_allclose(raw_i, g["image_features"], rtol=0, atol=2e-4 * max(1.0, sc_i))
+            np.testing.assert_allclose(raw_t, g["text_features"], rtol=0, atol=2e-4 * max(1.0, sc_t))
             np.testing.assert_allclose(img, want_i, rtol=0, atol=2e-4)
             np.testing.assert_allclose(txt, want_t, rtol=0, atol=2e-4)
         else:
@@ -70,7 +78,7 @@ def test_towers_vs_hf_fixture(golden_dir, name, fixture, n_extra, precision):
 
             o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
             px2, _ = make_pixels(n_extra, geo.image_size, 10, ood=True, seed=3)
-            got = net.get_image_features(pixel_values=torch.from_numpy(px2).cuda()).cpu().numpy()
+            got = net.get_image_features(pixel_values=torch.from_numpy(px2).cuda(), normalize=True).cpu().numpy()
             want = o.encode_image(px2)
             if precision == "fp32":
                 np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
@@ -99,7 +107,7 @@ def test_get_ood_scores_clip_vs_reference_outputs(golden_dir, precision):
             return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
 
     old = detection.load_tokenizer
-    detection.load_tokenizer = lambda ckpt: FixedTok()
+    detection.load_tokenizer = lambda ckpt, **kw: FixedTok()
     try:
         l_in = SyntheticLoader(SyntheticImageSet(n_id, geo.image_size, K, False, 1), bs)
         l_out = SyntheticLoader(SyntheticImageSet(n_ood, geo.image_size, K, True, 1), bs)
@@ -143,7 +151,7 @@ def _auroc_case(name, K, n, precisions):
     for precision in precisions:
         net = _net(name, precision, max_batch=256, max_prompt_tokens=2048)
         try:
-            txt = net.get_text_features(input_ids=torch.from_numpy(ids))
+            txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
             s_in = net.score_images(torch.from_numpy(px_in).cuda(), txt, 1.0, "MCM").cpu().numpy()
             s_out = net.score_images(torch.from_numpy(px_out).cuda(), txt, 1.0, "MCM").cpu().numpy()
         finally:
@@ -187,7 +195,7 @@ def test_full_size_properties(b16):
     """BASELINE config sizes (B/16, batch 512, K=1000): properties that need no oracle."""
     K = 1000
     ids, _ = make_token_ids(K, seed=2)
-    txt = b16.get_text_features(input_ids=torch.from_numpy(ids))
+    txt = b16.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
     assert txt.shape == (K, 512)
     assert torch.allclose(txt.norm(dim=1), torch.ones(K, device="cuda"), atol=1e-5)
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -207,7 +215,7 @@ def test_full_size_properties(b16):
     s_perm = b16.score_images(px[:64], txt[perm], 1.0, "MCM")
     torch.testing.assert_close(s_perm, s_full[:64], rtol=1e-6, atol=1e-9)
     # feature path == fused path
-    f = b16.get_image_features(pixel_values=px[:64])
+    f = b16.get_image_features(pixel_values=px[:64], normalize=True)
     torch.testing.assert_close(b16.score_features(f, txt, 1.0, "MCM"), s_full[:64], rtol=0, atol=0)
     # max-logit is the plain cosine: bounded by 1 and equal to the max of f @ txt.T
     ml = b16.score_features(f, txt, 1.0, "max-logit")
@@ -222,7 +230,7 @@ def test_full_size_bf16_vs_oracle_small_sample(b16):
     o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
     px, _ = make_pixels(4, 224, 10, ood=False, seed=9)
     want = o.encode_image(px)
-    got = b16.get_image_features(pixel_values=torch.from_numpy(px).cuda()).cpu().numpy()
+    got = b16.get_image_features(pixel_values=torch.from_numpy(px).cuda(), normalize=True).cpu().numpy()
     c = _cos(got, want)
     print("bf16 vs fp32-oracle cosine (full B/16):", c, "max|d|", np.abs(got - want).max())
     assert c.min() > 0.999
@@ -275,8 +283,10 @@ def test_uint8_ingest_matches_float_path():
     want = orc.OracleCLIP(geo, sd).encode_image(f32)
     net = _net("B16-2L", "fp32", max_batch=8, max_prompt_tokens=1024)
     try:
-        got_u8 = net.get_image_features(pixel_values=torch.from_numpy(u8).cuda()).cpu().numpy()
-        got_f = net.get_image_features(pixel_values=torch.from_numpy(f32).cuda()).cpu().numpy()
+        got_u8 = net.get_image_features(pixel_values=torch.from_numpy(u8).cuda(), normalize=True).cpu().numpy()
+        got_f = net.get_image_features(pixel_values=torch.from_numpy(f32).cuda(), normalize=True).cpu().numpy()
+        raw_u8 = net.get_image_features(pixel_values=torch.from_numpy(u8).cuda()).cpu().numpy()
+        np.testing.assert_allclose(_unit(raw_u8), got_u8, rtol=0, atol=1e-6)
     finally:
         net.close()
     np.testing.assert_allclose(got_u8, want, rtol=0, atol=2e-4)
@@ -296,7 +306,7 @@ def test_prompt_ensemble_bank():
         tok = detection.load_tokenizer("x")
         prompts = [t.format(c=c) for c in labels for t in detection.DEFAULT_TEMPLATES]
         ids = tok(prompts, padding=True, return_tensors="pt")["input_ids"]
-        feats = net.get_text_features(input_ids=ids).cpu().numpy().reshape(7, T, -1)
+        feats = net.get_text_features(input_ids=ids, normalize=True).cpu().numpy().reshape(7, T, -1)
     finally:
         net.close()
     want = feats.mean(axis=1)

@@ -69,7 +69,8 @@ def test_feeds_the_scoring_path(net):
     imgs = [rng.integers(0, 256, (int(rng.integers(230, 600)), int(rng.integers(230, 600)), 3), dtype=np.uint8)
             for _ in range(6)]
     ids, mask = make_token_ids(10, seed=1)
-    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                                normalize=True)
     dev = net.score_images(net.resize_crop([_dev(i) for i in imgs]), txt, 1.0, "MCM")
     ref = net.score_images(_dev(np.stack([orc.resize_crop_u8(i, 224) for i in imgs])), txt, 1.0, "MCM")
     assert torch.equal(dev, ref) and torch.isfinite(dev).all()

@@ -14,7 +14,7 @@ from mcm_amd.synth import make_token_ids  # noqa: E402
 n_id, n_ood, B = (int(v) for v in (sys.argv[1:4] + ["8192", "4096", "512"][len(sys.argv) - 1:]))
 net = build_model("ViT-B/16", max_batch=B, max_prompt_tokens=1000 * 16)
 ids, mask = make_token_ids(1000, seed=2)
-txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), normalize=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 pool = [torch.randint(0, 256, (375, 500, 3), dtype=torch.uint8, device="cuda", generator=g) for _ in range(B)]
 shift = [torch.clamp(p.int() + 40, 0, 255).to(torch.uint8) for p in pool]  # a brighter "OOD" set

@@ -1,5 +1,5 @@
 // gemm_bench.hip — standalone A/B harness for the GEMM kernels of mcm_amd/csrc/gemm.hip.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I mcm_amd/csrc tools/gemm_bench.hip \
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMCM_HARNESS [-DMCM_GEMM_TRACE] -I mcm_amd/csrc tools/gemm_bench.hip \
 //        mcm_amd/csrc/gemm.hip -o /tmp/gemm_bench
 // Run:   gemm_bench M N K epi [iters]   → per-variant time / TFLOP/s, max |diff| vs variant 0
 #include <stdio.h>
@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(dt, 0, words * 8));
     GemmArgs b = a;
     b.pos = (const float*)dt;
-    gemm_set_variant(3);
+    gemm_set_variant(argc > 8 ? atoi(argv[8]) : 3);
     gemm_set_dbg((argc > 7 ? atoi(argv[7]) : 0) | 128);
     CK(launch_gemm(MCM_PREC_BF16, epi, b, 0));
     CK(hipDeviceSynchronize());
