@@ -4,23 +4,36 @@ A "step" is one pass of the hot path (reference utils/detection_util.py:223-248)
 batch of synthetic, device-resident, already-normalised fp32 pixels: vision tower → cosine
 vs the pre-encoded prompt bank → softmax/T → max → [B] scores, through the C ABI of
 libmcm_hip.so.  Workload at any N: CLIP-ViT-B/16, K=1000 prompts (the ImageNet-1k concept
-bank the metric is quoted on), batch 512 per GPU, bf16 MFMA operands / fp32 accumulate;
-random-init weights of that architecture (no checkpoint offline).  N>1 = one process per GPU
-(torchrun), images sharded with no data-path collective; the per-dataset RCCL all-gather of
-the score shards is inside the timed region (weak scaling).
+bank the metric is quoted on), batch 512 per GPU, 16-bit MFMA operands / fp32 accumulate;
+random-init weights of that architecture (no checkpoint offline).
 
-Prints ONE JSON line (rank 0) with `roofline` (GEMM kernel family: algorithmic FLOP ÷ HIP-event
-time of the launches of every 4th timed step — `profiled_steps`; bracketing every launch of every
-step costs 2.3 % of the throughput being measured) and `cpu_baseline` (the reference's own arithmetic — HF
-transformers CLIPModel, fp32 — driven by a re-statement of the reference loop on the host
-cores, on a bounded sample; the C oracle if transformers is unavailable).
+N > 1: one process per GPU.  Launched by the driver under `torch.distributed.run` (RANK / LOCAL_RANK /
+WORLD_SIZE in the env) or, when `--gpus N` is given WITHOUT that env, bench.py re-executes itself under
+`torch.distributed.run --nproc-per-node N` — `--gpus N` never silently measures one GPU.  Images are
+sharded with no data-path collective; the per-dataset all-gather of the score shards (RCCL) is inside
+the timed region (weak scaling).  If the box has fewer devices than ranks (a 1-GPU box running the
+2-rank logic check) the ranks share devices and the collective falls back to gloo, because RCCL refuses
+two ranks on one device; the JSON line says so (`"collective"`).
+
+Prints ONE JSON line (rank 0) with
+  roofline      GEMM kernel family: algorithmic FLOP ÷ HIP-event time of the launches of every 4th timed
+                step (`profiled_steps`; bracketing every launch of every step costs 2.3 % of throughput);
+  cpu_baseline  the reference's own arithmetic — HF transformers CLIPModel, fp32 — driven by a re-statement
+                of the reference loop on the host cores, on a bounded sample (the C oracle if transformers
+                is unavailable);
+  sustained     the same step repeated for >= 5 s after the timed region, with sclk / package power sampled
+                through rocm-smi: what the part holds at its power limit, next to the short timed burst;
+  parity        (N = 1) AUROC / AUPR / FPR95 of this dtype against the exact-fp32 arm on the headline
+                configuration (mcm_amd/parity.py): full B/16, K = 1000, 50 000 ID + 10 000 OOD images.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +43,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+DEFAULT_PRECISION = "fp16"  # the 16-bit mode that holds AUROC/FPR95 to the fp32 arm
 
 
 def pmc_traffic(family="gemm"):
@@ -39,11 +53,44 @@ def pmc_traffic(family="gemm"):
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1]))["per_launch_bytes"][family]["hbm_bytes"]
+        return json.load(open(files[-1]))["per_launch_bytes"][family]["hbm_bytes"], os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
+
+
+class SmiSampler(threading.Thread):
+    """sclk (MHz) and package power (W) of device 0 every `period` s through rocm-smi."""
+
+    def __init__(self, period=0.5):
+        super().__init__(daemon=True)
+        self.period, self.samples, self._stop_evt = period, [], threading.Event()
+
+    def run(self):
+        import re
+
+        while not self._stop_evt.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
+                                     timeout=5).stdout
+                clk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+                if clk and pw:
+                    self.samples.append((int(clk.group(1)), float(pw.group(1))))
+            except Exception:
+                pass
+            self._stop_evt.wait(self.period)
+
+    def stop(self):
+        self._stop_evt.set()
+        self.join(timeout=10)
+        busy = [s for s in self.samples if s[1] > 300]
+        if not busy:
+            return {"samples": len(self.samples), "busy_samples": 0}
+        return {"samples": len(self.samples), "busy_samples": len(busy),
+                "sclk_mhz_mean": sum(s[0] for s in busy) / len(busy),
+                "power_w_mean": sum(s[1] for s in busy) / len(busy)}
 
 
 def cpu_baseline(geo, sd, ids, mask, K, px_sample, budget_s, native_scores):
@@ -101,6 +148,18 @@ def cpu_baseline(geo, sd, ids, mask, K, px_sample, budget_s, native_scores):
     return info
 
 
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: become N ranks."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,16 +168,20 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
     ap.add_argument("--prompts", type=int, default=1000, help="K: size of the concept bank")
     ap.add_argument("--ckpt", default="ViT-B/16")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--sustain-seconds", type=float, default=5.0, help="0 disables the sustained-throughput leg")
+    ap.add_argument("--no-drift", action="store_true", help="skip the AUROC/FPR95 drift leg (N = 1 only)")
+    ap.add_argument("--drift-n", type=int, nargs=2, default=[50000, 10000], metavar=("N_ID", "N_OOD"))
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)
 
-    import numpy as np
     import torch
 
     from mcm_amd import dist as mdist
@@ -127,9 +190,15 @@ def main():
     from mcm_amd.synth import make_token_ids
     from mcm_amd.weights import synth_state_dict
 
-    rank, ws, local = mdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    assert ws == args.gpus or ws == 1, f"WORLD_SIZE={ws} but --gpus {args.gpus}"
+    ws_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws_env}; launch with "
+                         f"`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
+    ndev = torch.cuda.device_count()
+    shared = ws_env > ndev  # more ranks than devices: logic check only
+    rank, ws, local = mdist.init_from_env(backend="gloo" if shared else None)
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -178,7 +247,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if ws > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     prof = None
@@ -187,9 +256,29 @@ def main():
         net.profile(False)
     assert torch.isfinite(scores).all()
 
+    sustained = None
+    if args.sustain_seconds > 0:  # every rank runs it (the chip-level power state is what is being measured)
+        n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
+        sampler = SmiSampler() if rank == 0 else None
+        if sampler:
+            sampler.start()
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_sus):
+            net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[i % args.steps])
+        torch.cuda.synchronize()
+        barrier()
+        dts = time.perf_counter() - t1
+        sustained = {"steps": n_sus, "seconds": dts, "images_per_sec": ws * n_sus * B / dts}
+        if sampler:
+            sustained.update(sampler.stop())
+
+    line = None
     if rank == 0:
         total_images = ws * args.steps * B
         value = total_images / dt
+        nominal = geo.vision_flops_per_image() / 1e9 + 2e-9 * geo.proj_dim * K
         line = {
             "metric": "images/sec MCM-scored (CLIP-B/16, 1000 prompts)",
             "value": value, "unit": "images/sec", "n_gpus": ws, "steps": args.steps,
@@ -200,35 +289,64 @@ def main():
                                    f"random-init weights), K={K} prompts pre-encoded, batch {B}/GPU, "
                                    f"fp32 NCHW pixels resident in HBM → [B] scores",
                        "batch_per_gpu": B, "prompts": K, "parallelism": f"image-sharded x{ws}"},
-            "gflop_per_image": geo.vision_flops_per_image() / 1e9 + 2e-9 * geo.proj_dim * K,
+            "gflop_per_image": nominal,
         }
+        if ws > 1:
+            line["collective"] = ("gloo: %d ranks share %d device(s), RCCL refuses duplicate devices — logic "
+                                  "check, not a scaling number" % (ws, ndev)) if shared else \
+                "nccl (RCCL) all_gather_into_tensor of the score shards, inside the timed region"
+        if sustained:
+            line["sustained_images_per_sec"] = sustained.pop("images_per_sec")
+            line["sustained"] = sustained
         if prof:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
             peak = MFMA_PEAK_TFLOPS[args.precision]
+            traffic, traffic_src = pmc_traffic("gemm") if B == 512 else (None, None)
             line["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_p256_kernel family (all GEMM launches of a step)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak if ach else None,
-                "traffic": pmc_traffic("gemm") if (args.precision == "bf16" and B == 512) else None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_unit": "HBM bytes per launch = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC, profiles/",
                 "avg_launch_us": 1e3 * g["ms"] / g["launches"] if g["launches"] else None,
                 "flop_per_launch": g["flops"] / g["launches"] if g["launches"] else None,
             }
             tot = sum(v["ms"] for v in prof.values())
+            executed = sum(v["flops"] for v in prof.values()) / n_prof / B / 1e9
             line["kernel_ms_per_step"] = {k: round(v["ms"] / n_prof, 4) for k, v in prof.items()}
             line["profiled_steps"] = n_prof
             line["kernel_time_frac"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if tot}
-            line["end_to_end_mfma_frac"] = value * line["gflop_per_image"] / 1e3 / ws / peak
+            # effective: nominal tower FLOP per image over wall time.  The last layer runs its MLP / out-proj
+            # for the CLS row only (identical results), so the FLOP actually executed are lower:
+            line["end_to_end_mfma_frac_effective"] = value * nominal / 1e3 / ws / peak
+            line["gflop_per_image_executed"] = executed
+            line["end_to_end_mfma_frac_executed"] = value * executed / 1e3 / ws / peak
         if ws == 1 and args.cpu_seconds > 0:
             nb = args.cpu_batch
             px = bufs[0][:nb].cpu()
             native = scores[0][:nb].cpu().numpy() if args.steps >= 1 and nbuf >= 1 else None
             # scores[0] was computed from bufs[0] in step 0
             line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, px, args.cpu_seconds, native)
-        print(json.dumps(line), flush=True)
     net.close()
+    del bufs, scores
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if ws == 1 and not args.no_drift and args.precision != "fp32":
+            from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
+
+            d = measure_drift(args.ckpt, K=K, n_id=args.drift_n[0], n_ood=args.drift_n[1], batch=B,
+                              arms=(args.precision,), device=local, **HEADLINE_PIXELS)
+            arm = d["arms"][args.precision]
+            line["parity"] = {"vs": "exact-fp32 MFMA arm (itself pinned to the CPU oracle / HF)",
+                              "n_id": d["n_id"], "n_ood": d["n_ood"], "pixels": d["pixels"], "weights": d["weights"],
+                              "auroc_fp32": d["reference"]["auroc"], "fpr95_fp32": d["reference"]["fpr95"],
+                              "d_auroc": arm["d_auroc"], "d_aupr": arm["d_aupr"], "d_fpr95": arm["d_fpr95"],
+                              "max_abs_dscore": arm["max_abs_dscore"], "rms_dscore": arm["rms_dscore"],
+                              "score_std_id": d["reference"]["score_std_id"]}
+        print(json.dumps(line), flush=True)
     if ws > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

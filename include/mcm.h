@@ -41,9 +41,10 @@ extern "C" {
 #define MCM_ESHAPE (-6)   /* parameter shape does not match the config                */
 #define MCM_ERANGE (-7)   /* batch / prompt count / sequence exceeds the config       */
 
-/* arithmetic modes for the GEMM/attention operands (accumulation is always fp32,
- * the residual stream, LayerNorm statistics, softmax and the whole scoring tail are
- * always fp32). */
+/* arithmetic modes for the GEMM/attention operands of the VISION tower (accumulation is always fp32,
+ * the residual stream, LayerNorm statistics, softmax and the whole scoring tail are always fp32).
+ * The TEXT tower always runs in MCM_PREC_F32: the prompt bank is encoded once per dataset, off the hot
+ * loop, and rounding it would perturb every image's cosines in the same direction. */
 #define MCM_PREC_BF16 0   /* bf16 MFMA operands  (v_mfma_f32_16x16x32_bf16)            */
 #define MCM_PREC_F32 1    /* exact fp32 MFMA     (v_mfma_f32_16x16x4_f32) — parity arm  */
 #define MCM_PREC_F16 2    /* fp16 MFMA operands  (v_mfma_f32_16x16x32_f16): same rate as bf16,
@@ -274,6 +275,10 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
  * 2-stage (4: counted epilogue stores)).  Process-wide.
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
+/* Testing hook: 16-bit attention kernel — 1 (default) = the transpose-read kernel (K and V by LDS-DMA,
+ * ds_read_b64_tr_b16, row sums on the matrix pipe), 0 = the round-1 kernel (V transposed while staged),
+ * kept as the A/B arm of tests/test_gpu_kernels.py.  Process-wide. */
+int mcm_debug_attention_variant(int32_t variant);
 
 #ifdef __cplusplus
 }

@@ -209,6 +209,203 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
   }
 }
 
+// =========================================================================================
+// Round-2 kernel: K AND V by LDS-DMA (no register staging, no transposing LDS writes), V^T
+// fragments by the gfx950 transpose read, row sums on the matrix pipe, three workgroups per CU.
+//
+// What changed against attn_bf16_kernel above and why (rocprofv3 of round 1: 180 us per launch at
+// B/16 batch 512, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 %, VALU-issue bound):
+//   * V stays row-major in LDS ([key][64 d], 128-B rows, the 32-B column segment XORed with
+//     (key>>1)&3) and is filled by LDS-DMA exactly like K.  The PV A-operand (V^T, 4 keys x 16 dims
+//     per 16-lane group) comes from ds_read_b64_tr_b16: lane i of a group passes the address of 4
+//     contiguous dims of key i/4 and receives dim i of the 4 keys (tools/isa_probe.hip).  Gone: 8
+//     global V loads, ~64 ds_write_b32 and the XOR address arithmetic per thread, and the bank
+//     conflicts of the transposing writes.  The read address is lane_base[dt] + tile * 2048: one VGPR
+//     per 16-dim block, everything else immediate offsets.
+//   * the softmax denominator is one more MFMA per key step (A = all ones): 52 v_add per 16-query
+//     block leave the VALU, which is the pipe this kernel is bound by; it also makes the denominator
+//     the sum of the ROUNDED probabilities, i.e. the weights that multiply V sum to exactly 1.
+//   * keys are padded to a multiple of 16, not 32 (an odd tile count ends with one 16x16x16 MFMA), so
+//     197 tokens need 2 x 208 x 128 B = 52 KiB and three workgroups fit a CU (was 62 KiB, two): more
+//     loads in flight per CU for a kernel whose floor is HBM (620 MB per launch).
+// =========================================================================================
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 tr_read16(const char* p) {  // ds_read_b64_tr_b16
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)p));
+}
+
+// Two things learned on the device while bringing this kernel up (tools/attn_debug.py):
+//  * every value that feeds an MFMA must come from an instruction hipcc can see.  The bf16 pack used to
+//    be an inline-asm v_cvt_pk_bf16_f32; hipcc pads no wait states between an asm statement's VALU write
+//    and an MFMA reading it as an operand (guide §5.7 item 2), and here the packed probabilities go
+//    straight into the row-sum and PV MFMAs: wrong rows for fixed lane groups, bf16 only.  pack_bf2
+//    (common.hpp) is now __builtin_convertvector, which selects the same instruction with the hazard
+//    handled by the compiler.
+//  * an odd tile count does NOT end with a v_mfma_f32_16x16x16 in the same accumulator chain as the
+//    16x16x32 steps: every instantiation that mixed the two shapes in one chain (NT = 3, 5, 7, 13, 17)
+//    returned wrong 16-dim blocks whose position moved with register allocation, instantiations with one
+//    shape (NT = 1, 4) were exact.  The 16-key tail is a 32-key step whose upper half is zero on both
+//    operands (one extra 16-cycle MFMA per 16-dim block).
+// mfma_keep additionally keeps A and B live past the instruction so the result is never allocated on top
+// of an operand (no instruction emitted; not the cause of either fault, kept as cheap insurance).
+template <int PREC>
+__device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
+  f32x4_t d = mfma16<PREC>(a, b, c);
+  asm volatile("" : "+v"(d) : "v"(__builtin_bit_cast(u32x4_t, a)), "v"(__builtin_bit_cast(u32x4_t, b)));
+  return d;
+}
+
+template <int PREC, int NT, bool CAUSAL>
+__global__ __launch_bounds__(256, (NT <= 13 ? 3 : 2)) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
+                                                                         uint16_t* __restrict__ out, int L,
+                                                                         int heads, int qrows, int rev) {
+  enter_precision_mode<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LP = NT * 16;           // padded keys
+  constexpr int MAXQB = (NT + 3) / 4;   // q-blocks per wave
+  constexpr uint32_t ONE2 = PREC == MCM_PREC_F16 ? 0x3c003c00u : 0x3f803f80u;  // two 1.0 operands
+  char* Ks = smem;               // [LP][128 B], GEMM-style pair/XOR image
+  char* Vs = smem + LP * 128;    // [LP][128 B], 32-B segment s stored at s ^ ((key >> 1) & 3)
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int seq = bid / heads, h = bid - seq * heads;
+  const int D = heads * 64;
+  const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
+  const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+  const int fr = lane & 15, g = lane >> 4;
+
+  // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
+  const int nqb = (qrows + 15) / 16;
+  uint4 qf[MAXQB][2];
+#pragma unroll
+  for (int i = 0; i < MAXQB; ++i) {
+    const int qr = min((wave + 4 * i) * 16 + fr, L - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[i][kk] = (wave + 4 * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
+                                       : make_uint4(0, 0, 0, 0);
+  }
+  for (int blk = wave; blk < LP / 8; blk += 4) {  // 1-KiB pieces: 8 key rows each
+    {
+      const int p = blk * 4 + (lane >> 4), s = lane & 15;
+      const int row = min(2 * p + (s >> 3), L - 1);
+      const int chunk = (s & 7) ^ (p & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + D + chunk * 8),
+                                       (lptr_t)(Ks + blk * 1024), 16, 0, 0);
+    }
+    {
+      const int row = blk * 8 + (lane >> 3), pc = lane & 7;
+      const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);  // logical 16-B chunk of this slot
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)min(row, L - 1) * rs + 2 * D + lc * 8),
+                                       (lptr_t)(Vs + blk * 1024), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = ktile_off(fr, kk * 4 + g);
+  // V^T fragment of key tile t, dims [16 dt, 16 dt + 16): this lane reads 4 dims of key 16 t + 4 g + fr/4.
+  // (key >> 1) & 3 = (2 g + (fr >> 3)) & 3 for every t, so the swizzle is a per-lane constant.
+  const char* vlane[4];
+  {
+    const int sw = (2 * g + (fr >> 3)) & 3;
+    const char* vb = Vs + (4 * g + (fr >> 2)) * 128 + (fr & 3) * 8;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vlane[dt] = vb + ((dt ^ sw) << 5);
+  }
+  constexpr float SC = 0.125f * 1.4426950408889634f;  // scale * log2(e)
+
+#pragma unroll
+  for (int i = 0; i < MAXQB; ++i) {
+    const int qb = wave + 4 * i;
+    if (qb >= nqb) break;
+    const int q = qb * 16 + fr;
+    const uint4 q0 = qf[i][0], q1 = qf[i][1];
+    f32x4_t s[NT];
+    uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint4 k0 = kn0, k1 = kn1;
+      if (t + 1 < NT) {
+        kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
+        kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
+      }
+      s[t] = mfma_keep<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+      s[t] = mfma_keep<PREC>(k1, q1, s[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bool full = (t * 16 + 15 < L) && (!CAUSAL || t * 16 + 15 <= qb * 16);
+      if (!full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 16 + g * 4 + r;
+          const bool ok = key < L && (!CAUSAL || key <= q);
+          s[t][r] = ok ? s[t][r] : -INFINITY;
+        }
+      }
+      m = fmaxf(fmaxf(fmaxf(fmaxf(m, s[t][0]), s[t][1]), s[t][2]), s[t][3]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msc = m * SC;
+    // P = exp2(s*SC - m*SC) in MFMA operand order; the row sum is taken on the matrix pipe below
+    uint2 pt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], SC, -msc));
+      pt[t] = make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
+    }
+    // key step u: tiles 2u, 2u+1 (the last step of an odd tile count has a zero upper half).  Kept a macro:
+    // through a lambda the (never taken) pt[NT] index of the last step sent the whole array to scratch.
+#define MCM_PSTEP(u)                                                                             \
+  ((2 * (u) + 1 < NT) ? make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
+                                   pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
+                      : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
+    constexpr int NS = (NT + 1) / 2;
+    const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t lacc = zero;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), MCM_PSTEP(u), lacc);
+    // O^T = V^T · P^T, 16 dims at a time
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      o[dt] = zero;
+      const char* vp = vlane[dt];
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const uint2 lo = tr_read16(vp + (2 * u) * 2048);
+        const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
+        o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), MCM_PSTEP(u), o[dt]);
+      }
+    }
+#undef MCM_PSTEP
+    const float rl = 1.0f / lacc[0];
+    if (q < L) {
+      uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
+        pk.y = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
+        *(uint2*)(orow + dt * 16) = pk;
+      }
+    }
+  }
+}
+
 // ---- fp32 parity arm -------------------------------------------------------------------
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv,
@@ -284,12 +481,55 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
   return hipGetLastError();
 }
 
+template <int PREC, int NT>
+hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
+                     hipStream_t s, int rev) {
+  constexpr int lds = NT * 16 * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (causal)
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true>), dim3(nseq * heads), dim3(256), lds, s,
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
+  else
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false>), dim3(nseq * heads), dim3(256), lds, s,
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
+  return hipGetLastError();
+}
+
+template <int PREC>
+hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
+                              hipStream_t s, int rev) {
+  const int nt = (L + 15) / 16;
+#define MCM_TR(N) \
+  if (nt <= N) return launch_tr<PREC, N>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
+  MCM_TR(1); MCM_TR(2); MCM_TR(3); MCM_TR(4); MCM_TR(5); MCM_TR(6); MCM_TR(8); MCM_TR(10); MCM_TR(13); MCM_TR(17);
+  MCM_TR(18);
+#undef MCM_TR
+  return hipErrorInvalidValue;
+}
+int g_attn_variant = 1;  // 1 = attn_tr_kernel (round 2), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
+
 }  // namespace
+
+void attention_set_variant(int v) { g_attn_variant = v; }
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
                             bool causal, int qrows, hipStream_t s, bool reverse) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
+  if (prec != MCM_PREC_F32 && g_attn_variant == 1) {
+    if (prec == MCM_PREC_F16)
+      return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
+    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
+  }
   if (prec != MCM_PREC_F32) {
 #define MCM_ATTN_BY_LP(P)                                                                      \
   do {                                                                                          \

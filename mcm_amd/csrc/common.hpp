@@ -22,13 +22,15 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(uint16_t h) {
   return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
-// two fp32 → packed bf16x2 (lo in bits 0-15), round-to-nearest-even, in ONE instruction:
-// gfx950's v_cvt_pk_bf16_f32 (no builtin on ROCm 7.2 — guide T12).  The software f2bf above
-// costs ~6 VALU per element and was a large share of every bf16 epilogue.
+// two fp32 → packed bf16x2 (lo in bits 0-15), round-to-nearest-even, in ONE instruction: the vector
+// conversion selects gfx950's v_cvt_pk_bf16_f32 (the software f2bf above costs ~6 VALU per element and
+// was a large share of every bf16 epilogue).  Deliberately NOT inline asm: hipcc inserts no wait states
+// between an asm statement's VALU write and an MFMA that reads the value as an operand.
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
 }
 
 // LDS-DMA, 16 B per lane: lane i's 16 bytes at `gsrc` land at LDS byte address lds_base + 16*i
@@ -130,12 +132,14 @@ struct GemmArgs {
   int np;             // EPI_PATCH: patches per image
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
   int rev;            // persistent kernel: walk the M tiles from the last to the first
+  int stagger;        // persistent 256x256 kernel: start delay in cycles per CU phase group (0 = off)
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
+void gemm_set_stagger(int cycles);
 #endif
 void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
@@ -147,6 +151,8 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
                             bool causal, int qrows, hipStream_t s, bool reverse = false);
+
+void attention_set_variant(int v);  // testing hook: 1 = transpose-read kernel (default), 0 = round-1 kernel
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);

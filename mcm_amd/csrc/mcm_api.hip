@@ -36,6 +36,7 @@ struct LayerW {
 
 struct Tower {
   int D = 0, heads = 0, layers = 0, ff = 0;
+  int prec = MCM_PREC_BF16;  // operand mode of this tower's GEMMs / attention / LayerNorm output
   std::vector<LayerW> L;
 };
 
@@ -159,26 +160,27 @@ bool next_dir(mcm_handle* h) {
   h->flip = !h->flip;
   return h->flip;
 }
-hipError_t gemm(mcm_handle* h, hipStream_t s, int epi, const GemmArgs& a_in) {
+hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs& a_in) {
   GemmArgs a = a_in;
   a.rev = next_dir(h) ? 1 : 0;
   Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);
-  return launch_gemm(h->cfg.precision, epi, a, s);
+  return launch_gemm(prec, epi, a, s);
 }
-hipError_t lnorm(mcm_handle* h, hipStream_t s, const float* x, const float* g, const float* b,
+hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b,
                  void* y, int M, int D, bool out_f32) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
-  return launch_layernorm(h->cfg.precision, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s, 0, 0, next_dir(h));
+  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s, 0, 0, next_dir(h));
 }
-hipError_t attn(mcm_handle* h, hipStream_t s, int nseq, int L, int heads, bool causal, int qrows = 0) {
+hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int heads, bool causal,
+                int qrows = 0) {
   const int q = qrows > 0 ? qrows : L;
   Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)q * L * 64 * (causal ? 0.5 : 1.0));
-  return launch_attention(h->cfg.precision, h->qkv, h->att, nseq, L, heads, causal, qrows, s, next_dir(h));
+  return launch_attention(prec, h->qkv, h->att, nseq, L, heads, causal, qrows, s, next_dir(h));
 }
-hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, const float* x, const float* g, const float* b,
-                         void* y, int M, int D, size_t xs, size_t ys) {
+hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g,
+                         const float* b, void* y, int M, int D, size_t xs, size_t ys) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
-  return launch_layernorm(h->cfg.precision, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys);
+  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys);
 }
 
 // CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place).
@@ -188,52 +190,52 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, const float* x, const flo
 // consumed rows (every op after attention is row-wise), 1/12 less work for a 12-layer tower.
 int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal,
                bool pooled_row0) {
-  const int M = nseq * L, D = t.D;
-  const int es = prec_esize(h->cfg.precision);
+  const int M = nseq * L, D = t.D, P = t.prec;
+  const int es = prec_esize(P);
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
-    HIP_TRY(h, lnorm(h, s, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
     if (!cls) {
       GemmArgs a{};
       a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
       a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
-      HIP_TRY(h, gemm(h, s, EPI_STORE, a));
-      HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal));
+      HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
+      HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal));
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
       kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * D * es; kv.bias = w.bqkv + D;
       kv.out = (char*)h->qkv + (size_t)D * es;
       kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D;
-      HIP_TRY(h, gemm(h, s, EPI_STORE, kv));
+      HIP_TRY(h, gemm(h, s, P, EPI_STORE, kv));
       GemmArgs q{};   // Q of row 0 of every sequence (row stride L*D in, L*3D out)
       q.x = h->ln; q.w = w.wqkv; q.bias = w.bqkv; q.out = h->qkv;
       q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D;
-      HIP_TRY(h, gemm(h, s, EPI_STORE, q));
-      HIP_TRY(h, attn(h, s, nseq, L, t.heads, causal, 1));
+      HIP_TRY(h, gemm(h, s, P, EPI_STORE, q));
+      HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal, 1));
     }
     const int Mr = cls ? nseq : M;            // rows that continue
     const int rs = cls ? L * D : D;           // their stride in x / att
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
     o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
-    HIP_TRY(h, gemm(h, s, EPI_RESID, o));
-    if (!cls) HIP_TRY(h, lnorm(h, s, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
-    else HIP_TRY(h, lnorm_strided(h, s, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
+    HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
+    if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+    else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
     GemmArgs f1{};
     f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
     f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
-    HIP_TRY(h, gemm(h, s, EPI_GELU, f1));
+    HIP_TRY(h, gemm(h, s, P, EPI_GELU, f1));
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
     f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
-    HIP_TRY(h, gemm(h, s, EPI_RESID, f2));
+    HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
   }
   return MCM_OK;
 }
 
 int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s) {
-  const int prec = h->cfg.precision, es = prec_esize(prec), D = t.D, ff = t.ff;
+  const int prec = t.prec, es = prec_esize(prec), D = t.D, ff = t.ff;
   t.L.resize(t.layers);
   for (int l = 0; l < t.layers; ++l) {
     LayerW& w = t.L[l];
@@ -311,8 +313,12 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   const int kreal = 3 * c.patch_size * c.patch_size;
   const int kalign = 128 / es;
   h->kpad = (kreal + kalign - 1) / kalign * kalign;
-  h->vis = Tower{c.v_width, c.v_heads, c.v_layers, c.v_mlp, {}};
-  h->txt = Tower{c.t_width, c.t_heads, c.t_layers, c.t_mlp, {}};
+  // The text tower always runs in exact fp32 (MCM_PREC_F32 kernels), whatever cfg.precision says: the
+  // prompt bank is encoded once per dataset, off the hot loop, and a bank rounded to 16-bit operands
+  // is a FIXED perturbation of every cosine of every image — it shifts AUROC / FPR95 systematically
+  // instead of averaging out.  cfg.precision selects the vision tower's operand mode.
+  h->vis = Tower{c.v_width, c.v_heads, c.v_layers, c.v_mlp, c.precision, {}};
+  h->txt = Tower{c.t_width, c.t_heads, c.t_layers, c.t_mlp, MCM_PREC_F32, {}};
 
   // parameter registry (HF state_dict names)
   add_param(h, "vision_model.embeddings.class_embedding", {c.v_width});
@@ -340,14 +346,17 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   // activation workspace
   const int64_t mv = (int64_t)c.max_batch * h->ntok, mt = c.max_prompt_tokens;
   h->max_rows = mv > mt ? mv : mt;
+  // shared by both towers: vision rows in the operand dtype of cfg.precision, text rows in fp32
+  auto both = [&](int64_t vcols, int64_t tcols) {
+    const size_t a = (size_t)mv * vcols * es, b = (size_t)mt * tcols * sizeof(float);
+    return a > b ? a : b;
+  };
   const int64_t dmax = c.v_width > c.t_width ? c.v_width : c.t_width;
-  const int64_t ffmax = c.v_mlp > c.t_mlp ? c.v_mlp : c.t_mlp;
-  const size_t R = (size_t)h->max_rows;
-  if (!rc) rc = dev_alloc(h, (void**)&h->x, R * dmax * sizeof(float));
-  if (!rc) rc = dev_alloc(h, &h->ln, R * dmax * es);
-  if (!rc) rc = dev_alloc(h, &h->qkv, R * 3 * dmax * es);
-  if (!rc) rc = dev_alloc(h, &h->att, R * dmax * es);
-  h->hbuf_bytes = R * ffmax * es;
+  if (!rc) rc = dev_alloc(h, (void**)&h->x, (size_t)h->max_rows * dmax * sizeof(float));
+  if (!rc) rc = dev_alloc(h, &h->ln, both(c.v_width, c.t_width));
+  if (!rc) rc = dev_alloc(h, &h->qkv, both(3 * (int64_t)c.v_width, 3 * (int64_t)c.t_width));
+  if (!rc) rc = dev_alloc(h, &h->att, both(c.v_width, c.t_width));
+  h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
   if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
@@ -449,13 +458,13 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
   a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
   a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
   a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np;
-  HIP_TRY(h, gemm(h, s, EPI_PATCH, a));
+  HIP_TRY(h, gemm(h, s, c.precision, EPI_PATCH, a));
   {
     Scope sc(h, s, MCM_KC_EMBED, 0.0);
     HIP_TRY(h, launch_cls_rows(h->x, W(h, "vision_model.embeddings.class_embedding"), a.pos, B,
                                h->ntok, D, s));
   }
-  HIP_TRY(h, lnorm(h, s, h->x, W(h, "vision_model.pre_layrnorm.weight"),
+  HIP_TRY(h, lnorm(h, s, c.precision, h->x, W(h, "vision_model.pre_layrnorm.weight"),
                    W(h, "vision_model.pre_layrnorm.bias"), h->x, B * h->ntok, D, true));
   if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true))) return rc;
   {
@@ -741,8 +750,14 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
   return MCM_OK;
 }
 
+int mcm_debug_attention_variant(int32_t variant) {
+  if (variant < 0 || variant > 1) return MCM_EINVAL;
+  attention_set_variant(variant);
+  return MCM_OK;
+}
+
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || variant > 4) return MCM_EINVAL;
+  if (variant < -1 || variant > 6) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }

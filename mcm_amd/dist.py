@@ -65,6 +65,9 @@ def all_gather_scores(local, n_total: int):
     rank, ws = world()
     if ws == 1:
         return local
+    home = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:  # ranks sharing a device (logic checks): host bounce
+        local = local.cpu()
     per = -(-n_total // ws)
     buf = torch.zeros(per, dtype=torch.float32, device=local.device)
     buf[: local.numel()] = local.to(torch.float32)
@@ -74,7 +77,7 @@ def all_gather_scores(local, n_total: int):
     for r in range(ws):
         lo, hi = shard_range(n_total, r, ws)
         parts.append(out[r * per: r * per + (hi - lo)])
-    return torch.cat(parts)
+    return torch.cat(parts).to(home)
 
 
 def all_gather_histograms(local_scores, edges, net=None):
