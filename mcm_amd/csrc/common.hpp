@@ -132,14 +132,12 @@ struct GemmArgs {
   int np;             // EPI_PATCH: patches per image
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
   int rev;            // persistent kernel: walk the M tiles from the last to the first
-  int stagger;        // persistent 256x256 kernel: start delay in cycles per CU phase group (0 = off)
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
-void gemm_set_stagger(int cycles);
 #endif
 void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 

@@ -84,51 +84,6 @@ __device__ __forceinline__ void wave_khalf(const char* xs, const char* ws, int f
       }
   }
 }
-// The same K half with `slot(i)` called after every (32 / SLOTS) MFMAs, i = 0 .. SLOTS-1 (SLOTS = 4 or 8,
-// MF = 8): the persistent 256x256 kernel issues its LDS-DMA refill from these slots, one 1-KiB piece at a
-// time, so that a wave blocked in a DMA issue (70-155 cycles) always has its SIMD partner's MFMAs — and
-// its own next MFMAs queued right behind — instead of eight back-to-back blocked issues.
-template <int PREC, int MF, int SLOTS, typename F>
-__device__ __forceinline__ void wave_khalf_slots(const char* xs, const char* ws, int foff, f32x4_t (&acc)[4][MF],
-                                                 F&& slot) {
-  static_assert(MF == 8 && (SLOTS == 4 || SLOTS == 8 || SLOTS == 0), "256x256 wave tile");
-  uint4 wf[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) wf[f] = *(const uint4*)(ws + f * 2048 + foff);
-#pragma unroll
-  for (int h = 0; h < MF / 4; ++h) {
-    uint4 xf[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) xf[f] = *(const uint4*)(xs + (h * 4 + f) * 2048 + foff);
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-#pragma unroll
-      for (int fq = 0; fq < 4; ++fq) {
-        const int fi = h * 4 + fq;
-        if constexpr (PREC != MCM_PREC_F32) {
-          acc[fj][fi] = mfma16<PREC>(wf[fj], xf[fq], acc[fj][fi]);
-        } else {
-          const f32x4_t wv = __builtin_bit_cast(f32x4_t, wf[fj]);
-          const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[fq]);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[fj][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], acc[fj][fi], 0, 0, 0);
-        }
-      }
-      if constexpr (SLOTS == 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        slot(h * 4 + fj);
-        __builtin_amdgcn_sched_barrier(0);
-      } else if constexpr (SLOTS == 4) {
-        if (fj & 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          slot(h * 2 + (fj >> 1));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-  }
-}
 template <int PREC, int MF>
 __device__ __forceinline__ void wave_kstep(const char* xs, const char* ws, const int (&foff)[2],
                                            f32x4_t (&acc)[4][MF]) {
@@ -641,7 +596,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 
 #define TRACE(k)
 #endif
 
-template <int PREC, int EPI, bool COUNT_STORES, int SCHED = 0>
+template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   using namespace p256;
   enter_precision_mode<PREC>();
@@ -742,15 +697,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // De-phasing.  Identical work per tile keeps all CUs in lockstep, so every CU's epilogue stores hit
-  // the fabric in the same ~8000 cycles of a ~48000-cycle tile and the matrix pipes wait for the drain.
-  // The CUs of an XCD start in four phase groups `stagger` cycles apart (the last group is the one
-  // holding the CUs with one tile less), which spreads the store bursts over the tile time.
-  if (a.stagger > 0) {
-    const uint64_t wait = (uint64_t)((jx * 4) / G8) * (uint64_t)a.stagger;
-    const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   cursor_init(ci);
   set_issue_tile();
   issue(0);
@@ -780,57 +726,20 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
     // priority 1) compute the first K half, refill, compute the second.
     const bool refill = issued < total;
+    if (refill && !late && !DBG(1)) issue(issued & 1);
+    TRACE(3);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
-    if constexpr (SCHED == 0) {
-      if (refill && !late && !DBG(1)) issue(issued & 1);
-      TRACE(3);
-      if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
-      TRACE(4);
-      if (refill && late && !DBG(1)) issue(issued & 1);
-      if (refill) ++issued;
-      TRACE(5);
-      if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
-      TRACE(6);
-    } else {
-      // refill issued one piece at a time from slots between the MFMAs.  SCHED 1: every wave puts its 8
-      // pieces into the 8 slots of the first K half.  SCHED 2: waves 0-3 do that, waves 4-7 use 4 slots in
-      // each half (their pieces start later, so the two waves of a SIMD are not blocked at the same time).
-      const uint32_t ibase = lds0 + (issued & 1) * STAGE_BYTES;
-      const size_t ko = (size_t)kti * ROWB;
-      auto piece = [&](int i) {
-        if (!refill || DBG(1)) return;
-        if (i < 4) glds16(gx[i] + ko, __builtin_amdgcn_readfirstlane(ibase + (i * 8 + wave) * 1024));
-        else glds16(gw[i - 4] + ko, __builtin_amdgcn_readfirstlane(ibase + A_BYTES + ((i - 4) * 8 + wave) * 1024));
-      };
-      TRACE(3);
-      if (SCHED == 1 || !late) {
-        wave_khalf_slots<PREC, 8, 8>(sb + xbase, sb + wbase, foff[0], acc, [&](int i) { piece(((i & 1) << 2) | (i >> 1)); });
-        TRACE(4);
-        TRACE(5);
-        wave_khalf_slots<PREC, 8, 0>(sb + xbase, sb + wbase, foff[1], acc, [&](int) {});
-      } else {
-        wave_khalf_slots<PREC, 8, 4>(sb + xbase, sb + wbase, foff[0], acc, [&](int i) { piece(i); piece(i + 4); });
-        TRACE(4);
-        TRACE(5);
-        wave_khalf_slots<PREC, 8, 0>(sb + xbase, sb + wbase, foff[1], acc, [&](int) {});
-      }
-      TRACE(6);
-      if (refill) {
-        if (++kti == nk) {
-          kti = 0;
-          if (++ji < ntl) {
-            cursor_next(ci, ji);
-            set_issue_tile();
-          }
-        }
-        ++issued;
-      }
-    }
+    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
+    TRACE(4);
+    if (refill && late && !DBG(1)) issue(issued & 1);
+    if (refill) ++issued;
+    TRACE(5);
+    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
+    TRACE(6);
     if (++ktc == nk) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (DBG(32) && late) __builtin_amdgcn_s_setprio(0);  // harness: equal VALU priority in the epilogue
       if (!DBG(4)) {
         // dbg 8 (harness only): fold every tile's stores onto a 64-tile region that stays in L2
         const int em0 = DBG(8) ? (int)(blockIdx.x & 63) * BM : cm0;
@@ -838,7 +747,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
         wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
                                         smem + 2 * STAGE_BYTES + wave * 4096);
       }
-      if (DBG(32) && late) __builtin_amdgcn_s_setprio(1);
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
       ktc = 0;
@@ -898,16 +806,16 @@ hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool CS, int SCHED = 0>
+template <int PREC, int EPI, bool CS>
 hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS, SCHED>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS, SCHED>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -926,9 +834,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
   if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
   if (v == 3) return launch_p256<PREC, EPI, false>(a, s);
-  if (v == 4) return launch_p256<PREC, EPI, true>(a, s);
-  if (v == 5) return launch_p256<PREC, EPI, false, 1>(a, s);
-  return launch_p256<PREC, EPI, false, 2>(a, s);
+  return launch_p256<PREC, EPI, true>(a, s);
 }
 
 template <int PREC>
@@ -949,12 +855,10 @@ void gemm_set_variant(int v) { g_variant = v; }
 #ifdef MCM_HARNESS
 int g_group_n = 0;  // 0 = heuristic
 int g_dbg = 0;
-int g_stagger = -1;  // -1 = the launcher's default
 void gemm_set_dbg(int d) { g_dbg = d; }
 void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
-void gemm_set_stagger(int cycles) { g_stagger = cycles; }
 #else
-constexpr int g_group_n = 0, g_dbg = 0, g_stagger = -1;
+constexpr int g_group_n = 0, g_dbg = 0;
 #endif
 
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
@@ -969,7 +873,6 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
     a.gn = g_group_n > 0 ? g_group_n : nbn;
   }
   a.dbg = g_dbg;
-  if (g_stagger >= 0) a.stagger = g_stagger;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)
     return hipErrorInvalidValue;

@@ -245,3 +245,149 @@ def test_score_kinds(tiny_net, K, T):
         got = tiny_net.score_features(_dev(img), _dev(txt), T, name).cpu().numpy()
         tol = dict(rtol=3e-5, atol=1e-6) if name != "var" else dict(rtol=2e-3, atol=1e-10)
         np.testing.assert_allclose(got, want, err_msg=f"{name} K={K} T={T}", **tol)
+
+
+ATTN_MORE = [(2, 65, 2, False), (2, 80, 2, False), (2, 96, 2, False), (2, 112, 2, False), (3, 40, 2, True),
+             (2, 128, 2, True), (1, 288, 1, False), (2, 1, 2, False)]
+
+
+@pytest.mark.parametrize("nseq,L,heads,causal", ATTN_MORE)
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_attention_every_tile_count(tiny_net, nseq, L, heads, causal, prec):
+    """The transpose-read kernel is instantiated per key-tile count (1 .. 18 tiles of 16 keys); odd counts
+    end with a half-empty key step.  Both 16-bit modes, the round-2 kernel AND the round-1 kernel (A/B arm),
+    against the oracle."""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(L * 7 + heads)
+    D = heads * 64
+    qkv = rng.standard_normal((nseq * L, 3 * D)).astype(np.float32)
+    qkv[:, :2 * D] *= 1.5
+    qkv = _round_to(qkv, prec)
+    want = orc.attention(qkv, nseq, L, heads, 64, causal)
+    dt = DTYPE[prec]
+    qd = _dev(qkv, dt)
+    tol = 2e-2 if prec == "bf16" else 3e-3
+    lib = tiny_net._lib
+    try:
+        for variant in (1, 0):
+            assert lib.mcm_debug_attention_variant(variant) == 0
+            out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
+            rc = lib.mcm_op_attention(tiny_net._h, PREC[prec], _ptr(qd), _ptr(out), nseq, L, heads, int(causal), None)
+            assert rc == 0, lib.mcm_last_error(tiny_net._h)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=tol, atol=tol,
+                                       err_msg=f"variant {variant}")
+    finally:
+        lib.mcm_debug_attention_variant(1)
+
+
+def test_attention_full_size_bitwise_repeatable(tiny_net):
+    """B/16 batch 512 (6144 workgroups, 3 per CU): three launches bit-identical, and equal to the same
+    sequences run as a small launch (a timing-dependent fault shows up as a differing workgroup)."""
+    nseq, L, heads = 512, 197, 12
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = (torch.randn((nseq * L, 3 * D), device="cuda", generator=g) * 1.3).to(torch.float16)
+    outs = []
+    for _ in range(3):
+        out = torch.zeros((nseq * L, D), device="cuda", dtype=torch.float16)
+        rc = tiny_net._lib.mcm_op_attention(tiny_net._h, 2, _ptr(qkv), _ptr(out), nseq, L, heads, 0, None)
+        assert rc == 0
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    small = torch.zeros((7 * L, D), device="cuda", dtype=torch.float16)
+    rc = tiny_net._lib.mcm_op_attention(tiny_net._h, 2, _ptr(qkv[100 * L:107 * L].contiguous()), _ptr(small), 7, L,
+                                        heads, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(small, outs[0][100 * L:107 * L])
+
+
+@pytest.mark.parametrize("epi", [0, 1])
+def test_fp16_outputs_saturate_instead_of_overflowing(tiny_net, epi):
+    """MODE.FP16_OVFL: a QKV / QuickGELU output beyond the fp16 range is stored as +-65504, not +-inf (an inf
+    would turn the whole row into NaN at the next LayerNorm).  In-range outputs are untouched."""
+    from oracle import oracle as orc
+
+    M, N, K = 70, 128, 64
+    rng = np.random.default_rng(1)
+    x = _round_to(rng.standard_normal((M, K)), "fp16")
+    w = _round_to(rng.standard_normal((N, K)) * 0.1, "fp16")
+    b = np.zeros(N, np.float32)
+    x[3, :] = 200.0
+    w[5, :] = 60.0      # row 3 x col 5: 200*60*64 = 768000 > 65504
+    w[6, :] = -60.0     # and -768000 (QuickGELU maps it to ~0)
+    want = orc.linear(x, w, b)
+    if epi == 1:
+        want = want / (1.0 + np.exp(-1.702 * want.astype(np.float64)))
+    y = torch.zeros((M, N), device="cuda", dtype=torch.float16)
+    rc = tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(_dev(x, torch.float16)), _ptr(_dev(w, torch.float16)),
+                                     _ptr(_dev(b)), _ptr(y), None, M, N, K, epi, None)
+    assert rc == 0
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert got[3, 5] == 65504.0
+    if epi == 0:
+        assert got[3, 6] == -65504.0
+    ok = np.abs(want) < 6e4
+    np.testing.assert_allclose(got[ok], np.asarray(want, np.float32)[ok], rtol=2e-3, atol=2e-3)
+
+
+def test_fp16_layernorm_and_attention_saturate(tiny_net):
+    lib = tiny_net._lib
+    x = torch.zeros((8, 128), device="cuda")
+    x[:, 0] = 1.0
+    gamma = torch.full((128,), 3e4, device="cuda")   # (x - mean) / std ~ 11.3 at column 0 -> 3.4e5
+    beta = torch.zeros(128, device="cuda")
+    y = torch.zeros((8, 128), device="cuda", dtype=torch.float16)
+    assert lib.mcm_op_layernorm(tiny_net._h, 2, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), 8, 128, 1e-5, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and float(y[0, 0]) == 65504.0
+
+
+@pytest.mark.parametrize("P,geo_name", [(512, "ViT-B/16"), (768, "ViT-L/14")])
+@pytest.mark.parametrize("K", [1000, 37])
+def test_score_kinds_full_projection_dims(P, geo_name, K):
+    """The scoring tail at the projection widths of the real checkpoints (512 for B/16 and B/32, 768 for
+    L/14) and K = 1000, all five --score kinds, against the oracle (test_score_kinds covers the tiny P)."""
+    import dataclasses
+
+    from mcm_amd.config import SCORE_KINDS, geometry
+    from mcm_amd.engine import NativeCLIP
+    from mcm_amd.weights import synth_state_dict
+    from oracle import oracle as orc
+
+    geo = dataclasses.replace(geometry("tiny"), name=f"tiny-P{P}", proj_dim=P)
+    net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="fp16", max_batch=8, max_prompt_tokens=256)
+    try:
+        rng = np.random.default_rng(K + P)
+        B = 41
+        img = rng.standard_normal((B, P)).astype(np.float32)
+        img /= np.linalg.norm(img, axis=1, keepdims=True)
+        txt = rng.standard_normal((K, P)).astype(np.float32)
+        txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+        for T in (1.0, 0.05):
+            for name, kind in SCORE_KINDS.items():
+                want = orc.score_features(img, txt, T, kind)
+                got = net.score_features(_dev(img), _dev(txt), T, name).cpu().numpy()
+                tol = dict(rtol=3e-5, atol=1e-6) if name != "var" else dict(rtol=2e-3, atol=1e-10)
+                np.testing.assert_allclose(got, want, err_msg=f"{name} K={K} T={T} P={P}", **tol)
+        with pytest.raises(ValueError):   # a bank of the wrong width is refused, not read out of bounds
+            net.score_features(_dev(img), _dev(txt[:, : P // 2].copy()), 1.0, "MCM")
+        with pytest.raises(ValueError):
+            net.score_images(torch.zeros((1, 3, geo.image_size, geo.image_size), device="cuda"),
+                             _dev(txt[:, : P // 2].copy()))
+    finally:
+        net.close()
+
+
+def test_device_histogram_matches_numpy(tiny_net):
+    rng = np.random.default_rng(9)
+    s = rng.standard_normal(50001).astype(np.float32)
+    edges = np.linspace(-3, 3, 257).astype(np.float32)
+    s[:5] = [edges[0], edges[-1], edges[7], -3.5, 9.0]      # edge values and out-of-range scores
+    got = tiny_net.histogram(_dev(s), edges).cpu().numpy()
+    want = np.histogram(s, bins=edges)[0]
+    assert got.dtype == np.int64 and np.array_equal(got, want)

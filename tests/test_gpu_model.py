@@ -144,16 +144,19 @@ def _auroc_case(name, K, n, precisions):
     txt_o = o.encode_text(ids)
     px_in, _ = make_pixels(n, geo.image_size, K, ood=False, seed=1)
     px_out, _ = make_pixels(n, geo.image_size, K, ood=True, seed=1)
-    want_in = orc.score_features(o.encode_image(px_in), txt_o, 1.0, 0)
-    want_out = orc.score_features(o.encode_image(px_out), txt_o, 1.0, 0)
+    enc = lambda px: np.concatenate([o.encode_image(px[i:i + 2048]) for i in range(0, n, 2048)])  # noqa: E731
+    want_in = orc.score_features(enc(px_in), txt_o, 1.0, 0)
+    want_out = orc.score_features(enc(px_out), txt_o, 1.0, 0)
     want = np.array(get_measures(-want_in, -want_out))
     report = {}
     for precision in precisions:
         net = _net(name, precision, max_batch=256, max_prompt_tokens=2048)
         try:
             txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
-            s_in = net.score_images(torch.from_numpy(px_in).cuda(), txt, 1.0, "MCM").cpu().numpy()
-            s_out = net.score_images(torch.from_numpy(px_out).cuda(), txt, 1.0, "MCM").cpu().numpy()
+            s_in = np.concatenate([net.score_images(torch.from_numpy(px_in[i:i + 4096]).cuda(), txt, 1.0, "MCM")
+                                   .cpu().numpy() for i in range(0, n, 4096)])
+            s_out = np.concatenate([net.score_images(torch.from_numpy(px_out[i:i + 4096]).cuda(), txt, 1.0, "MCM")
+                                    .cpu().numpy() for i in range(0, n, 4096)])
         finally:
             net.close()
         got = np.array(get_measures(-s_in, -s_out))
@@ -163,16 +166,17 @@ def _auroc_case(name, K, n, precisions):
 
 
 def test_auroc_parity_vs_oracle_large_sample():
-    """North-star bar |ΔAUROC|, |ΔFPR95| ≤ 1e-4 vs the fp32 oracle, on a sample large enough
-    that 1e-4 is above the metric quantum (tiny geometry: 2x1500 images, oracle in seconds)."""
-    rep = _auroc_case("tiny", K=20, n=1500, precisions=("fp32", "bf16", "fp16"))
-    print("tiny n=1500:", rep)
+    """North-star bar |ΔAUROC|, |ΔAUPR|, |ΔFPR95| ≤ 1e-4 vs the fp32 ORACLE (CPU), on a sample large enough that
+    1e-4 is above the metric quantum of every metric (tiny geometry, 2 x 20 000 images: FPR95 moves in steps
+    of 5e-5).  fp32 mode and fp16 mode (the benchmarked dtype) are held to the bar; bf16 is the documented
+    coarser arm and is bounded so a regression shows."""
+    rep = _auroc_case("tiny", K=20, n=20000, precisions=("fp32", "fp16", "bf16"))
+    print("tiny n=20000:", rep)
     assert 0.05 < rep["fp32"]["oracle"][0] < 0.95  # non-degenerate AUROC
     assert rep["fp32"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
+    assert rep["fp16"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
     d = rep["bf16"]["d_auroc_aupr_fpr"]
     assert d[0] <= 1e-3 and d[2] <= 5e-3, rep  # bf16 operands: measured drift, see DESIGN.md
-    d = rep["fp16"]["d_auroc_aupr_fpr"]
-    assert d[0] <= 3e-4 and d[2] <= 2e-3, rep  # fp16 operands: 8x finer rounding than bf16
 
 
 def test_auroc_parity_vs_oracle_b16_2l():

@@ -1,8 +1,7 @@
 // gemm_bench.hip — standalone A/B harness for the GEMM kernels of mcm_amd/csrc/gemm.hip.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMCM_HARNESS [-DMCM_GEMM_TRACE] -I mcm_amd/csrc tools/gemm_bench.hip \
 //        mcm_amd/csrc/gemm.hip -o /tmp/gemm_bench
-// Run:   gemm_bench M N K epi [iters [gn [dbg [trace_variant [stagger_cycles [variant_mask]]]]]]
-//        → per-variant time / TFLOP/s, max |diff| vs variant 0
+// Run:   gemm_bench M N K epi [iters]   → per-variant time / TFLOP/s, max |diff| vs variant 0
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -43,7 +42,6 @@ int main(int argc, char** argv) {
             iters = argc > 5 ? atoi(argv[5]) : 20;
   if (argc > 6) gemm_set_group_n(atoi(argv[6]));
   if (argc > 7) gemm_set_dbg(atoi(argv[7]));
-  if (argc > 9) gemm_set_stagger(atoi(argv[9]));
   setvbuf(stdout, NULL, _IONBF, 0);
   printf("M=%d N=%d K=%d epi=%d\n", M, N, K, epi);
   uint64_t seed = 1;
@@ -73,12 +71,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int nvar = 7;
-  const int vmask = argc > 10 ? atoi(argv[10]) : 127;  // bit v = run variant v (variant 0 is the reference)
+  const int nvar = 5;
   double best[nvar] = {0};
   for (int round = 0; round < 3; ++round)
     for (int v = 0; v < nvar; ++v) {
-      if (v && !((vmask >> v) & 1)) continue;
       gemm_set_variant(v);
       if (round == 0) {  // correctness pass
         CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
