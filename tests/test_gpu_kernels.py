@@ -323,9 +323,10 @@ def test_fp16_outputs_saturate_instead_of_overflowing(tiny_net, epi):
     if epi == 1:
         want = want / (1.0 + np.exp(-1.702 * want.astype(np.float64)))
     y = torch.zeros((M, N), device="cuda", dtype=torch.float16)
-    rc = tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(_dev(x, torch.float16)), _ptr(_dev(w, torch.float16)),
-                                     _ptr(_dev(b)), _ptr(y), None, M, N, K, epi, None)
+    xd, wd, bd = _dev(x, torch.float16), _dev(w, torch.float16), _dev(b)   # keep the operands alive
+    rc = tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), None, M, N, K, epi, None)
     assert rc == 0
+    torch.cuda.synchronize()
     got = y.float().cpu().numpy()
     assert np.isfinite(got).all()
     assert got[3, 5] == 65504.0

@@ -98,7 +98,7 @@ def test_checkpoint_file_round_trip(tmp_path, fmt):
 
     geo = geometry("tiny")
     sd = synth_state_dict(geo, 3)
-    extra = {"logit_scale": np.float32(4.6052) * np.ones((), np.float32),
+    extra = {"logit_scale": np.full((1,), 4.6052, dtype=np.float32),
              "text_model.embeddings.position_ids": np.arange(77, dtype=np.int64)[None]}
     path = str(tmp_path / ("ckpt.safetensors" if fmt == "safetensors" else "ckpt.pt"))
     if fmt == "safetensors":

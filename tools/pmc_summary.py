@@ -21,10 +21,28 @@ def main():
             key = short(r["Kernel_Name"])
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     names = sorted({c for v in agg.values() for c in v})
-    print(f"{'kernel':50s} {'launches':>8s} " + " ".join(f"{n:>22s}" for n in names))
+    derived = []
+    if {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"} <= set(names):
+        derived.append("MFMA_BUSY_%")      # busy cycles summed over SIMDs / (4 SIMD x 256 CU x kernel cycles)
+    if {"SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"} <= set(names):
+        derived.append("LDS_CONFLICT_%")   # extra LDS-array cycles / all LDS-array cycles
+    print(f"{'kernel':50s} {'launches':>8s} " + " ".join(f"{n:>22s}" for n in names + derived))
     for k, v in sorted(agg.items()):
         n = max(len(x) for x in v.values())
-        print(f"{k:50s} {n:8d} " + " ".join(f"{(sum(v[c]) / len(v[c]) if v.get(c) else float('nan')):22.4g}" for c in names))
+        mean = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in names}
+        extra = []
+        for d in derived:
+            if d == "MFMA_BUSY_%":
+                g = mean["GRBM_GUI_ACTIVE"]
+                extra.append(100.0 * mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * g) if g else float("nan"))
+            else:
+                a = mean["SQ_LDS_IDX_ACTIVE"]
+                extra.append(100.0 * mean["SQ_LDS_BANK_CONFLICT"] / a if a else 0.0)
+        print(f"{k:50s} {n:8d} " + " ".join(f"{mean[c]:22.4g}" for c in names) + " " +
+              " ".join(f"{x:22.2f}" for x in extra))
+    if derived:
+        print("# MFMA_BUSY_% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE); "
+              "LDS_CONFLICT_% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (means per launch)")
 
 
 if __name__ == "__main__":
