@@ -1,4 +1,3 @@
 set -x
-mkdir -p gpurun_out/r2f
-timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/r2f/pytest.txt 2>&1
-tail -30 gpurun_out/r2f/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_round2.py -m gpu -q -k "large_sample or round_trip" 2>&1 | tail -8
+bash tools/profile.sh r02_a

@@ -10,9 +10,22 @@ import json
 import sys
 
 
+def rows(path):
+    """(kernel name, counter name, value) per dispatch from a rocprofv3 counter_collection CSV or from the
+    rocpd SQLite database rocprofv3 7.2 writes by default (view `counters_collection`)."""
+    if path.endswith(".db"):
+        import sqlite3
+
+        db = sqlite3.connect(path)
+        for name, cname, val in db.execute("select kernel_name, counter_name, value from counters_collection"):
+            yield {"Kernel_Name": name, "Counter_Name": cname, "Counter_Value": val}
+    else:
+        yield from csv.DictReader(open(path))
+
+
 def family(name):
-    if "gemm_" in name:
-        return "gemm"
+    if "gemm_" in name:  # <1, ...> = exact-fp32 kernels: the text tower's one pass, not the vision step
+        return "gemm_fp32_text_tower" if "_kernel<1," in name else "gemm"
     for k in ("attn", "layernorm", "patchify", "score", "pool_project"):
         if k in name:
             return k
@@ -21,7 +34,7 @@ def family(name):
 
 def mean_by_family(path, counter):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    for r in rows(path):
         f = family(r["Kernel_Name"])
         if f and r["Counter_Name"] == counter:
             acc[f].append(float(r["Counter_Value"]))
