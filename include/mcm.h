@@ -270,26 +270,6 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
                      int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
                      void* stream);
 
-/* LayerNorm folded into the GEMMs around it (16-bit modes; what a handle with a >= 16384-row workspace runs
- * for 21 of the 25 LayerNorms of a B/16 tower — modeling_clip.py:370,379 between :333 / :349 and :309-311 /
- * :347).  Exposed so each piece can be pinned against the oracle:
- *   mcm_op_resid_ln       resid[M,N] (fp32) += x·w^T + bias  as epilogue 2, plus in the same pass
- *                         xg[M,N] (operand dtype) = resid * gamma and the row statistics
- *                         rowab[M][2] = (rstd, rstd * mean) of the UPDATED resid rows (stats_dev [M][N/64][2]
- *                         is scratch);
- *   mcm_op_ln_fold        colsum[n] = sum_k gamma[k] w[n,k], bias2[n] = bias[n] + sum_k beta[k] w[n,k] for the
- *                         consumer weight w (operand dtype);
- *   mcm_op_linear_folded  y[M,N] = rstd_m * (xg·w^T)[m,n] - (rstd_m mean_m) * colsum[n] + bias2[n]  (+ QuickGELU
- *                         when gelu != 0)  ==  LayerNorm(resid; gamma, beta) · w^T + bias  [QuickGELU]. */
-int mcm_op_resid_ln(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev, const float* bias_dev,
-                    float* resid_dev, const float* gamma_dev, void* xg_dev, float* stats_dev, float* rowab_dev,
-                    int32_t M, int32_t N, int32_t K, float eps, void* stream);
-int mcm_op_ln_fold(mcm_handle* h, int32_t prec, const void* w_dev, const float* gamma_dev, const float* beta_dev,
-                   const float* bias_dev, int32_t N, int32_t K, float* colsum_dev, float* bias2_dev, void* stream);
-int mcm_op_linear_folded(mcm_handle* h, int32_t prec, const void* xg_dev, const float* rowab_dev, const void* w_dev,
-                         const float* colsum_dev, const float* bias2_dev, void* y_dev, int32_t M, int32_t N,
-                         int32_t K, int32_t gelu, void* stream);
-
 /* Testing hook: force the GEMM kernel variant (-1 auto [default], 0 = 128x128 tile kernel,
  * 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 3/4 = persistent 256x256
  * 2-stage (4: counted epilogue stores)).  Process-wide.

@@ -156,8 +156,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 #endif
-void gemm_set_variant(int v);
-bool gemm_persistent_available();  // the device has >= 8 CUs for the persistent kernels  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
+void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
 // layernorm.hip: the two small kernels of the folded LayerNorm (see EPI_RESID_LN)
 hipError_t launch_ln_stats_finalize(const float* stats, int npart, int M, int D, float eps, float* rowab,

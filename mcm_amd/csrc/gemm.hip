@@ -168,10 +168,10 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
 }
 
 // per-lane extras of the folded-LayerNorm epilogues (unused, and optimised away, for the others)
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct LnRegs {
-  f32x4_t sv[4];    // consumer: colsum of this lane's 16 columns
-  f32x2_t rab[8];   // consumer: (rstd, rstd * mean) of row (unit u, fr)
+  f32x4_t sv[4];   // consumer: colsum of this lane's 16 columns
+  float ra[8];     // consumer: rstd of row (unit u, fr)
+  float rb[8];     // consumer: rstd * mean
 };
 constexpr bool epi_out16(int epi) { return epi == EPI_STORE || epi == EPI_GELU || epi == EPI_STORE_LN || epi == EPI_GELU_LN; }
 constexpr bool epi_gelu(int epi) { return epi == EPI_GELU || epi == EPI_GELU_LN; }
@@ -204,7 +204,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         if constexpr (epi_ln_consumer(EPI)) {
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            v[fj][t] = fmaf(ln.rab[u][0], acc[fj][u][t], fmaf(-ln.rab[u][1], ln.sv[fj][t], bv[fj][t]));
+            v[fj][t] = fmaf(ln.ra[u], acc[fj][u][t], fmaf(-ln.rb[u], ln.sv[fj][t], bv[fj][t]));
         } else {
           v[fj] = acc[fj][u] + bv[fj];
         }
@@ -280,10 +280,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         } else {
           ptr = row_ptr(c, t, ok);
         }
-        if constexpr (EPI == EPI_RESID_LN)  // read once, overwritten below, not needed by a LayerNorm kernel: stream it
-          rnext[t] = ok ? __builtin_nontemporal_load((const f32x4_t*)ptr) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        else
-          rnext[t] = ok ? *(const f32x4_t*)ptr : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        rnext[t] = ok ? *(const f32x4_t*)ptr : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
     };
     constexpr bool ADD = (EPI == EPI_RESID || EPI == EPI_PATCH || EPI == EPI_RESID_LN);
@@ -321,14 +318,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         if constexpr (ADD) v += r[t];
         bool ok;
         float* dst = row_ptr(c, t, ok);
-        if constexpr (EPI == EPI_RESID_LN) {
-          // with the LayerNorm folded nobody re-reads these fp32 rows before the NEXT residual GEMM: stream
-          // them, so that they do not push xg — the next GEMM's A operand, written right below — out of the
-          // Infinity Cache (as plain stores they did, and cost that GEMM ~30 us of HBM reads)
-          if (ok) store16_stream(dst, v);
-        } else {
-          if (ok) *(f32x4_t*)dst = v;  // fp32 / residual rows: streaming them measured no gain
-        }
+        if (ok) *(f32x4_t*)dst = v;  // fp32 / residual rows: streaming them measured no gain
         if constexpr (EPI == EPI_RESID_LN) {
           if (ok) {
             const int m = mw + c * 16 + t * 4 + rrow;
@@ -673,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 8 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && epi_out16(EPI)) ? 16 : 32;
+  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 16 : 32;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
 
@@ -766,13 +756,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   f32x4_t bv[4];
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  LnRegs ln;  // folded-LayerNorm consumer epilogues only (dead code otherwise)
-  if constexpr (epi_ln_consumer(EPI)) {
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) ln.sv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 8; ++u) ln.rab[u] = (f32x2_t){0.f, 0.f};
-  }
 
   cursor_init(ci);
   set_issue_tile();
@@ -817,32 +800,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if constexpr (epi_ln_consumer(EPI)) {
-        // the tile's LayerNorm terms: colsum of this lane's 16 columns and (rstd, rstd * mean) of the 8 rows
-        // (one per 16-row unit) it converts.  Loaded HERE, not at the tile's first step like the bias: 32
-        // more registers live across the K-loop made hipcc shorten its fragment prefetch and cost the
-        // K-loop 13-15 %; one exposed L2 round trip per tile is the cheaper price.
-        const float* cs = a.colsum + min(cn0 + wc * 64 + g * 16, a.N - 16);
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ln.sv[fj]) : "v"(cs + fj * 4) : "memory");
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float* rp = a.rowab + 2 * (size_t)min(cm0 + wr * 128 + u * 16 + fr, a.M - 1);
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ln.rab[u]) : "v"(rp) : "memory");
-        }
-        wait_vmcnt<0>();
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(ln.sv[fj]));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(ln.rab[u]));
-      }
       if (!DBG(4)) {
         // dbg 8 (harness only): fold every tile's stores onto a 64-tile region that stays in L2
         const int em0 = DBG(8) ? (int)(blockIdx.x & 63) * BM : cm0;
         const int en0 = DBG(8) ? 0 : cn0;
         wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
-                                        smem + 2 * STAGE_BYTES + wave * 4096, ln);
+                                        smem + 2 * STAGE_BYTES + wave * 4096);
       }
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
@@ -941,16 +904,6 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_GELU: return launch_one<PREC, EPI_GELU>(a, s);
     case EPI_RESID: return launch_one<PREC, EPI_RESID>(a, s);
     case EPI_PATCH: return launch_one<PREC, EPI_PATCH>(a, s);
-    default: break;
-  }
-  if constexpr (PREC != MCM_PREC_F32) {  // folded-LayerNorm epilogues: persistent 256x256 kernel only
-    if (persistent_grid() < 8) return hipErrorInvalidValue;
-    switch (epi) {
-      case EPI_RESID_LN: return launch_p256<PREC, EPI_RESID_LN, false>(a, s);
-      case EPI_STORE_LN: return launch_p256<PREC, EPI_STORE_LN, false>(a, s);
-      case EPI_GELU_LN: return launch_p256<PREC, EPI_GELU_LN, false>(a, s);
-      default: break;
-    }
   }
   return hipErrorInvalidValue;
 }
@@ -958,7 +911,6 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 void gemm_set_variant(int v) { g_variant = v; }
-bool gemm_persistent_available() { return persistent_grid() >= 8; }
 
 #ifdef MCM_HARNESS
 int g_group_n = 0;  // 0 = heuristic

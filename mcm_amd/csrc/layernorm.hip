@@ -74,77 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
   }
 }
 
-// ---- folded LayerNorm (common.hpp, EPI_RESID_LN): row statistics from the producer's partial sums ------
-// stats[M][npart][2] = (sum x, sum x^2) over 64-column slices  ->  rowab[M][2] = (rstd, rstd * mean).
-// Partials are fp32 sums of 64 fp32 terms; they are combined in fp64, so the variance's mean^2 subtraction
-// loses nothing beyond the partials' own rounding (relative 1e-7, against 5e-4 operand rounding).
-__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ stats, int npart, int M,
-                                                                int D, float eps, float* __restrict__ rowab) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  const float2* p = (const float2*)(stats + (size_t)m * npart * 2);
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < npart; ++i) {
-    const float2 v = p[i];
-    s1 += v.x;
-    s2 += v.y;
-  }
-  const double mean = s1 / D;
-  double var = s2 / D - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const float rstd = 1.0f / sqrtf((float)var + eps);
-  *(float2*)(rowab + 2 * (size_t)m) = make_float2(rstd, rstd * (float)mean);
-}
-
-// colsum[n] = sum_k gamma[k] * W[n,k],  bias2[n] = bias[n] + sum_k beta[k] * W[n,k], with W the OPERAND copy
-// the MFMAs read (so the folded terms match the products exactly); one wave per output column, fp64 sums.
-template <int PREC>
-__global__ __launch_bounds__(256) void ln_fold_kernel(const void* __restrict__ w, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, const float* __restrict__ bias,
-                                                      int N, int K, float* __restrict__ colsum,
-                                                      float* __restrict__ bias2) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  double sg = 0.0, sb = 0.0;
-  for (int k = lane; k < K; k += 64) {
-    float wv;
-    if constexpr (PREC == MCM_PREC_F16) wv = (float)((const _Float16*)w)[(size_t)n * K + k];
-    else wv = bf2f(((const uint16_t*)w)[(size_t)n * K + k]);
-    sg += (double)gamma[k] * wv;
-    sb += (double)beta[k] * wv;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    sg += __shfl_xor(sg, o, 64);
-    sb += __shfl_xor(sb, o, 64);
-  }
-  if (lane == 0) {
-    colsum[n] = (float)sg;
-    bias2[n] = (float)((bias ? (double)bias[n] : 0.0) + sb);
-  }
-}
-
 }  // namespace
-
-hipError_t launch_ln_stats_finalize(const float* stats, int npart, int M, int D, float eps, float* rowab,
-                                    hipStream_t s) {
-  if (!stats || !rowab || npart <= 0 || M <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, npart, M, D, eps, rowab);
-  return hipGetLastError();
-}
-
-hipError_t launch_ln_fold(int prec, const void* w_op, const float* gamma, const float* beta, const float* bias,
-                          int N, int K, float* colsum, float* bias2, hipStream_t s) {
-  if (prec == MCM_PREC_F16)
-    hipLaunchKernelGGL(ln_fold_kernel<MCM_PREC_F16>, dim3((N + 3) / 4), dim3(256), 0, s, w_op, gamma, beta, bias, N, K,
-                       colsum, bias2);
-  else if (prec == MCM_PREC_BF16)
-    hipLaunchKernelGGL(ln_fold_kernel<MCM_PREC_BF16>, dim3((N + 3) / 4), dim3(256), 0, s, w_op, gamma, beta, bias, N, K,
-                       colsum, bias2);
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
-}
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,

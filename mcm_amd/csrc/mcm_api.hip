@@ -32,14 +32,11 @@ struct LayerW {
   void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // operand dtype
   float *bqkv = nullptr;                                               // [3D] packed
   const float *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;               // fp32 masters
-  // folded LayerNorm (EPI_*_LN): gamma.W column sums and beta.W + bias of the two consumer GEMMs
-  float *cs_qkv = nullptr, *b2_qkv = nullptr, *cs_fc1 = nullptr, *b2_fc1 = nullptr;
 };
 
 struct Tower {
   int D = 0, heads = 0, layers = 0, ff = 0;
   int prec = MCM_PREC_BF16;  // operand mode of this tower's GEMMs / attention / LayerNorm output
-  bool fold = false;         // LayerNorm folded into the GEMMs around it (see run_layers)
   std::vector<LayerW> L;
 };
 
@@ -61,7 +58,6 @@ struct mcm_handle {
   float* x = nullptr;
   void *ln = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
   float* feat = nullptr;          // [max_batch, proj_dim] scratch for mcm_score
-  float *ln_stats = nullptr, *ln_rowab = nullptr;  // folded LayerNorm: [rows][width/64][2] partial sums, [rows][2]
   int32_t *ids_dev = nullptr, *rowidx_dev = nullptr;
   int32_t *ids_pin = nullptr, *rowidx_pin = nullptr;
   PrepImage *prep_pin = nullptr, *prep_dev = nullptr;  // mcm_resize_crop_u8 geometry, max_batch entries
@@ -196,31 +192,15 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
                bool pooled_row0) {
   const int M = nseq * L, D = t.D, P = t.prec;
   const int es = prec_esize(P);
-  // t.fold (vision tower, 16-bit modes, workspace big enough for the persistent kernel): LayerNorm 2 of every
-  // layer and LayerNorm 1 of layers 1 .. L-2 never run as kernels.  The residual GEMM in front of them
-  // (out-proj, fc2) writes x * gamma in the operand dtype plus per-row partial sums next to its fp32
-  // residual update (EPI_RESID_LN); a row-statistics kernel turns the sums into (rstd, rstd * mean); the
-  // GEMM behind (fc1, QKV) applies the normalisation algebraically in its epilogue (EPI_*_LN).  What
-  // disappears is the LayerNorm kernel's 310-MB fp32 re-read of the residual stream, 21 of 25 calls.
-  // The first LayerNorm 1 (after the embedding's pre-LN) and everything in the CLS-only last layer
-  // keep the standalone kernel.  All choices depend on the handle, never on the batch, so per-image
-  // results do not depend on how a dataset is cut into batches.
-  auto ln_finalize = [&]() -> hipError_t {
-    Scope sc(h, s, MCM_KC_LAYERNORM, 0.0);
-    return launch_ln_stats_finalize(h->ln_stats, D / 64, M, D, h->cfg.ln_eps, h->ln_rowab, s);
-  };
-  bool ln1_folded = false;  // the previous layer's fc2 produced this layer's x * gamma1 and statistics
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
-    if (ln1_folded) HIP_TRY(h, ln_finalize());
-    else HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
     if (!cls) {
       GemmArgs a{};
-      a.x = h->ln; a.w = w.wqkv; a.bias = ln1_folded ? w.b2_qkv : w.bqkv; a.out = h->qkv;
-      a.colsum = w.cs_qkv; a.rowab = h->ln_rowab;
+      a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
       a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
-      HIP_TRY(h, gemm(h, s, P, ln1_folded ? EPI_STORE_LN : EPI_STORE, a));
+      HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
       HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal));
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
@@ -236,28 +216,20 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     }
     const int Mr = cls ? nseq : M;            // rows that continue
     const int rs = cls ? L * D : D;           // their stride in x / att
-    const bool fold2 = t.fold && !cls;
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
-    o.gamma = w.ln2w; o.xg = h->ln; o.stats = h->ln_stats;
     o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
-    HIP_TRY(h, gemm(h, s, P, fold2 ? EPI_RESID_LN : EPI_RESID, o));
-    if (fold2) HIP_TRY(h, ln_finalize());
-    else if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+    HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
+    if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
     else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
     GemmArgs f1{};
-    f1.x = h->ln; f1.w = w.w1; f1.bias = fold2 ? w.b2_fc1 : w.b1; f1.out = h->hbuf;
-    f1.colsum = w.cs_fc1; f1.rowab = h->ln_rowab;
+    f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
     f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
-    HIP_TRY(h, gemm(h, s, P, fold2 ? EPI_GELU_LN : EPI_GELU, f1));
-    // the next layer's LayerNorm 1, unless that layer is the CLS-only last one (or there is none)
-    const bool next_cls = pooled_row0 && l + 1 == t.layers - 1 && L > 1;
-    ln1_folded = t.fold && !cls && l + 1 < t.layers && !next_cls;
+    HIP_TRY(h, gemm(h, s, P, EPI_GELU, f1));
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
-    if (ln1_folded) { f2.gamma = t.L[l + 1].ln1w; f2.xg = h->ln; f2.stats = h->ln_stats; }
     f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
-    HIP_TRY(h, gemm(h, s, P, ln1_folded ? EPI_RESID_LN : EPI_RESID, f2));
+    HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
   }
   return MCM_OK;
 }
@@ -291,14 +263,6 @@ int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s
     w.ln1b = W(h, pre + ".layer_norm1.bias");
     w.ln2w = W(h, pre + ".layer_norm2.weight");
     w.ln2b = W(h, pre + ".layer_norm2.bias");
-    if (t.fold) {
-      if ((rc = dev_alloc(h, (void**)&w.cs_qkv, (size_t)3 * D * sizeof(float)))) return rc;
-      if ((rc = dev_alloc(h, (void**)&w.b2_qkv, (size_t)3 * D * sizeof(float)))) return rc;
-      if ((rc = dev_alloc(h, (void**)&w.cs_fc1, (size_t)ff * sizeof(float)))) return rc;
-      if ((rc = dev_alloc(h, (void**)&w.b2_fc1, (size_t)ff * sizeof(float)))) return rc;
-      HIP_TRY(h, launch_ln_fold(prec, w.wqkv, w.ln1w, w.ln1b, w.bqkv, 3 * D, D, w.cs_qkv, w.b2_qkv, s));
-      HIP_TRY(h, launch_ln_fold(prec, w.w1, w.ln2w, w.ln2b, w.b1, ff, D, w.cs_fc1, w.b2_fc1, s));
-    }
   }
   return MCM_OK;
 }
@@ -353,13 +317,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   // prompt bank is encoded once per dataset, off the hot loop, and a bank rounded to 16-bit operands
   // is a FIXED perturbation of every cosine of every image — it shifts AUROC / FPR95 systematically
   // instead of averaging out.  cfg.precision selects the vision tower's operand mode.
-  h->vis = Tower{c.v_width, c.v_heads, c.v_layers, c.v_mlp, c.precision, false, {}};
-  h->txt = Tower{c.t_width, c.t_heads, c.t_layers, c.t_mlp, MCM_PREC_F32, false, {}};
-  // LayerNorm folding (run_layers): a property of the handle — 16-bit vision operands, a workspace of at
-  // least 16384 token rows (the persistent 256x256 GEMM is the only kernel with the folded epilogues and
-  // is pointless below that), and >= 2 layers besides the CLS-only last one.
-  h->vis.fold = c.precision != MCM_PREC_F32 && (int64_t)c.max_batch * h->ntok >= 16384 && c.v_layers >= 3 &&
-                gemm_persistent_available();
+  h->vis = Tower{c.v_width, c.v_heads, c.v_layers, c.v_mlp, c.precision, {}};
+  h->txt = Tower{c.t_width, c.t_heads, c.t_layers, c.t_mlp, MCM_PREC_F32, {}};
 
   // parameter registry (HF state_dict names)
   add_param(h, "vision_model.embeddings.class_embedding", {c.v_width});
@@ -399,8 +358,6 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->att, both(c.v_width, c.t_width));
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
-  if (!rc && h->vis.fold) rc = dev_alloc(h, (void**)&h->ln_stats, (size_t)mv * (c.v_width / 64) * 2 * sizeof(float));
-  if (!rc && h->vis.fold) rc = dev_alloc(h, (void**)&h->ln_rowab, (size_t)mv * 2 * sizeof(float));
   if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
@@ -790,40 +747,6 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
   if (!h) return MCM_EINVAL;
   HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, 0,
                               (hipStream_t)stream));
-  return MCM_OK;
-}
-
-int mcm_op_resid_ln(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev, const float* bias_dev,
-                    float* resid_dev, const float* gamma_dev, void* xg_dev, float* stats_dev, float* rowab_dev,
-                    int32_t M, int32_t N, int32_t K, float eps, void* stream) {
-  if (!h) return MCM_EINVAL;
-  if (prec == MCM_PREC_F32 || N % 64) return fail(h, MCM_EINVAL, "folded LayerNorm: 16-bit modes, N % 64 == 0");
-  GemmArgs a{};
-  a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.resid = resid_dev; a.gamma = gamma_dev; a.xg = xg_dev;
-  a.stats = stats_dev;
-  a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
-  HIP_TRY(h, launch_gemm(prec, EPI_RESID_LN, a, (hipStream_t)stream));
-  HIP_TRY(h, launch_ln_stats_finalize(stats_dev, N / 64, M, N, eps, rowab_dev, (hipStream_t)stream));
-  return MCM_OK;
-}
-
-int mcm_op_ln_fold(mcm_handle* h, int32_t prec, const void* w_dev, const float* gamma_dev, const float* beta_dev,
-                   const float* bias_dev, int32_t N, int32_t K, float* colsum_dev, float* bias2_dev, void* stream) {
-  if (!h) return MCM_EINVAL;
-  HIP_TRY(h, launch_ln_fold(prec, w_dev, gamma_dev, beta_dev, bias_dev, N, K, colsum_dev, bias2_dev,
-                            (hipStream_t)stream));
-  return MCM_OK;
-}
-
-int mcm_op_linear_folded(mcm_handle* h, int32_t prec, const void* xg_dev, const float* rowab_dev, const void* w_dev,
-                         const float* colsum_dev, const float* bias2_dev, void* y_dev, int32_t M, int32_t N,
-                         int32_t K, int32_t gelu, void* stream) {
-  if (!h) return MCM_EINVAL;
-  if (prec == MCM_PREC_F32) return fail(h, MCM_EINVAL, "folded LayerNorm: 16-bit modes only");
-  GemmArgs a{};
-  a.x = xg_dev; a.w = w_dev; a.bias = bias2_dev; a.colsum = colsum_dev; a.rowab = rowab_dev; a.out = y_dev;
-  a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
-  HIP_TRY(h, launch_gemm(prec, gelu ? EPI_GELU_LN : EPI_STORE_LN, a, (hipStream_t)stream));
   return MCM_OK;
 }
 

@@ -68,9 +68,6 @@ def load_library():
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.mcm_debug_gemm_variant.argtypes = [i32]
     L.mcm_debug_attention_variant.argtypes = [i32]
-    L.mcm_op_resid_ln.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]
-    L.mcm_op_ln_fold.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
-    L.mcm_op_linear_folded.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
@@ -106,7 +103,6 @@ EXPORTED_SYMBOLS = [
     "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram", "mcm_debug_attention_variant",
-    "mcm_op_resid_ln", "mcm_op_ln_fold", "mcm_op_linear_folded",
 ]
 
 

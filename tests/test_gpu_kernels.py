@@ -392,60 +392,3 @@ def test_device_histogram_matches_numpy(tiny_net):
     got = tiny_net.histogram(_dev(s), edges).cpu().numpy()
     want = np.histogram(s, bins=edges)[0]
     assert got.dtype == np.int64 and np.array_equal(got, want)
-
-
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
-@pytest.mark.parametrize("M,D,N2,K1,gelu", [(700, 768, 2304, 768, 0), (513, 768, 3072, 3072, 1), (300, 1024, 1024, 1024, 0)])
-def test_folded_layernorm_trio_vs_oracle(tiny_net, prec, M, D, N2, K1, gelu):
-    """LayerNorm folded into the GEMMs around it (EPI_RESID_LN -> row statistics -> EPI_*_LN) against the
-    oracle's unfused chain  resid += x·W1^T + b1;  y = LN(resid; gamma, beta)·W2^T + b2 [QuickGELU]."""
-    from oracle import oracle as orc
-
-    lib, h = tiny_net._lib, tiny_net._h
-    rng = np.random.default_rng(M + D + N2)
-    x = _round_to(rng.standard_normal((M, K1)), prec)
-    w1 = _round_to(rng.standard_normal((D, K1)) * K1 ** -0.5, prec)
-    b1 = (rng.standard_normal(D) * 0.1).astype(np.float32)
-    resid = (rng.standard_normal((M, D)) * 2 + 0.7).astype(np.float32)     # a non-zero row mean
-    resid[:, 5] += 9.0                                                     # one "massive" channel
-    gamma = (1 + 0.2 * rng.standard_normal(D)).astype(np.float32)
-    beta = (0.3 * rng.standard_normal(D)).astype(np.float32)
-    w2 = _round_to(rng.standard_normal((N2, D)) * D ** -0.5, prec)
-    b2 = (rng.standard_normal(N2) * 0.1).astype(np.float32)
-    want_resid = resid + orc.linear(x, w1, b1)
-    want_ln = orc.layernorm(want_resid, gamma, beta)
-    want = orc.linear(want_ln, w2, b2)
-    if gelu:
-        want = want / (1.0 + np.exp(-1.702 * want))
-    dt = DTYPE[prec]
-    xd, w1d, w2d = _dev(x, dt), _dev(w1, dt), _dev(w2, dt)
-    b1d, b2d, gd, bd, rd = _dev(b1), _dev(b2), _dev(gamma), _dev(beta), _dev(resid)
-    xg = torch.zeros((M, D), device="cuda", dtype=dt)
-    stats = torch.zeros((M, D // 64, 2), device="cuda")
-    rowab = torch.zeros((M, 2), device="cuda")
-    cs, bias2 = torch.zeros(N2, device="cuda"), torch.zeros(N2, device="cuda")
-    y = torch.zeros((M, N2), device="cuda", dtype=dt)
-    assert lib.mcm_op_resid_ln(h, PREC[prec], _ptr(xd), _ptr(w1d), _ptr(b1d), _ptr(rd), _ptr(gd), _ptr(xg), _ptr(stats),
-                               _ptr(rowab), M, D, K1, 1e-5, None) == 0, lib.mcm_last_error(h)
-    assert lib.mcm_op_ln_fold(h, PREC[prec], _ptr(w2d), _ptr(gd), _ptr(bd), _ptr(b2d), N2, D, _ptr(cs), _ptr(bias2), None) == 0
-    assert lib.mcm_op_linear_folded(h, PREC[prec], _ptr(xg), _ptr(rowab), _ptr(w2d), _ptr(cs), _ptr(bias2), _ptr(y),
-                                    M, N2, D, gelu, None) == 0, lib.mcm_last_error(h)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(rd.cpu().numpy(), want_resid, rtol=1e-5, atol=2e-5)          # the fp32 residual update
-    mu, var = want_resid.mean(axis=1), want_resid.var(axis=1)
-    np.testing.assert_allclose(rowab[:, 0].cpu().numpy(), 1 / np.sqrt(var + 1e-5), rtol=2e-5)
-    np.testing.assert_allclose(rowab[:, 1].cpu().numpy(), mu / np.sqrt(var + 1e-5), rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(xg.float().cpu().numpy(), want_resid * gamma, rtol=OUT_TOL[prec], atol=OUT_TOL[prec])
-    got = y.float().cpu().numpy()
-    # same budget as the unfused 16-bit chain: operand rounding of the LN output (here of x*gamma) and of y
-    tol = 4 * OUT_TOL[prec]
-    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
-    # and against the UNFUSED kernels on the same operands (standalone LayerNorm -> plain GEMM): the two routes
-    # must agree to operand rounding, much tighter than either agrees with fp32
-    lnd = torch.zeros((M, D), device="cuda", dtype=dt)
-    assert lib.mcm_op_layernorm(h, PREC[prec], _ptr(rd), _ptr(gd), _ptr(bd), _ptr(lnd), M, D, 1e-5, 0, None) == 0
-    y2 = torch.zeros((M, N2), device="cuda", dtype=dt)
-    assert lib.mcm_op_linear(h, PREC[prec], _ptr(lnd), _ptr(w2d), _ptr(b2d), _ptr(y2), None, M, N2, D, gelu, None) == 0
-    torch.cuda.synchronize()
-    d = (y.float() - y2.float()).abs()
-    assert float(d.mean()) < OUT_TOL[prec] * 0.5 and float(d.max()) < 12 * OUT_TOL[prec], (float(d.mean()), float(d.max()))

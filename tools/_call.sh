@@ -1,3 +1,3 @@
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d /root/repo/gpurun_out/prof_fold/fetch -o f -- python /root/repo/bench.py --steps 6 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 --no-profile > /root/repo/gpurun_out/prof_fold/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d /root/repo/gpurun_out/prof_fold/write -o w -- python /root/repo/bench.py --steps 6 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 --no-profile > /root/repo/gpurun_out/prof_fold/write.log 2>&1
+set -x
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_round2.py -m gpu -q -k "large_sample or round_trip" 2>&1 | tail -8
+bash tools/profile.sh r02_a
