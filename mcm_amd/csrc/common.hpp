@@ -117,18 +117,6 @@ enum GemmEpi : int {
   EPI_GELU = 1,    // out = QuickGELU(acc + bias)
   EPI_RESID = 2,   // resid[M,N] (fp32) += acc + bias
   EPI_PATCH = 3,   // x[b*(np+1)+1+p, :] (fp32) = acc + pos[1+p, :]   (m = b*np + p)
-  // LayerNorm folded into the two GEMMs around it (16-bit modes, persistent 256x256 kernel only):
-  //   producer  EPI_RESID_LN : resid += acc + bias as EPI_RESID, and in the same pass xg[M,N] (operand dtype)
-  //             = resid * gamma (the NEXT LayerNorm's weight, per column) plus per-row partial sums
-  //             (sum x, sum x^2 over each wave's 64 columns) -> stats[M][N/64][2]
-  //   consumer  EPI_STORE_LN / EPI_GELU_LN : A = xg; out = rstd_m * acc - (rstd_m * mu_m) * colsum_n + bias_n
-  //             [then QuickGELU], with rowab[M][2] = (rstd, rstd * mu) from ln_stats_finalize and
-  //             colsum_n = sum_k gamma_k W[n,k], bias_n = b_n + sum_k beta_k W[n,k] folded at finalize.
-  //   LN(x) W^T + b = rstd (x.gamma) W^T - rstd mu (gamma W^T) + (beta W^T + b): the 310-MB fp32 re-read of
-  //   the residual stream by a LayerNorm kernel disappears; W itself is untouched (stays exact in fp16).
-  EPI_RESID_LN = 4,
-  EPI_STORE_LN = 5,
-  EPI_GELU_LN = 6,
 };
 
 struct GemmArgs {
@@ -138,11 +126,6 @@ struct GemmArgs {
   void* out;          // EPI_STORE / EPI_GELU: [M, N] operand dtype; EPI_PATCH: fp32 x
   float* resid;       // EPI_RESID: [M, N] fp32
   const float* pos;   // EPI_PATCH: position embedding [np+1, N]
-  const float* gamma;   // EPI_RESID_LN: next LayerNorm's weight [N]
-  void* xg;             // EPI_RESID_LN: [M, N] operand dtype, row stride N
-  float* stats;         // EPI_RESID_LN: [M][N/64][2] partial (sum x, sum x^2)
-  const float* rowab;   // EPI_*_LN consumers: [M][2] = (rstd, rstd * mean)
-  const float* colsum;  // EPI_*_LN consumers: [N] = sum_k gamma_k W[n,k]
   int M, N, K;
   int ldx;            // elements
   int ldo;            // elements (row stride of out / resid)
@@ -157,12 +140,6 @@ void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 #endif
 void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
-
-// layernorm.hip: the two small kernels of the folded LayerNorm (see EPI_RESID_LN)
-hipError_t launch_ln_stats_finalize(const float* stats, int npart, int M, int D, float eps, float* rowab,
-                                    hipStream_t s);
-hipError_t launch_ln_fold(int prec, const void* w_op, const float* gamma, const float* beta, const float* bias,
-                          int N, int K, float* colsum, float* bias2, hipStream_t s);
 
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,

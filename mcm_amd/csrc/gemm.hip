@@ -167,31 +167,12 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
 }
 
-// per-lane extras of the folded-LayerNorm epilogues (unused, and optimised away, for the others)
-struct LnRegs {
-  f32x4_t sv[4];   // consumer: colsum of this lane's 16 columns
-  float ra[8];     // consumer: rstd of row (unit u, fr)
-  float rb[8];     // consumer: rstd * mean
-};
-constexpr bool epi_out16(int epi) { return epi == EPI_STORE || epi == EPI_GELU || epi == EPI_STORE_LN || epi == EPI_GELU_LN; }
-constexpr bool epi_gelu(int epi) { return epi == EPI_GELU || epi == EPI_GELU_LN; }
-constexpr bool epi_ln_consumer(int epi) { return epi == EPI_STORE_LN || epi == EPI_GELU_LN; }
-
-// sum over the 16 lanes of a DPP row (all lanes receive it): quad butterflies, then the two mirrors
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return v;
-}
-
 template <int PREC, int EPI, int MF>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
-                                                  char* scratch, const LnRegs& ln) {
+                                                  char* scratch) {
   const int fr = lane & 15, g = lane >> 4;
-  if constexpr (PREC != MCM_PREC_F32 && epi_out16(EPI)) {
+  if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
     // written while unit u-1 is read back and stored, so the LDS round trip and the store issue
     // (a 1-KiB store blocks its wave like an LDS-DMA piece does) overlap the next unit's VALU work.
@@ -201,14 +182,8 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
       f32x4_t v[4];
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) {
-        if constexpr (epi_ln_consumer(EPI)) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            v[fj][t] = fmaf(ln.ra[u], acc[fj][u][t], fmaf(-ln.rb[u], ln.sv[fj][t], bv[fj][t]));
-        } else {
-          v[fj] = acc[fj][u] + bv[fj];
-        }
-        if constexpr (epi_gelu(EPI)) {
+        v[fj] = acc[fj][u] + bv[fj];
+        if constexpr (EPI == EPI_GELU) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
         }
@@ -261,7 +236,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
       if constexpr (EPI == EPI_PATCH) {
         const int mm = min(m, a.M - 1), b = mm / a.np, p = mm - b * a.np;
         return (float*)a.out + (size_t)(b * (a.np + 1) + 1 + p) * a.ldo + n;
-      } else if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_LN) {
+      } else if constexpr (EPI == EPI_RESID) {
         return a.resid + (size_t)m * a.ldo + n;
       } else {
         return (float*)a.out + (size_t)m * a.ldo + n;
@@ -283,15 +258,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         rnext[t] = ok ? *(const f32x4_t*)ptr : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
     };
-    constexpr bool ADD = (EPI == EPI_RESID || EPI == EPI_PATCH || EPI == EPI_RESID_LN);
-    // EPI_RESID_LN: this lane's 4 columns of gamma, and the row statistics it ends up owning: after the
-    // 16-lane reductions every lane of a row group has the sums, lane c16 keeps those of (c, t) = c16 / 4,
-    // c16 % 4 (+16: second register), so the tile's 128 rows x 2 sums leave in two 8-byte stores per lane
-    f32x4_t gam = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
-    if constexpr (EPI == EPI_RESID_LN) {
-      if (ncol) gam = *(const f32x4_t*)(a.gamma + n);
-    }
+    constexpr bool ADD = (EPI == EPI_RESID || EPI == EPI_PATCH);
     if constexpr (ADD) prefetch(0);
 #pragma unroll
     for (int c = 0; c < MF; ++c) {
@@ -319,33 +286,6 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         bool ok;
         float* dst = row_ptr(c, t, ok);
         if (ok) *(f32x4_t*)dst = v;  // fp32 / residual rows: streaming them measured no gain
-        if constexpr (EPI == EPI_RESID_LN) {
-          if (ok) {
-            const int m = mw + c * 16 + t * 4 + rrow;
-            uint2 pk;
-            pk.x = pack2<PREC>(v[0] * gam[0], v[1] * gam[1]);
-            pk.y = pack2<PREC>(v[2] * gam[2], v[3] * gam[3]);
-            *(uint2*)((uint16_t*)a.xg + (size_t)m * a.N + n) = pk;
-          }
-          const f32x4_t vz = ncol ? v : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          const float s1 = row16_sum((vz[0] + vz[1]) + (vz[2] + vz[3]));
-          const float s2 = row16_sum(fmaf(vz[0], vz[0], vz[1] * vz[1]) + fmaf(vz[2], vz[2], vz[3] * vz[3]));
-          const int j = c * 4 + t;  // 0 .. 31
-          const bool mine = c16 == (j & 15);
-          st1[j >> 4] = mine ? s1 : st1[j >> 4];
-          st2[j >> 4] = mine ? s2 : st2[j >> 4];
-        }
-      }
-    }
-    if constexpr (EPI == EPI_RESID_LN) {
-      const int npart = a.N >> 6, part = nw >> 6;
-      if (nw < a.N) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int j = hh * 16 + c16;
-          const int m = mw + (j >> 2) * 16 + (j & 3) * 4 + rrow;
-          if (m < a.M) *(float2*)(a.stats + ((size_t)m * npart + part) * 2) = make_float2(st1[hh], st2[hh]);
-        }
       }
     }
   }
