@@ -258,14 +258,14 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
   return d;
 }
 
-template <int PREC, int NT, bool CAUSAL>
-__global__ __launch_bounds__(256, (NT <= 13 ? 3 : 2)) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
+template <int PREC, int NT, bool CAUSAL, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
                                                                          uint16_t* __restrict__ out, int L,
                                                                          int heads, int qrows, int rev) {
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP = NT * 16;           // padded keys
-  constexpr int MAXQB = (NT + 3) / 4;   // q-blocks per wave
+  constexpr int MAXQB = (NT + NW - 1) / NW;   // q-blocks per wave (NW waves per workgroup)
   constexpr uint32_t ONE2 = PREC == MCM_PREC_F16 ? 0x3c003c00u : 0x3f803f80u;  // two 1.0 operands
   char* Ks = smem;               // [LP][128 B], GEMM-style pair/XOR image
   char* Vs = smem + LP * 128;    // [LP][128 B], 32-B segment s stored at s ^ ((key >> 1) & 3)
@@ -284,13 +284,13 @@ __global__ __launch_bounds__(256, (NT <= 13 ? 3 : 2)) void attn_tr_kernel(const 
   uint4 qf[MAXQB][2];
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
-    const int qr = min((wave + 4 * i) * 16 + fr, L - 1);
+    const int qr = min((wave + NW * i) * 16 + fr, L - 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      qf[i][kk] = (wave + 4 * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
+      qf[i][kk] = (wave + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
                                        : make_uint4(0, 0, 0, 0);
   }
-  for (int blk = wave; blk < LP / 8; blk += 4) {  // 1-KiB pieces: 8 key rows each
+  for (int blk = wave; blk < LP / 8; blk += NW) {  // 1-KiB pieces: 8 key rows each
     {
       const int p = blk * 4 + (lane >> 4), s = lane & 15;
       const int row = min(2 * p + (s >> 3), L - 1);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, (NT <= 13 ? 3 : 2)) void attn_tr_kernel(const 
 
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
-    const int qb = wave + 4 * i;
+    const int qb = wave + NW * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
     const uint4 q0 = qf[i][0], q1 = qf[i][1];
@@ -481,40 +481,47 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
   return hipGetLastError();
 }
 
-template <int PREC, int NT>
+template <int PREC, int NT, int NW, int OCC>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                      hipStream_t s, int rev) {
   constexpr int lds = NT * 16 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true>,
+      e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true, NW, OCC>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (causal)
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true>), dim3(nseq * heads), dim3(256), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
   else
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false>), dim3(nseq * heads), dim3(256), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
   return hipGetLastError();
 }
 
+// Waves per workgroup.  The q-blocks of a sequence are dealt round-robin to the waves, so the slowest wave has
+// ceil(q-blocks / waves) of them.  Measured at B/16 batch 512 / L/14 batch 256 (tools/attn_probe.py, same
+// box, old kernel 215 / 295 us): 4 waves (4-3-3-3 blocks) 164 - 167 / 183 - 186 us, 5 - 6 waves 171 - 178, 7 waves
+// 154 - 168, **8 waves (2-2-2-2-2-1-1-1) 149 - 153 / 156 - 158 us**; occupancy bounds 1 ... 4 waves per SIMD make no
+// difference at 8 waves (90 / 116 VGPRs either way), 6 and more cost spills.  Results are bit-identical
+// for every wave count (a q-block's arithmetic does not depend on which wave runs it).
 template <int PREC>
 hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                               hipStream_t s, int rev) {
   const int nt = (L + 15) / 16;
-#define MCM_TR(N) \
-  if (nt <= N) return launch_tr<PREC, N>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
-  MCM_TR(1); MCM_TR(2); MCM_TR(3); MCM_TR(4); MCM_TR(5); MCM_TR(6); MCM_TR(8); MCM_TR(10); MCM_TR(13); MCM_TR(17);
-  MCM_TR(18);
+#define MCM_TR(N, W, O) \
+  if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
+  MCM_TR(1, 4, 3); MCM_TR(2, 4, 3); MCM_TR(3, 4, 3); MCM_TR(4, 4, 3); MCM_TR(5, 4, 3); MCM_TR(6, 4, 3);
+  MCM_TR(8, 4, 3); MCM_TR(10, 8, 3); MCM_TR(13, 8, 3); MCM_TR(17, 8, 3); MCM_TR(18, 8, 3);
 #undef MCM_TR
   return hipErrorInvalidValue;
 }
+
 int g_attn_variant = 1;  // 1 = attn_tr_kernel (round 2), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
 
 }  // namespace
@@ -525,7 +532,7 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
                             bool causal, int qrows, hipStream_t s, bool reverse) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
-  if (prec != MCM_PREC_F32 && g_attn_variant == 1) {
+  if (prec != MCM_PREC_F32 && g_attn_variant >= 1) {
     if (prec == MCM_PREC_F16)
       return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
     return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);

@@ -60,8 +60,7 @@ for prec, dt in ((0, torch.bfloat16), (2, torch.float16)):
                   f"({(qkv.numel() + out.numel()) * 2 / us / 1e6:.2f} TB/s)", flush=True)
         n_ref = min(nseq, 8)
         want = ref(qkv[: n_ref * L], n_ref, L, heads, causal).float()
-        print(f"    max|v1-v0| = {(outs[1] - outs[0]).abs().max().item():.3e}   max|v0-ref| = "
-              f"{(outs[0][: n_ref * L] - want).abs().max().item():.3e}   max|v1-ref| = "
-              f"{(outs[1][: n_ref * L] - want).abs().max().item():.3e}", flush=True)
+        print("    max|v-ref| per variant: " + "  ".join(f"{(o[: n_ref * L] - want).abs().max().item():.3e}" for o in outs)
+              + "   all new-kernel variants bit-equal: " + str(all(torch.equal(outs[1], o) for o in outs[2:])), flush=True)
 lib.mcm_debug_attention_variant(1)
 net.close()
