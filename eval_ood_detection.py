@@ -58,7 +58,8 @@ def process_args(argv=None):
     p.add_argument("--max_count", default=250, type=int)
     # additive
     p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="MFMA operand precision")
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+                   help="MFMA operand format of the vision tower (fp16 holds AUROC/FPR95 to the fp32 arm at 1e-4; the text tower is always fp32)")
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")

@@ -116,7 +116,7 @@ class NativeCLIP:
     """CLIP towers + MCM scoring tail on one MI355X."""
 
     def __init__(self, geo: ClipGeometry | str, state_dict: Dict[str, np.ndarray], *,
-                 device: int = 0, precision: str = "bf16", max_batch: int = 512,
+                 device: int = 0, precision: str = "fp16", max_batch: int = 512,
                  max_prompt_tokens: int = 1024 * 77):
         import torch
 
