@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--no-drift", action="store_true", help="skip the AUROC/FPR95 drift leg (N = 1 only)")
     ap.add_argument("--drift-n", type=int, nargs=2, default=[50000, 10000], metavar=("N_ID", "N_OOD"))
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
+    ap.add_argument("--gemm-variant", type=int, default=-1,
+                    help="A/B hook: force a GEMM kernel variant (mcm_debug_gemm_variant; -1 = the library's choice)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
@@ -208,6 +210,8 @@ def main():
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
                      max_prompt_tokens=max(K * ids.shape[1], 77))
+    if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
+        raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
                                 normalize=True)
 

@@ -272,7 +272,8 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
 
 /* Testing hook: force the GEMM kernel variant (-1 auto [default], 0 = 128x128 tile kernel,
  * 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 3/4 = persistent 256x256
- * 2-stage (4: counted epilogue stores)).  Process-wide.
+ * 2-stage (4: counted epilogue stores), 5 = persistent 256x256 ping-pong (problems whose M and N
+ * are multiples of 256; others run as 3)).  Process-wide.
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
 /* Testing hook: 16-bit attention kernel — 1 (default) = the transpose-read kernel (K and V by LDS-DMA,

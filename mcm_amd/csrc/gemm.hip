@@ -36,6 +36,8 @@
 //                        private L2), the two waves of a SIMD take turns refilling, whole-row
 //                        epilogue stores are streamed (nt).  Measurements and what bounds it:
 //                        DESIGN.md sections 4.1 and 5.1.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -167,7 +169,9 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
 }
 
-template <int PREC, int EPI, int MF>
+// INTERIOR (16-bit outputs only; the ping-pong kernel): the caller guarantees a full tile and uniform mw / nw;
+// rows are then addressed as a uniform base plus one 32-bit lane offset, without bounds checks.
+template <int PREC, int EPI, int MF, bool INTERIOR = false>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
                                                   char* scratch) {
@@ -204,11 +208,17 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 128 + ((c8 ^ (row & 7)) << 4));
       }
     };
+    const int lane_off = rrow * a.ldo + c8 * 8;  // elements
     auto store_unit = [&](int u, const uint4 (&r)[2]) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int m = mw + u * 16 + t * 8 + rrow;
-        if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, r[t]);
+        if constexpr (INTERIOR) {
+          uint16_t* rowbase = (uint16_t*)a.out + (size_t)(mw + u * 16 + t * 8) * a.ldo + nw;
+          if (!DBG(16)) store16_stream(rowbase + lane_off, r[t]);
+        } else {
+          const int m = mw + u * 16 + t * 8 + rrow;
+          if (m < a.M && n < a.N && !DBG(16)) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, r[t]);
+        }
       }
     };
     write_unit(0);
@@ -759,9 +769,392 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   }
 }
 
+// fp32-row epilogue of a full (interior) 128x64 wave tile for the ping-pong kernel: the same LDS bounce and
+// the same arithmetic as the fp32 branch of wave_epilogue_lds, but every global access is issued from inline
+// asm and waited for by count.  hipcc's own waitcnt pass never sees them, so it has no reason to put a
+// vmcnt(0) in front of the fragment reads or the MFMAs of the K loop (it did, once the epilogue's plain
+// stores were inlined into the loop: the wait drains the LDS-DMA stream, -20 % on fc2).  The queue at the wait
+// of chunk c, oldest first: [older] [loads c] [stores c-1] [loads c+1]  =>  vmcnt <= 8 (<= 4 at both ends).
+__device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_pin(f32x4_t (&b)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+template <int EPI, int MF>
+__device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
+                                                           const f32x4_t (&bv)[4], int mw, int nw, int lane,
+                                                           char* scratch) {
+  static_assert(EPI != EPI_PATCH, "patch rows are remapped: not an interior form");
+  const int fr = lane & 15, g = lane >> 4;
+  const int rrow = lane >> 4, c16 = lane & 15;
+  const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes
+  const char* base = (const char*)(EPI == EPI_RESID ? a.resid : (float*)a.out) + ((size_t)mw * a.ldo + nw) * 4;
+  auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
+  f32x4_t buf[2][4];
+  if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
+  }
+#pragma unroll
+  for (int c = 0; c < MF; ++c) {
+    if constexpr (EPI == EPI_RESID) {
+      if (c + 1 < MF) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gload16(buf[(c + 1) & 1][t], rowbase(c + 1, t), voff);
+      }
+    }
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+      f32x4_t v = acc[fj][c] + bv[fj];
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
+      }
+      *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ fr) << 4)) = v;
+    }
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 4 + rrow;
+      v[t] = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
+    }
+    if constexpr (EPI == EPI_RESID) {
+      if (c == 0 || c + 1 == MF) wait_vmcnt_pin<4>(buf[c & 1]);
+      else wait_vmcnt_pin<8>(buf[c & 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] += buf[c & 1][t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gstore16(rowbase(c, t), voff, v[t]);
+  }
+}
+
+// =========================================================================================
+// persistent 256x256 "ping-pong" kernel.  Same tile, wave tiles, LDS image and epilogue as
+// gemm_p256_kernel, but the two waves of a SIMD (w and w+4) run half a K-step apart: while one
+// is in its MEMORY phase (8 LDS-DMA pieces for the next step, then the whole step's 24 fragments
+// into 96 registers) the other is in its COMPUTE phase (64 back-to-back MFMAs on registers), and
+// they swap at a workgroup barrier — two barriers per K-step instead of one, but the matrix pipe
+// of a SIMD always has one wave that does nothing but feed it.  Interior tiles only (M, N multiples
+// of 256).
+// =========================================================================================
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+
+// harness-only phase timing of the ping-pong kernel: s_memtime deltas accumulated in scalar registers (stamps
+// only where the wave has to drain lgkmcnt anyway), split into mid-tile steps and steps that carry an epilogue;
+// written out once at the end (a.pos = uint32 buffer [block][wave][2][5]: 4 sums + step count)
+#ifdef MCM_GEMM_TRACE
+#define PPT_INIT()                                  \
+  uint32_t ppt_sum[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; \
+  uint64_t ppt_prev = __builtin_amdgcn_s_memtime(); \
+  int ppt_set = 0
+#define PPT(k)                                                    \
+  do {                                                            \
+    if (DBG(128)) {                                               \
+      if ((k) == 0) ppt_set = pend ? 1 : 0;                       \
+      const uint64_t t = __builtin_amdgcn_s_memtime();            \
+      ppt_sum[ppt_set][k] += (uint32_t)(t - ppt_prev);            \
+      ppt_prev = t;                                               \
+      if ((k) == 3) ppt_sum[ppt_set][4] += 1;                     \
+    }                                                             \
+  } while (0)
+#define PPT_DUMP()                                                                                      \
+  do {                                                                                                  \
+    if (DBG(128) && lane == 0) {                                                                        \
+      uint32_t* o = (uint32_t*)a.pos + ((size_t)blockIdx.x * 8 + wave) * 10;                            \
+      for (int i = 0; i < 2; ++i)                                                                       \
+        for (int j = 0; j < 5; ++j) o[i * 5 + j] = ppt_sum[i][j];                                       \
+    }                                                                                                   \
+  } while (0)
+#else
+#define PPT_INIT()
+#define PPT(k)
+#define PPT_DUMP()
+#endif
+
+template <int PREC, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
+  using namespace p256;
+  enter_precision_mode<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = prec_esize(PREC);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
+  const int grp = wave >> 2, w4 = wave & 3;
+
+  const int nbn = a.N / BN, nbm = a.M / BM;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nmt_x = (nbm - xcd + 7) >> 3;
+  const int ntl_x = nmt_x * nbn;
+  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
+  if (ntl == 0) return;
+  const int nk = (a.K * ES) / ROWB;
+  const int total = ntl * nk;
+
+  const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
+  struct Cursor { int mtl, nt; };
+  auto cursor_next = [&](Cursor& c) {
+    c.mtl += dmt;
+    c.nt += dnt;
+    if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
+  };
+  auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
+  const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
+
+  // ---- LDS-DMA side.  Waves 0-3 (rows 0-127 of the tile) stage their half of the X panel and all of W,
+  // 12 pieces per wave and step; waves 4-7 stage the other X half, which only they read, 4 pieces.  Every
+  // piece is issued in the memory phase of step s for step s+1 and waited for at the end of the issuing
+  // wave's compute phase, one phase before its first reader.
+  // Per-lane constants (DMA source offsets, fragment offsets) are NOT kept across the loop: 128 accumulators
+  // + 64 fragments leave hipcc no room, and a spilled loop invariant comes back through a scratch load whose
+  // vmcnt(0) drains the DMA stream.  They are rebuilt from an opaque copy of the lane id where needed (~12 VALU).
+  struct LaneK { uint32_t voff_x, voff_w; int fo0, fo1; };
+  auto lane_consts = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int rr = (l >> 4) * 2 + ((l & 15) >> 3);
+    const int chunk = (l & 7) ^ (((w4 & 1) << 2) | (l >> 4));
+    LaneK c;
+    c.voff_x = (uint32_t)(rr * (uint32_t)sx + chunk * 16);
+    c.voff_w = (uint32_t)(perm_n(w4 * 8 + rr) * (uint32_t)sw + chunk * 16);
+    c.fo0 = frag_off(l & 15, l >> 4, 0);
+    c.fo1 = frag_off(l & 15, l >> 4, 1);
+    return c;
+  };
+  Cursor ci{jx / nbn, jx % nbn};
+  int ji = 0, kti = 0;
+  const char *tx, *tw;  // uniform: first byte of this wave's rows of the tile being staged
+  auto set_issue_tile = [&]() {
+    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
+    tx = (const char*)a.x + (size_t)(m0 + grp * 128 + w4 * 8) * sx;
+    tw = (const char*)a.w + (size_t)n0 * sw;
+  };
+  const uint32_t lds0 = lds_addr(smem);
+  auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
+    const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
+    const size_t ko = (size_t)kti * ROWB;
+    if (i < 4) {
+      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+    } else {
+      const int q = i - 4;
+      glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
+    }
+  };
+  auto issue_done = [&]() {
+    if (++kti == nk) {
+      kti = 0;
+      if (++ji < ntl) {
+        cursor_next(ci);
+        set_issue_tile();
+      }
+    }
+  };
+
+  // ---- MFMA side
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
+  const int fr = lane & 15, g = lane >> 4;
+  const int xbase = wr * 128 * ROWB;
+  const int wbase = A_BYTES + wc * 64 * ROWB;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  // Fragments of a step: the W fragments of both K halves and the X fragments of the first half are read in
+  // the memory phase (16 reads, 64 registers); the X fragments of the second half replace those of the first
+  // one by one during the compute phase (each after its last use) — the rows they come from are staged by this
+  // very wave group, so nobody overwrites them before the group's own next memory phase.
+  u32x4_t xf[8], wf[2][4];
+  auto readf = [&](const LaneK& lk, int st, int i) {  // memory-phase read i of 16
+    const char* sb = smem + st * STAGE_BYTES;
+    if (i < 4) wf[0][i] = *(const u32x4_t*)(sb + wbase + i * 2048 + lk.fo0);
+    else if (i < 12) xf[i - 4] = *(const u32x4_t*)(sb + xbase + (i - 4) * 2048 + lk.fo0);
+    else wf[1][i - 12] = *(const u32x4_t*)(sb + wbase + (i - 12) * 2048 + lk.fo1);
+  };
+  auto pin_frags = [&]() {  // the fragments are in registers here, not wherever hipcc would sink the reads to
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(wf[0][f]));
+#pragma unroll
+    for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(wf[1][f]));
+#pragma unroll
+    for (int f = 0; f < 8; ++f) asm volatile("" : "+v"(xf[f]));
+  };
+  f32x4_t acc[4][8];
+  zero_acc<8>(acc);
+  auto mfma_pair = [&](const u32x4_t& wv4, const u32x4_t& xv4, f32x4_t& c) {
+    if constexpr (PREC != MCM_PREC_F32) {
+      c = mfma16<PREC>(__builtin_bit_cast(uint4, wv4), __builtin_bit_cast(uint4, xv4), c);
+    } else {
+      const f32x4_t wv = __builtin_bit_cast(f32x4_t, wv4);
+      const f32x4_t xv = __builtin_bit_cast(f32x4_t, xv4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], c, 0, 0, 0);
+    }
+  };
+  auto compute = [&](int fo1, int st) {
+    const char* sb = smem + st * STAGE_BYTES;
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi) {
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) mfma_pair(wf[0][fj], xf[fi], acc[fj][fi]);
+      xf[fi] = *(const u32x4_t*)(sb + xbase + fi * 2048 + fo1);
+    }
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) mfma_pair(wf[1][fj], xf[fi], acc[fj][fi]);
+  };
+
+  Cursor cc{jx / nbn, jx % nbn};
+  int em0 = 0, en0 = 0;  // tile whose epilogue is pending
+  f32x4_t bv[4];  // bias of the pending tile: asm loads issued at the top of its last compute phase
+#pragma unroll
+  for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto epilogue = [&]() {
+    // every lane-derived address of the epilogue is recomputed from an opaque copy of the lane id: hoisted out
+    // of the K loop they would occupy ~20 registers that the loop (128 accumulators + 64 fragments) does not have
+    int le = lane;
+    asm volatile("" : "+v"(le));
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+    if (!DBG(4)) {
+      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+      if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
+        wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+      else
+        wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+    }
+    zero_acc<8>(acc);
+  };
+#ifdef MCM_HARNESS
+  if (a.dbg >> 8) {  // harness: de-phase the workgroups of an XCD, (dbg >> 8) x 1024 cycles per step of jx & 3
+    const uint64_t until = __builtin_amdgcn_s_memtime() + (uint64_t)((jx >> 3) & 3) * (uint64_t)(a.dbg >> 8) * 1024u;
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+  set_issue_tile();
+  {
+    const LaneK lk = lane_consts();
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      if (i < 4 || !grp) piece(lk, 0, i);
+  }
+  issue_done();
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp) {  // waves 4-7 run one phase behind
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int ktc = 0;
+  bool pend = false;
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  PPT_INIT();
+  for (int s = 0; s < total; ++s) {
+    // ---- memory phase of step s: the step's fragments into registers, interleaved with the DMA issues for
+    // step s+1 (a DMA issue blocks the wave on the TA, a ds_read on the LDS queue: alternating them lets the two
+    // queues drain side by side).  The first instruction is a ds_read on purpose: hipcc puts a vmcnt(0) in
+    // front of the first fragment read after an epilogue with compiler-visible stores, which must not have
+    // this phase's DMA to wait for.  After the very last step the issue re-reads the last tile (never used).
+    // At a tile boundary (`pend`) waves 0-3 issue, pass the barrier, run the epilogue and only then read the
+    // fragments; waves 4-7 run the epilogue first: both epilogues fall into the same phase and no fragment
+    // is live across them.
+    const int sr = s & 1, si = sr ^ 1;
+    const bool split = pend && !grp;
+    int fo1;
+    if (pend) {
+      if (!grp) {
+        const LaneK lk = lane_consts();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) piece(lk, si, i);
+        issue_done();
+        phase_barrier();
+      }
+      epilogue();
+      if (!grp) {
+        const LaneK lk = lane_consts();
+        fo1 = lk.fo1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) readf(lk, sr, i);
+      }
+    }
+    if (!split) {
+      const LaneK lk = lane_consts();
+      fo1 = lk.fo1;
+      if (!grp) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          if (i < 8) {
+            readf(lk, sr, 2 * i);
+            readf(lk, sr, 2 * i + 1);
+          }
+          piece(lk, si, i);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
+          piece(lk, si, i);
+        }
+      }
+      issue_done();
+    }
+    pin_frags();
+    PPT(0);
+    if (!split) phase_barrier();
+    PPT(1);
+    // ---- compute phase of step s
+    if (ktc == nk - 1 && a.bias) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
+    }
+    __builtin_amdgcn_s_setprio(1);
+    compute(fo1, sr);
+    __builtin_amdgcn_s_setprio(0);
+    PPT(2);
+    wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
+    phase_barrier();
+    PPT(3);
+    pend = false;
+    if (++ktc == nk) {
+      ktc = 0;
+      pend = true;
+      em0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
+      en0 = cc.nt * BN;
+      cursor_next(cc);
+    }
+  }
+  if (!grp) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (pend) epilogue();
+  PPT_DUMP();
+}
+
 // ---- launch ------------------------------------------------------------------------------
 
-int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores)
+int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores),
+                     // 5 ping-pong 256x256 (interior tiles only, else 3)
 
 int variant() { return g_variant; }
 
@@ -820,6 +1213,19 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int PREC, int EPI>
+hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+template <int PREC, int EPI>
 hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   int v = variant();
   if (v < 0) {  // auto: the persistent 256x256 kernel once its tiles cover most of the CUs, else the
@@ -827,13 +1233,19 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
                 // bench.py --batch 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 %
                 // end to end against the old >= 1024 rule).
     const long tiles = (long)((a.M + p256::BM - 1) / p256::BM) * ((a.N + p256::BN - 1) / p256::BN);
-    v = tiles >= 192 ? 3 : 0;
+    v = tiles >= 192 ? 5 : 0;  // 5 falls back to 3 when the problem has edge tiles
   }
   if (v != 0 && persistent_grid() < 8) v = 0;
   if (v == 0) return launch_tile<PREC, EPI>(a, s);
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
   if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
   if (v == 3) return launch_p256<PREC, EPI, false>(a, s);
+  if (v == 5) {
+    if constexpr (EPI != EPI_PATCH) {  // the patch epilogue remaps rows: stays with the plain kernel
+      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI>(a, s);
+    }
+    return launch_p256<PREC, EPI, false>(a, s);
+  }
   return launch_p256<PREC, EPI, true>(a, s);
 }
 

@@ -757,7 +757,7 @@ int mcm_debug_attention_variant(int32_t variant) {
 }
 
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || variant > 4) return MCM_EINVAL;
+  if (variant < -1 || variant > 5) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }

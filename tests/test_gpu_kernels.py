@@ -138,25 +138,70 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)      # fp32 accumulation order
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (768, 512, 3072), (2048, 256, 64)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_linear_pingpong_interior_shapes_vs_oracle(tiny_net, M, N, K, prec, epi):
+    """The ping-pong 256x256 kernel only takes problems made of whole tiles (the shapes of GEMM_SHAPES fall
+    back to the plain persistent kernel under variant 5), so it gets its own oracle cases: one tile, a few
+    tiles on a few workgroups, a long K, a single K-step."""
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(M + N * 5 + K * 11 + epi)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    resid0 = rng.standard_normal((M, N)).astype(np.float32)
+    if prec != "fp32":
+        x, w = _round_to(x, prec), _round_to(w, prec)
+    lin = orc.linear(x, w, bias)
+    dt = DTYPE[prec]
+    xd, wd, bd = _dev(x, dt), _dev(w, dt), _dev(bias)
+    y = torch.zeros((M, N), device="cuda", dtype=dt)
+    rd = _dev(resid0)
+    try:
+        assert tiny_net._lib.mcm_debug_gemm_variant(5) == 0
+        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC[prec], _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), _ptr(rd),
+                                         M, N, K, epi, None)
+        assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+        torch.cuda.synchronize()
+    finally:
+        tiny_net._lib.mcm_debug_gemm_variant(-1)
+    if epi == 0:
+        got, want = y.float().cpu().numpy(), lin
+    elif epi == 1:
+        got, want = y.float().cpu().numpy(), orc.quick_gelu(lin)
+    else:
+        got, want = rd.cpu().numpy(), resid0 + lin
+    if prec != "fp32" and epi != 2:
+        np.testing.assert_allclose(got, want, rtol=OUT_TOL[prec], atol=OUT_TOL[prec])
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 2), (768, 768, 2)])
-def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi):
-    """The four GEMM shapes of a B/16 layer at batch 512 (M = 512*197): the persistent 256x256 kernel
-    (both wait forms) against the one-workgroup-per-tile kernel, bit for bit, three launches each.
+def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi, prec):
+    """The four GEMM shapes of a B/16 layer at batch 512 (M = 512*197): the persistent 256x256 kernels
+    (both wait forms, and the ping-pong kernel) against the one-workgroup-per-tile kernel, bit for bit, three
+    launches each, in every operand format.
     Full-size runs are what exposes timing-dependent faults (missed hazards, DMA/LDS ordering) that
     the small oracle-checked shapes above cannot: the tile kernel shares the fragment and epilogue
     arithmetic but none of the persistent kernel's pipelining."""
-    M = 512 * 197
+    M = 512 * 197 if prec != "fp32" else 25600  # whole 256-row tiles either way (the ping-pong kernel needs them)
+    dt = DTYPE[prec]
     g = torch.Generator(device="cuda").manual_seed(N + K + epi)
-    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
-    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    x = torch.randn((M, K), generator=g, device="cuda").to(dt)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dt)
     bias = 0.1 * torch.randn(N, generator=g, device="cuda")
     resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
+    bits = {2: torch.int16, 4: torch.int32}
 
     def run(variant):
         assert tiny_net._lib.mcm_debug_gemm_variant(variant) == 0
-        y = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+        y = torch.zeros((M, N), device="cuda", dtype=dt)
         rd = resid0.clone() if epi == 2 else y
-        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC["bf16"], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
                                          _ptr(rd), M, N, K, epi, None)
         assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
         torch.cuda.synchronize()
@@ -165,11 +210,11 @@ def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi):
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (3, 4):
+        for variant in (3, 4, 5):
             for _ in range(3):
                 got = run(variant)
-                assert torch.equal(got.view(torch.int16 if epi != 2 else torch.int32),
-                                   ref.view(torch.int16 if epi != 2 else torch.int32)), f"variant {variant}"
+                assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
+                    f"variant {variant}"
     finally:
         tiny_net._lib.mcm_debug_gemm_variant(-1)
 

@@ -71,10 +71,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int nvar = 5;
+  const int nvar = 6;
+  const unsigned vmask = argc > 9 ? (unsigned)strtoul(argv[9], 0, 0) : 0x3fu;  // variants to time
   double best[nvar] = {0};
   for (int round = 0; round < 3; ++round)
     for (int v = 0; v < nvar; ++v) {
+      if (!((vmask >> v) & 1) && !(v == 0 && round == 0)) continue;
       gemm_set_variant(v);
       if (round == 0) {  // correctness pass
         CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
@@ -138,6 +140,21 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> ht(words);
     CK(hipMemcpy(ht.data(), dt, words * 8, hipMemcpyDeviceToHost));
     const int nk = K / 64;
+    const int tv = argc > 8 ? atoi(argv[8]) : 3;
+    if (tv == 5) {  // ping-pong kernel: per-phase sums (mid-tile steps | steps carrying an epilogue)
+      const uint32_t* u = (const uint32_t*)ht.data();
+      for (int blk : {0, 77, 200}) for (int w = 0; w < 8; ++w) {
+        const uint32_t* o = u + ((size_t)blk * 8 + w) * 10;
+        printf("PP blk %3d wave %d:", blk, w);
+        for (int i = 0; i < 2; ++i) {
+          const double n = o[i * 5 + 4] ? o[i * 5 + 4] : 1;
+          printf("  %s n=%u mem %.0f bar1 %.0f comp %.0f vm+bar2 %.0f | %.0f", i ? "epi-steps" : "mid-steps", o[i * 5 + 4],
+                 o[i * 5 + 0] / n, o[i * 5 + 1] / n, o[i * 5 + 2] / n, o[i * 5 + 3] / n,
+                 (o[i * 5 + 0] + o[i * 5 + 1] + o[i * 5 + 2] + o[i * 5 + 3]) / n);
+        }
+        printf("\n");
+      }
+    } else
     for (int blk : {0, 77}) for (int w : {0, 4}) {
       double d[8] = {0};
       int cnt = 0;
@@ -149,7 +166,7 @@ int main(int argc, char** argv) {
         d[7] += (double)(rn[0] - r[0]);
         ++cnt;
       }
-      printf("TRACE blk %3d wave %d (avg over %d steps, incl. tile ends): vmwait %.0f  barrier %.0f  issueA %.0f  half0 %.0f  issueB %.0f  half1 %.0f  tail %.0f | step %.0f cyc\n",
+      printf("TRACE blk %3d wave %d (avg over %d steps, incl. tile ends): d0 %.0f  d1 %.0f  d2 %.0f  d3 %.0f  d4 %.0f  d5 %.0f  tail %.0f | step %.0f cyc   [v3: vmwait barrier issueA half0 issueB half1 tail; v5: issue(+epi) reads waits barrier compute vmwait+barrier]\n",
              blk, w, cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, d[6] / cnt, d[7] / cnt);
       // a few steps in full: mid-tile, the tile's last step (tail = epilogue) and the two after it
       for (int st : {nk + 3, 2 * nk - 2, 2 * nk - 1, 2 * nk, 2 * nk + 1}) {
