@@ -1,8 +1,10 @@
 #!/bin/bash
 # scratch driver for one gpurun call
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "linear" 2>&1 | tail -3 > gpurun_out/pytest.log
-cat gpurun_out/pytest.log
-timeout 300 python tools/mlp_probe.py 12 fp16 3 5 > gpurun_out/mlp_probe.txt 2>&1
-cat gpurun_out/mlp_probe.txt
-for v in 3 5; do python bench.py --no-drift --cpu-seconds 0 --gemm-variant $v 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print($v, d['value'], d['sustained_images_per_sec'], d['kernel_ms_per_step'])"; done
+for rep in 1 2; do
+for sh in "2304 768 0" "3072 768 1" "768 3072 2" "768 768 2"; do
+  set -- $sh
+  echo -n "v2  "; timeout 120 tools/gemm_bench_pfv2 100864 $1 $2 $3 20 0 0 3 0x28 2>&1 | grep "BEST"
+  echo -n "v4  "; timeout 120 tools/gemm_bench 100864 $1 $2 $3 20 0 0 3 0x28 2>&1 | grep "BEST"
+done; done > gpurun_out/pp.txt 2>&1
+cat gpurun_out/pp.txt
