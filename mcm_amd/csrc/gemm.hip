@@ -769,189 +769,107 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   }
 }
 
-// ---- epilogues of the ping-pong kernel (full 128x64 wave tiles only).  Every global access is issued from
-// inline asm and waited for by count: hipcc's own waitcnt pass never sees them, so it has no reason to put a
-// vmcnt(0) in front of the fragment reads or the MFMAs of the K loop (it did, once an epilogue with plain
-// stores was inlined into the loop: the wait drains the LDS-DMA stream, -20 % on fc2).
+// fp32-row epilogue of a full (interior) 128x64 wave tile for the ping-pong kernel: the same LDS bounce and
+// the same arithmetic as the fp32 branch of wave_epilogue_lds, but every global access is issued from inline
+// asm and waited for by count.  hipcc's own waitcnt pass never sees them, so it has no reason to put a
+// vmcnt(0) in front of the fragment reads or the MFMAs of the K loop (it did, once the epilogue's plain
+// stores were inlined into the loop: the wait drains the LDS-DMA stream, -20 % on fc2).  The queue at the wait
+// of chunk c, oldest first: [older] [loads c] [stores c-1] [loads c+1]  =>  vmcnt <= 8 (<= 4 at both ends).
 __device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-// s_nop 1: a store of more than 64 bits must be 2 wait states ahead of a VALU write of its data registers
 __device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gstore16_stream(const void* sbase, uint32_t voff, const u32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_pin(f32x4_t (&b)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
 }
-
-// 16-bit outputs without LDS.  After the MFMAs lane (fr, g) holds 16 consecutive columns of row fr of a 16-row
-// unit: two 16-byte segments of that row's 128 bytes.  Lanes fr and fr^8 swap one segment each (DPP row_ror:8
-// with a bank mask, 8 moves per unit), after which the first store instruction carries rows 0-7 and the second
-// rows 8-15 of the unit as whole 128-byte lines (8 lanes per row), streamed past L2 like the LDS-staged form.
-template <int PREC, int EPI, int MF>
-__device__ __forceinline__ void wave_epilogue_16_dpp(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
-                                                     const f32x4_t (&bv)[4], int mw, int nw, int lane) {
-  const int fr = lane & 15, g = lane >> 4;
-  const uint32_t voff = (uint32_t)((fr & 7) * a.ldo + g * 16 + (fr >> 3) * 8) * 2u;  // bytes
-  const char* base = (const char*)a.out + ((size_t)mw * a.ldo + nw) * 2;
-#pragma unroll
-  for (int u = 0; u < MF; ++u) {
-    int d[8];
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-      f32x4_t v = acc[fj][u] + bv[fj];
-      if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = quick_gelu_fast(v[t]);
-      }
-      d[2 * fj] = (int)pack2<PREC>(v[0], v[1]);
-      d[2 * fj + 1] = (int)pack2<PREC>(v[2], v[3]);
-    }
-    u32x4_t lo, hi;  // lo: rows 0-7 of the unit, hi: rows 8-15
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      lo[j] = (uint32_t)__builtin_amdgcn_update_dpp(d[j], d[4 + j], 0x128, 0xF, 0xC, false);
-      hi[j] = (uint32_t)__builtin_amdgcn_update_dpp(d[4 + j], d[j], 0x128, 0xF, 0x3, false);
-    }
-    if (!DBG(16)) {
-      gstore16_stream(base + (size_t)(u * 16) * a.ldo * 2, voff, lo);
-      gstore16_stream(base + (size_t)(u * 16 + 8) * a.ldo * 2, voff, hi);
-    }
-  }
-}
-
-// fp32 rows (fp32 outputs, residual read-modify-write): 16-row units bounced through 4 KiB of LDS scratch so that
-// every global instruction moves whole rows (4 rows x 256 B).  The scratch is four 1-KiB chunks 4 KiB apart
-// (rows 4j .. 4j+3 in chunk j): exactly the LDS-DMA destinations of the calling wave in a stage buffer that is
-// dead at epilogue time (see the kernel), so no LDS is reserved for it.  The residual rows of unit c+1 are
-// requested before unit c is finished.  Queue at the wait of unit c, oldest first:
-// [older] [loads c] [stores c-1] [loads c+1]  =>  vmcnt <= 8 (<= 4 at both ends).
 template <int EPI, int MF>
 __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
-                                                           const f32x4_t& b4, int mw, int nw, int lane,
-                                                           char* scr) {
+                                                           const f32x4_t (&bv)[4], int mw, int nw, int lane,
+                                                           char* scratch) {
   static_assert(EPI != EPI_PATCH, "patch rows are remapped: not an interior form");
-  // b4: bias of the 4 columns nw + (lane & 15) * 4 ..., i.e. in the layout the lanes have AFTER the bounce (the
-  // pre-bounce layout needs 16 bias registers per lane; (acc + bias) + resid is evaluated in the same order)
   const int fr = lane & 15, g = lane >> 4;
   const int rrow = lane >> 4, c16 = lane & 15;
   const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes
   const char* base = (const char*)(EPI == EPI_RESID ? a.resid : (float*)a.out) + ((size_t)mw * a.ldo + nw) * 4;
-  auto rowbase = [&](int c, int j) { return base + (size_t)(c * 16 + j * 4) * a.ldo * 4; };  // rows c*16 + j*4 + rrow
-  auto srow = [&](int row) { return scr + (row >> 2) * 4096 + (row & 3) * 256; };
+  auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
   f32x4_t buf[2][4];
   if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gload16(buf[0][j], rowbase(0, j), voff);
+    for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
   }
 #pragma unroll
   for (int c = 0; c < MF; ++c) {
     if constexpr (EPI == EPI_RESID) {
       if (c + 1 < MF) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gload16(buf[(c + 1) & 1][j], rowbase(c + 1, j), voff);
+        for (int t = 0; t < 4; ++t) gload16(buf[(c + 1) & 1][t], rowbase(c + 1, t), voff);
       }
     }
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) *(f32x4_t*)(srow(fr) + (((g * 4 + fj) ^ fr) << 4)) = acc[fj][c];
-    f32x4_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = j * 4 + rrow;
-      v[j] = *(const f32x4_t*)(srow(row) + ((c16 ^ row) << 4)) + b4;
+    for (int fj = 0; fj < 4; ++fj) {
+      f32x4_t v = acc[fj][c] + bv[fj];
       if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[j][e] = quick_gelu(v[j][e]);
+        for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
       }
+      *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ fr) << 4)) = v;
+    }
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 4 + rrow;
+      v[t] = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
     }
     if constexpr (EPI == EPI_RESID) {
       if (c == 0 || c + 1 == MF) wait_vmcnt_pin<4>(buf[c & 1]);
       else wait_vmcnt_pin<8>(buf[c & 1]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += buf[c & 1][j];
+      for (int t = 0; t < 4; ++t) v[t] += buf[c & 1][t];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gstore16(rowbase(c, j), voff, v[j]);
+    for (int t = 0; t < 4; ++t) gstore16(rowbase(c, t), voff, v[t]);
   }
 }
 
 // =========================================================================================
-// persistent 256x256 "ping-pong" kernel.  Same tile, wave tiles, LDS images and arithmetic as
-// gemm_p256_kernel, different schedule.  A K-step of a wave is a MEMORY part (LDS-DMA issue for the
-// steps ahead, interleaved with the reads that bring the step's fragments into registers) and a
-// COMPUTE part (64 back-to-back MFMAs on registers).  The two waves of a SIMD (w and w+4) run them
-// in opposite order inside one interval between two workgroup barriers:
-//        waves 0-3:  memory(s)    -> compute(s)   | barrier |  memory(s+1)  -> compute(s+1) | ...
-//        waves 4-7:  compute(s-1) -> memory(s)    | barrier |  compute(s)   -> memory(s+1)  | ...
-// so a SIMD always has one wave feeding the matrix pipe, the switch inside an interval needs no
-// synchronisation at all (a wave that finishes its memory part early simply starts computing
-// next to its sibling), and there is ONE barrier per K-step.  Measured on the way here (DESIGN.md
-// section 5.4): with a barrier at every switch the pipe idled ~250 cycles per switch, 2 x per step.
-//
-// Who stages what.  A piece is waited for by its issuer before a barrier and is visible to everybody after it;
-// a stage buffer may be refilled only when a barrier separates the refill from its last reader.  Waves 4-7
-// still read X fragments (second K half) while they compute, i.e. in the interval AFTER the one that loaded the
-// step, so the X rows 128-255 of step s-1 are busy during interval s and nothing waves 4-7 could issue at the
-// end of an interval may land on them: X is staged by waves 0-3 alone, at the start of an interval, one step
-// ahead (rows 0-127: two stages; rows 128-255: ring of three), together with W rows 0-127 (two stages) — 12
-// pieces per wave and step.  Waves 4-7 stage W rows 128-255 (read only in memory parts) two steps ahead, ring
-// of three, waited for one barrier later by count — 4 pieces.  The uneven split costs little here: with no
-// barrier between the parts a long memory part only delays its own wave's compute part.
-// LDS: X(0-127) 2 x 16 KiB, X(128-255) 3 x 16, W(0-127) 2 x 16, W(128-255) 3 x 16 = 160 KiB; the fp32 epilogues
-// borrow this wave's own DMA destinations in the W stage of the tile's last step, dead by then, as scratch.
-// Interior tiles only (M, N multiples of 256).
+// persistent 256x256 "ping-pong" kernel.  Same tile, wave tiles, LDS image and epilogue as
+// gemm_p256_kernel, but the two waves of a SIMD (w and w+4) run half a K-step apart: while one
+// is in its MEMORY phase (8 LDS-DMA pieces for the next step, then the whole step's 24 fragments
+// into 96 registers) the other is in its COMPUTE phase (64 back-to-back MFMAs on registers), and
+// they swap at a workgroup barrier — two barriers per K-step instead of one, but the matrix pipe
+// of a SIMD always has one wave that does nothing but feed it.  Interior tiles only (M, N multiples
+// of 256).
 // =========================================================================================
-namespace pp {
-constexpr int BM = 256, BN = 256;
-constexpr int HALF = 128 * ROWB;            // 16 KiB: 128 rows of one operand, one K-step
-constexpr int OFF_X0 = 0;                   // X rows 0-127, two stages
-constexpr int OFF_X1 = OFF_X0 + 2 * HALF;   // X rows 128-255, ring of three
-constexpr int OFF_W0 = OFF_X1 + 3 * HALF;   // W rows 0-127, two stages
-constexpr int OFF_W1 = OFF_W0 + 2 * HALF;   // W rows 128-255, ring of three
-constexpr int LDS_BYTES = OFF_W1 + 3 * HALF;
-static_assert(LDS_BYTES == 160 * 1024, "the whole LDS of a CU");
-}  // namespace pp
-
-// One LDS-DMA piece with a scalar base + 32-bit lane offset.  m0 (the LDS destination) is written and NOT
-// restored: a memory part brackets its pieces with m0_save / m0_restore instead of paying three scalar moves
-// per piece (a wave issues at most one instruction every ~4 cycles, and the memory part is issue-bound).
-// Nothing between the bracket's ends uses m0: only ds_read / VALU / SALU code sits there.
-__device__ __forceinline__ uint32_t m0_save() {
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_base) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-  return keep;
-}
-__device__ __forceinline__ void m0_restore(uint32_t keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep)); }
-__device__ __forceinline__ void glds16m(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
 }
 
-// harness-only timing of the ping-pong kernel: s_memtime deltas accumulated in scalar registers, written out
-// once at the end (a.pos = uint32 buffer [block][wave][2][5]: 4 sums + step count)
+// harness-only phase timing of the ping-pong kernel: s_memtime deltas accumulated in scalar registers (stamps
+// only where the wave has to drain lgkmcnt anyway), split into mid-tile steps and steps that carry an epilogue;
+// written out once at the end (a.pos = uint32 buffer [block][wave][2][5]: 4 sums + step count)
 #ifdef MCM_GEMM_TRACE
-#ifndef MCM_PPT_MASK
-#define MCM_PPT_MASK 15
-#endif
 #define PPT_INIT()                                  \
   uint32_t ppt_sum[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; \
   uint64_t ppt_prev = __builtin_amdgcn_s_memtime(); \
   int ppt_set = 0
 #define PPT(k)                                                    \
   do {                                                            \
-    if (((MCM_PPT_MASK) >> (k)) & 1) {                            \
-      if (DBG(128)) {                                             \
-        const uint64_t t = __builtin_amdgcn_s_memtime();          \
-        ppt_sum[ppt_set][k] += (uint32_t)(t - ppt_prev);          \
-        ppt_prev = t;                                             \
-      }                                                           \
+    if (DBG(128)) {                                               \
+      if ((k) == 0) ppt_set = pend ? 1 : 0;                       \
+      const uint64_t t = __builtin_amdgcn_s_memtime();            \
+      ppt_sum[ppt_set][k] += (uint32_t)(t - ppt_prev);            \
+      ppt_prev = t;                                               \
+      if ((k) == 3) ppt_sum[ppt_set][4] += 1;                     \
     }                                                             \
-    if ((k) == 3 && DBG(128)) ppt_sum[ppt_set][4] += 1;           \
   } while (0)
 #define PPT_DUMP()                                                                                      \
   do {                                                                                                  \
@@ -969,7 +887,7 @@ __device__ __forceinline__ void glds16m(const void* sbase, uint32_t voff, uint32
 
 template <int PREC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
-  using namespace pp;
+  using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
@@ -988,9 +906,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const int total = ntl * nk;
 
   const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
+  struct Cursor { int mtl, nt; };
+  auto cursor_next = [&](Cursor& c) {
+    c.mtl += dmt;
+    c.nt += dnt;
+    if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
+  };
   auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
   const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
 
+  // ---- LDS-DMA side.  Waves 0-3 (rows 0-127 of the tile) stage their half of the X panel and all of W,
+  // 12 pieces per wave and step; waves 4-7 stage the other X half, which only they read, 4 pieces.  Every
+  // piece is issued in the memory phase of step s for step s+1 and waited for at the end of the issuing
+  // wave's compute phase, one phase before its first reader.
   // Per-lane constants (DMA source offsets, fragment offsets) are NOT kept across the loop: 128 accumulators
   // + 64 fragments leave hipcc no room, and a spilled loop invariant comes back through a scratch load whose
   // vmcnt(0) drains the DMA stream.  They are rebuilt from an opaque copy of the lane id where needed (~12 VALU).
@@ -1007,57 +935,51 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     c.fo1 = frag_off(l & 15, l >> 4, 1);
     return c;
   };
-
-  // ---- LDS-DMA side: the cursor names the (tile, K-step) this group's stream is about to stage
-  struct Cursor { int mtl, nt, ji, kti; const char *tx, *tw; };
-  auto set_tile = [&](Cursor& c) {
-    const int m0 = (mt_of(c.mtl) * 8 + xcd) * BM, n0 = c.nt * BN;
-    c.tx = (const char*)a.x + (size_t)(m0 + w4 * 8) * sx;    // this wave's rows of the X tile (waves 0-3)
-    c.tw = (const char*)a.w + (size_t)(n0 + grp * 128) * sw;  // its group's W half
+  Cursor ci{jx / nbn, jx % nbn};
+  int ji = 0, kti = 0;
+  const char *tx, *tw;  // uniform: first byte of this wave's rows of the tile being staged
+  auto set_issue_tile = [&]() {
+    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
+    tx = (const char*)a.x + (size_t)(m0 + grp * 128 + w4 * 8) * sx;
+    tw = (const char*)a.w + (size_t)n0 * sw;
   };
-  auto advance = [&](Cursor& c) {
-    if (++c.kti == nk) {
-      c.kti = 0;
-      if (++c.ji < ntl) {  // past the last tile the stream re-reads the last one (never used)
-        c.mtl += dmt;
-        c.nt += dnt;
-        if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
-        set_tile(c);
+  const uint32_t lds0 = lds_addr(smem);
+  auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
+    const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
+    const size_t ko = (size_t)kti * ROWB;
+    if (i < 4) {
+      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+    } else {
+      const int q = i - 4;
+      glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
+    }
+  };
+  auto issue_done = [&]() {
+    if (++kti == nk) {
+      kti = 0;
+      if (++ji < ntl) {
+        cursor_next(ci);
+        set_issue_tile();
       }
     }
   };
-  const uint32_t lds0 = lds_addr(smem) + w4 * 1024;
-  // The K offset of a step travels in the lane offset (one VALU add per operand and step), so the scalar base of
-  // a piece depends on the tile only.  X piece i (0-7): rows (i >> 2) * 128 + (i & 3) * 32 + w4 * 8 ...; W piece p
-  // (0-3): W rows grp * 128 + ...
-  auto xpiece = [&](uint32_t vx, const Cursor& c, int slot2, int slot3, int i) {
-    if (DBG(1)) return;
-    glds16m(c.tx + (size_t)(i * 32) * sx, vx,
-            lds0 + (i < 4 ? OFF_X0 + slot2 * HALF : OFF_X1 + slot3 * HALF) + (i & 3) * 4096);
-  };
-  auto wpiece = [&](uint32_t vw, const Cursor& c, int slot, int p) {
-    if (DBG(1)) return;
-    glds16m(c.tw + (size_t)((p >> 1) * 64 + (p & 1) * 8) * sw, vw,
-            lds0 + (grp ? OFF_W1 : OFF_W0) + slot * HALF + p * 4096);
-  };
-  Cursor cur{jx / nbn, jx % nbn, 0, 0, nullptr, nullptr};
-  set_tile(cur);
 
   // ---- MFMA side
-  const int wr = grp, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64: the row half is the staging group
+  const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
+  const int fr = lane & 15, g = lane >> 4;
+  const int xbase = wr * 128 * ROWB;
+  const int wbase = A_BYTES + wc * 64 * ROWB;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
   // Fragments of a step: the W fragments of both K halves and the X fragments of the first half are read in
-  // the memory part (16 reads, 64 registers); the X fragments of the second half replace those of the first
-  // one by one during the compute part (each after its last use) — the rows they come from are staged by this
-  // very wave group, which does not overwrite them before its next memory part.
+  // the memory phase (16 reads, 64 registers); the X fragments of the second half replace those of the first
+  // one by one during the compute phase (each after its last use) — the rows they come from are staged by this
+  // very wave group, so nobody overwrites them before the group's own next memory phase.
   u32x4_t xf[8], wf[2][4];
-  auto xsrc = [&](int sr, int s3) { return smem + (grp ? OFF_X1 + s3 * HALF : OFF_X0 + sr * HALF); };
-  auto wsrc = [&](int sr, int s3) {
-    return smem + (wc < 2 ? OFF_W0 + sr * HALF : OFF_W1 + s3 * HALF) + (wc & 1) * 64 * ROWB;
-  };
-  auto readf = [&](const LaneK& lk, const char* sa, const char* swp, int i) {  // memory-part read i of 16
-    if (i < 4) wf[0][i] = *(const u32x4_t*)(swp + i * 2048 + lk.fo0);
-    else if (i < 12) xf[i - 4] = *(const u32x4_t*)(sa + (i - 4) * 2048 + lk.fo0);
-    else wf[1][i - 12] = *(const u32x4_t*)(swp + (i - 12) * 2048 + lk.fo1);
+  auto readf = [&](const LaneK& lk, int st, int i) {  // memory-phase read i of 16
+    const char* sb = smem + st * STAGE_BYTES;
+    if (i < 4) wf[0][i] = *(const u32x4_t*)(sb + wbase + i * 2048 + lk.fo0);
+    else if (i < 12) xf[i - 4] = *(const u32x4_t*)(sb + xbase + (i - 4) * 2048 + lk.fo0);
+    else wf[1][i - 12] = *(const u32x4_t*)(sb + wbase + (i - 12) * 2048 + lk.fo1);
   };
   auto pin_frags = [&]() {  // the fragments are in registers here, not wherever hipcc would sink the reads to
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1080,184 +1002,152 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], xv[t], c, 0, 0, 0);
     }
   };
-  auto compute = [&](const char* sa) {  // sa: X source of the step being computed (second-half fragments)
-    if (DBG(2)) return;
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    const int fo1 = frag_off(l & 15, l >> 4, 1);
-    // a computing wave outranks a wave in its memory part, and of two computing waves the younger (w+4) outranks
-    // the older: left alone the issue arbiter serves the older wave first and the younger one's MFMAs wait even
-    // for the older wave's scalar bookkeeping (measured: 2450 cycles for its 64 MFMAs)
-#ifndef MCM_PP_PRIO
-#define MCM_PP_PRIO 1
-#endif
-    if (MCM_PP_PRIO) {
-      if (grp) __builtin_amdgcn_s_setprio(3);
-      else __builtin_amdgcn_s_setprio(2);
-    }
+  auto compute = [&](int fo1, int st) {
+    const char* sb = smem + st * STAGE_BYTES;
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi) {
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) mfma_pair(wf[0][fj], xf[fi], acc[fj][fi]);
-      xf[fi] = *(const u32x4_t*)(sa + fi * 2048 + fo1);
+      xf[fi] = *(const u32x4_t*)(sb + xbase + fi * 2048 + fo1);
     }
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) mfma_pair(wf[1][fj], xf[fi], acc[fj][fi]);
-    if (MCM_PP_PRIO) __builtin_amdgcn_s_setprio(0);
-  };
-  // memory part of step s: fragments of step s from (sr, s3) interleaved with this wave's pieces for the step at
-  // `cur` (a ds_read first, then alternate: the TA and the LDS queue drain side by side).  n2 / n3: the 2-stage
-  // and ring-of-3 slots to fill.
-  auto memory = [&](int sr, int s3, int n2, int n3) {
-    const LaneK lk = lane_consts();
-    const char* sa = xsrc(sr, s3);
-    const char* swp = wsrc(sr, s3);
-    const uint32_t vx = lk.voff_x + cur.kti * ROWB, vw = lk.voff_w + cur.kti * ROWB;
-    const uint32_t keep = m0_save();
-    if (!grp) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        if (i < 8) {
-          readf(lk, sa, swp, 2 * i);
-          readf(lk, sa, swp, 2 * i + 1);
-          xpiece(vx, cur, n2, n3, i);
-        } else {
-          wpiece(vw, cur, n2, i - 8);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) readf(lk, sa, swp, 4 * i + j);
-        wpiece(vw, cur, n3, i);
-      }
-    }
-    m0_restore(keep);
-    advance(cur);
-    pin_frags();
   };
 
-  // ---- the tile being computed and its epilogue
-  int cmtl = jx / nbn, cnt = jx % nbn, ktc = 0;
-  f32x4_t bv[4];  // bias: asm loads issued at the top of a tile's last compute part
+  Cursor cc{jx / nbn, jx % nbn};
+  int em0 = 0, en0 = 0;  // tile whose epilogue is pending
+  f32x4_t bv[4];  // bias of the pending tile: asm loads issued at the top of its last compute phase
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  constexpr bool EPI16 = PREC != MCM_PREC_F32 && EPI <= EPI_GELU;
-  auto bias_prefetch = [&]() {
-    if (ktc != nk - 1 || !a.bias) return;
+  auto epilogue = [&]() {
+    // every lane-derived address of the epilogue is recomputed from an opaque copy of the lane id: hoisted out
+    // of the K loop they would occupy ~20 registers that the loop (128 accumulators + 64 fragments) does not have
     int le = lane;
     asm volatile("" : "+v"(le));
-    // 16-bit epilogue: the 16 columns a lane owns after the MFMAs; fp32-row epilogue: the 4 columns it owns
-    // after the LDS bounce
-    if constexpr (EPI16) load_bias_async(a, cnt * BN + wc * 64 + (le >> 4) * 16, bv);
-    else gload16(bv[0], a.bias + cnt * BN + wc * 64, (uint32_t)(le & 15) * 16u);
-  };
-  // after compute(s): true when that was the tile's last step; (em0, en0) then name the finished tile
-  int em0 = 0, en0 = 0;
-  auto step_done = [&]() {
-    if (++ktc < nk) return false;
-    ktc = 0;
-    em0 = (mt_of(cmtl) * 8 + xcd) * BM;
-    en0 = cnt * BN;
-    cmtl += dmt;
-    cnt += dnt;
-    if (cnt >= nbn) { cnt -= nbn; ++cmtl; }
-    return true;
-  };
-  auto epilogue = [&](int wslot) {  // wslot: this group's W stage of the tile's last step (dead: fp32 scratch)
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    constexpr int NB = EPI16 ? 4 : 1;  // bias registers of this epilogue form
 #pragma unroll
-    for (int fj = 0; fj < NB; ++fj) asm volatile("" : "+v"(bv[fj]));
+    for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
     if (!DBG(4)) {
-      if constexpr (EPI16)
-        wave_epilogue_16_dpp<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le);
+      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+      if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
+        wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
       else
-        wave_epilogue_f32_interior<EPI, 8>(a, acc, bv[0], em0 + wr * 128, en0 + wc * 64, le,
-                                           smem + (grp ? OFF_W1 : OFF_W0) + wslot * HALF + w4 * 1024);
+        wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
     }
     zero_acc<8>(acc);
   };
-  auto barrier = [&]() {
+#ifdef MCM_HARNESS
+  if (a.dbg >> 8) {  // harness: de-phase the workgroups of an XCD, (dbg >> 8) x 1024 cycles per step of jx & 3
+    const uint64_t until = __builtin_amdgcn_s_memtime() + (uint64_t)((jx >> 3) & 3) * (uint64_t)(a.dbg >> 8) * 1024u;
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+  set_issue_tile();
+  {
+    const LaneK lk = lane_consts();
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      if (i < 4 || !grp) piece(lk, 0, i);
+  }
+  issue_done();
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp) {  // waves 4-7 run one phase behind
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int ktc = 0;
+  bool pend = false;
+  auto phase_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-
-  {  // prologue: step 0 (and step 1 of the two-ahead stream) land before anybody reads
-    const LaneK lk = lane_consts();
-    const uint32_t keep = m0_save();
-    if (!grp) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xpiece(lk.voff_x, cur, 0, 0, i);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) wpiece(lk.voff_w, cur, 0, p);
-    advance(cur);
-    if (grp) {
-      const uint32_t ko = cur.kti * ROWB;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) wpiece(lk.voff_w + ko, cur, 1, p);
-      advance(cur);
-    }
-    m0_restore(keep);
-  }
-  wait_vmcnt<0>();
-  barrier();
   PPT_INIT();
-  bool pend = false;
-  if (!grp) {
-    // waves 0-3: [epilogue] memory(s) compute(s) | barrier        — n3 = (s + 1) % 3
-    int s3 = 0, n3 = 1;  // s % 3 (the W(128-255) ring slot to read)
-    for (int s = 0; s < total; ++s) {
-      const int sr = s & 1;
-      if (pend) epilogue(sr ^ 1);
-      memory(sr, s3, sr ^ 1, n3);
-      PPT(0);
-      bias_prefetch();
-      compute(xsrc(sr, 0));
-      PPT(1);
-      if (!DBG(32)) wait_vmcnt<0>();  // this interval's pieces (step s+1), issued a compute part ago
-      barrier();
-      PPT(3);
-      pend = step_done();
-      s3 = n3;
-      n3 = n3 == 2 ? 0 : n3 + 1;
+  for (int s = 0; s < total; ++s) {
+    // ---- memory phase of step s: the step's fragments into registers, interleaved with the DMA issues for
+    // step s+1 (a DMA issue blocks the wave on the TA, a ds_read on the LDS queue: alternating them lets the two
+    // queues drain side by side).  The first instruction is a ds_read on purpose: hipcc puts a vmcnt(0) in
+    // front of the first fragment read after an epilogue with compiler-visible stores, which must not have
+    // this phase's DMA to wait for.  After the very last step the issue re-reads the last tile (never used).
+    // At a tile boundary (`pend`) waves 0-3 issue, pass the barrier, run the epilogue and only then read the
+    // fragments; waves 4-7 run the epilogue first: both epilogues fall into the same phase and no fragment
+    // is live across them.
+    const int sr = s & 1, si = sr ^ 1;
+    const bool split = pend && !grp;
+    int fo1;
+    if (pend) {
+      if (!grp) {
+        const LaneK lk = lane_consts();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) piece(lk, si, i);
+        issue_done();
+        phase_barrier();
+      }
+      epilogue();
+      if (!grp) {
+        const LaneK lk = lane_consts();
+        fo1 = lk.fo1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) readf(lk, sr, i);
+      }
     }
-    if (pend) epilogue((total - 1) & 1);
-  } else {
-    // waves 4-7: compute(s-1) [epilogue] memory(s) | barrier   — s3 = s % 3, p3 = (s - 1) % 3
-    int s3 = 0, p3 = 2;
-    for (int s = 0; s < total; ++s) {
-      if (s > 0) {
-        bias_prefetch();
-        compute(xsrc(0, p3));
-        PPT(1);
-        if (step_done()) {
-          wait_vmcnt<0>();  // the bias (and, older, the pieces of step s)
-          epilogue(p3);
+    if (!split) {
+      const LaneK lk = lane_consts();
+      fo1 = lk.fo1;
+      if (!grp) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          if (i < 8) {
+            readf(lk, sr, 2 * i);
+            readf(lk, sr, 2 * i + 1);
+          }
+          piece(lk, si, i);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
+          piece(lk, si, i);
         }
       }
-      memory(s & 1, s3, 0, s3 == 0 ? 2 : s3 - 1);  // W pieces of step s+2 into ring slot (s+2) % 3
-      PPT(0);
-      if (!DBG(32)) wait_vmcnt<4>();  // the pieces of step s+1, issued an interval ago; this interval's may fly
-      barrier();
-      PPT(3);
-      p3 = s3;
-      s3 = s3 == 2 ? 0 : s3 + 1;
+      issue_done();
     }
-    bias_prefetch();
-    compute(xsrc(0, p3));
-    pend = step_done();
-    wait_vmcnt<0>();
-    if (pend) epilogue(p3);
+    pin_frags();
+    PPT(0);
+    if (!split) phase_barrier();
+    PPT(1);
+    // ---- compute phase of step s
+    if (ktc == nk - 1 && a.bias) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
+    }
+    __builtin_amdgcn_s_setprio(1);
+    compute(fo1, sr);
+    __builtin_amdgcn_s_setprio(0);
+    PPT(2);
+    wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
+    phase_barrier();
+    PPT(3);
+    pend = false;
+    if (++ktc == nk) {
+      ktc = 0;
+      pend = true;
+      em0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
+      en0 = cc.nt * BN;
+      cursor_next(cc);
+    }
   }
-  wait_vmcnt<0>();  // no LDS-DMA of this wave may still be in flight when its LDS is released
+  if (!grp) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (pend) epilogue();
   PPT_DUMP();
 }
 
@@ -1327,11 +1217,11 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), pp::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
