@@ -308,7 +308,7 @@ def main():
             peak = MFMA_PEAK_TFLOPS[args.precision]
             traffic, traffic_src = pmc_traffic("gemm") if B == 512 else (None, None)
             line["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_p256_kernel family (all GEMM launches of a step)",
+                "bound": "mfma", "kernel": "persistent 256x256 GEMM family: gemm_pp_kernel + gemm_p256_kernel (all GEMM launches of a step)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak if ach else None,
                 "traffic": traffic, "traffic_source": traffic_src,

@@ -153,10 +153,8 @@ struct Scope {
 // Consecutive kernels of a tower walk their rows in opposite directions: a producer's last rows are
 // the ones still in L2 / Infinity Cache, so its consumer starts there (results do not depend on the
 // order).  `flip` alternates per launch.  Measured: LayerNorm 2.19 -> 1.99 ms per step (it reads the
-// residual stream the previous GEMM just wrote), +0.9 % end to end; MCM_ALT_DIR=0 turns it off.
+// residual stream the previous GEMM just wrote), +0.9 % end to end.
 bool next_dir(mcm_handle* h) {
-  static const bool on = [] { const char* e = getenv("MCM_ALT_DIR"); return e ? atoi(e) != 0 : true; }();
-  if (!on) return false;
   h->flip = !h->flip;
   return h->flip;
 }

@@ -1,10 +1,8 @@
 #!/bin/bash
 # scratch driver for one gpurun call
 mkdir -p gpurun_out
-for rep in 1 2; do
-for sh in "2304 768 0" "3072 768 1" "768 3072 2" "768 768 2"; do
-  set -- $sh
-  echo -n "v2  "; timeout 120 tools/gemm_bench_pfv2 100864 $1 $2 $3 20 0 0 3 0x28 2>&1 | grep "BEST"
-  echo -n "v2a "; timeout 120 tools/gemm_bench 100864 $1 $2 $3 20 0 0 3 0x28 2>&1 | grep "BEST\|differing elem" | grep -v "variant 3" | tr '\n' ' '; echo
-done; done > gpurun_out/pp.txt 2>&1
-cat gpurun_out/pp.txt
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 > gpurun_out/pytest.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
+bash tools/profile.sh r02_b > gpurun_out/profile.log 2>&1
+timeout 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+cat gpurun_out/pytest.log; tail -4 gpurun_out/smoke.log; tail -5 gpurun_out/profile.log; cat gpurun_out/bench_default.json

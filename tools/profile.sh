@@ -18,11 +18,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $out/fetch -o f -- $bench > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $out/write -o w -- $bench > $out/write.log 2>&1
 cd $root
-stats=$(find $out/trace -name "*kernel_stats.csv" | head -1)
-[ -n "$stats" ] && cp $stats profiles/${tag}_kernel_stats.csv
-sq=$(find $out/sq -name "*counter_collection.csv" | head -1)
-fe=$(find $out/fetch -name "*counter_collection.csv" | head -1)
-wr=$(find $out/write -name "*counter_collection.csv" | head -1)
+# rocprofv3 7.2 writes rocpd SQLite databases by default (older builds: CSV); the summary tools read either
+first() { find $1 \( -name "*_results.db" -o -name "$2" \) | head -1; }
+tr=$(first $out/trace "*kernel_stats.csv")
+sq=$(first $out/sq "*counter_collection.csv")
+fe=$(first $out/fetch "*counter_collection.csv")
+wr=$(first $out/write "*counter_collection.csv")
+case "$tr" in
+  *.db) python tools/rocpd_summary.py $tr > profiles/${tag}_kernel_stats.txt ;;
+  *.csv) cp $tr profiles/${tag}_kernel_stats.csv ;;
+esac
 [ -n "$sq" ] && python tools/pmc_summary.py $sq > profiles/${tag}_pmc_sq.txt
 [ -n "$fe" ] && [ -n "$wr" ] && python tools/pmc_summary.py $fe $wr > profiles/${tag}_pmc_traffic.txt
 [ -n "$fe" ] && [ -n "$wr" ] && python tools/traffic_json.py $fe $wr profiles/${tag}_traffic.json > /dev/null
