@@ -219,6 +219,40 @@ def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi, prec):
         tiny_net._lib.mcm_debug_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("N,K,epi", [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2)])
+def test_linear_l14_shapes_pingpong_bitwise(tiny_net, N, K, epi):
+    """BASELINE config 4 (ViT-L/14, batch 256: M = 256 * 257 rows, K = 1024 / 4096): the ping-pong kernel against
+    the one-workgroup-per-tile kernel, bit for bit, fp16 operands — other K-loop lengths (16 / 64 steps), other
+    tile counts per workgroup and another walk direction than the B/16 cases above."""
+    M = 256 * 257
+    dt = DTYPE["fp16"]
+    g = torch.Generator(device="cuda").manual_seed(N * 3 + K + epi)
+    x = torch.randn((M, K), generator=g, device="cuda").to(dt)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dt)
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
+
+    def run(variant):
+        assert tiny_net._lib.mcm_debug_gemm_variant(variant) == 0
+        y = torch.zeros((M, N), device="cuda", dtype=dt)
+        rd = resid0.clone() if epi == 2 else y
+        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC["fp16"], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                         _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+        torch.cuda.synchronize()
+        return rd if epi == 2 else y
+
+    try:
+        ref = run(0)
+        assert torch.isfinite(ref.float()).all()
+        for _ in range(2):  # mcm_op_linear alternates the walk direction per launch: both get exercised
+            got = run(5)
+            view = torch.int32 if epi == 2 else torch.int16
+            assert torch.equal(got.view(view), ref.view(view))
+    finally:
+        tiny_net._lib.mcm_debug_gemm_variant(-1)
+
+
 ATTN_CASES = [(3, 197, 12, False), (2, 50, 12, False), (5, 17, 2, False), (4, 77, 8, True),
               (6, 16, 8, True), (2, 257, 16, False), (3, 33, 2, True)]
 
