@@ -94,7 +94,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 2, 4], ids=["tile128", "persist256x128", "persist256x256"])
+@pytest.fixture(params=[0, 2, 4, 5], ids=["tile128", "persist256x128", "persist256x256", "pingpong256x256"])
 def gemm_variant(request, tiny_net):
     """Every GEMM kernel variant must pass the same parity cases (the auto policy picks by
     problem size, so small test shapes would otherwise only exercise the tile kernel)."""
@@ -138,13 +138,16 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)      # fp32 accumulation order
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (768, 512, 3072), (2048, 256, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (768, 512, 3072), (2048, 256, 64),
+                                   (300, 256, 128), (1, 512, 256), (700, 768, 768), (129, 256, 3072)])
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_linear_pingpong_interior_shapes_vs_oracle(tiny_net, M, N, K, prec, epi):
-    """The ping-pong 256x256 kernel only takes problems made of whole tiles (the shapes of GEMM_SHAPES fall
-    back to the plain persistent kernel under variant 5), so it gets its own oracle cases: one tile, a few
-    tiles on a few workgroups, a long K, a single K-step."""
+    """The ping-pong 256x256 kernel only takes problems made of whole tiles, so it gets its own oracle cases:
+    one tile, a few tiles on a few workgroups, a long K, a single K-step.  The shapes with a partial last M tile
+    check the routing: under variant 5 they must come out right through the plain persistent kernel.  (Partial
+    M tiles inside the ping-pong kernel were built and measured: the second epilogue form cost the whole-tile
+    path 3 - 5 %, DESIGN.md section 5.4.)"""
     from oracle import oracle as orc
 
     rng = np.random.default_rng(M + N * 5 + K * 11 + epi)
