@@ -375,20 +375,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
                       : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
     constexpr int NS = (NT + 1) / 2;
     const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // O^T = V^T · P^T for the four 16-dim blocks and the row sum (all-ones A operand), key step by key step: five
+    // independent accumulator chains in flight, so no MFMA waits for the one just issued (dim-block-outer order
+    // made each of the 7 steps of a chain wait out the previous step's latency)
     f32x4_t lacc = zero;
+    f32x4_t o[4] = {zero, zero, zero, zero};
 #pragma unroll
-    for (int u = 0; u < NS; ++u) lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), MCM_PSTEP(u), lacc);
-    // O^T = V^T · P^T, 16 dims at a time
-    f32x4_t o[4];
+    for (int u = 0; u < NS; ++u) {
+      const uint4 pu = MCM_PSTEP(u);
+      lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), pu, lacc);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      o[dt] = zero;
-      const char* vp = vlane[dt];
-#pragma unroll
-      for (int u = 0; u < NS; ++u) {
+      for (int dt = 0; dt < 4; ++dt) {
+        const char* vp = vlane[dt];
         const uint2 lo = tr_read16(vp + (2 * u) * 2048);
         const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
-        o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), MCM_PSTEP(u), o[dt]);
+        o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pu, o[dt]);
       }
     }
 #undef MCM_PSTEP
@@ -504,6 +505,8 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
   return hipGetLastError();
 }
 
+int g_attn_variant = 1;  // 1 = attn_tr_kernel (round 2), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
+
 // Waves per workgroup.  The q-blocks of a sequence are dealt round-robin to the waves, so the slowest wave has
 // ceil(q-blocks / waves) of them.  Measured at B/16 batch 512 / L/14 batch 256 (tools/attn_probe.py, same
 // box, old kernel 215 / 295 us): 4 waves (4-3-3-3 blocks) 164 - 167 / 183 - 186 us, 5 - 6 waves 171 - 178, 7 waves
@@ -522,7 +525,6 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   return hipErrorInvalidValue;
 }
 
-int g_attn_variant = 1;  // 1 = attn_tr_kernel (round 2), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
 
 }  // namespace
 
