@@ -1,8 +1,16 @@
 #!/bin/bash
 # scratch driver for one gpurun call
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > gpurun_out/pytest.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
-bash tools/profile.sh r02_c > gpurun_out/profile.log 2>&1
-timeout 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-cat gpurun_out/pytest.log; tail -2 gpurun_out/smoke.log; tail -8 gpurun_out/profile.log; cat gpurun_out/bench_default.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['sustained_images_per_sec'], d['kernel_ms_per_step'], d['roofline']['frac'], d['parity']['d_auroc'])"
+timeout 900 python - > gpurun_out/drift_L14.json 2> gpurun_out/drift_L14.err <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+from mcm_amd.parity import measure_drift, HEADLINE_PIXELS
+print(json.dumps(measure_drift("ViT-L/14", n_id=20000, n_ood=5000, batch=256, arms=("fp16", "bf16"), **HEADLINE_PIXELS)))
+PY
+timeout 900 python - > gpurun_out/drift_B32.json 2> gpurun_out/drift_B32.err <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+from mcm_amd.parity import measure_drift, HEADLINE_PIXELS
+print(json.dumps(measure_drift("ViT-B/32", n_id=50000, n_ood=10000, batch=512, arms=("fp16", "bf16"), **HEADLINE_PIXELS)))
+PY
+cat gpurun_out/drift_L14.json gpurun_out/drift_B32.json; tail -2 gpurun_out/drift_L14.err
