@@ -394,15 +394,28 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     }
 #undef MCM_PSTEP
     const float rl = 1.0f / lacc[0];
-    if (q < L) {
-      uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64 + g * 4;
+    // A lane holds 4 dims (8 B) of each of the four 16-dim blocks.  Lanes g and g^1 (16 lanes apart) trade one
+    // block of each pair by v_permlane16_swap, after which a lane owns 8 consecutive dims (16 B) of ONE block:
+    // two 16-byte stores per lane and q-block instead of four 8-byte ones, 64 contiguous bytes per row and store.
+    uint32_t pk[4][2];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
-        pk.y = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
-        *(uint2*)(orow + dt * 16) = pk;
-      }
+    for (int dt = 0; dt < 4; ++dt) {
+      pk[dt][0] = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
+      pk[dt][1] = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
+    }
+    uint4 wide[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      // vdst = block 2pr, src = block 2pr+1: the odd rows of vdst and the even rows of src change places
+      const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+      const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+      wide[pr] = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+    }
+    if (q < L) {
+      uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)  // even g: block 2pr, dims g*4 .. g*4+7; odd g: block 2pr+1, dims (g-1)*4 ..
+        *(uint4*)(orow + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = wide[pr];
     }
   }
 }
