@@ -42,7 +42,20 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        # gloo's C++ side prints "[Gloo] Rank r is connected ..." on fd 1; callers such as bench.py promise ONE
+        # JSON line on stdout, so anything the rendezvous writes goes to stderr instead
+        import sys
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+            if backend == "gloo":
+                dist.barrier()  # the connection messages are printed lazily, on the first collective
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, ws, local
 
 
