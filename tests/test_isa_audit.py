@@ -1,0 +1,62 @@
+"""ISA audit of the ping-pong GEMM kernels (CPU: hipcc cross-compiles gfx950 without a GPU).
+
+The kernel's speed rests on two properties of the generated code that no numerical test sees:
+no scratch traffic in the K loop (a spilled loop invariant comes back through a scratch load whose vmcnt(0)
+drains the LDS-DMA stream) and no compiler-inserted vmcnt wait (a compiler-visible global access in the loop
+makes hipcc put vmcnt(0) in front of fragment reads / MFMAs).  Both showed up during development as silent
+10 - 30 % losses that depended on unrelated code, so the library build is checked for them here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def gemm_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa")
+    # the flags of mcm_amd/csrc/Makefile (no -DMCM_HARNESS: the shipped code, not the harness build)
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "mcm_amd", "csrc"),
+           "-c", os.path.join(ROOT, "mcm_amd", "csrc", "gemm.hip"), "-o", str(out / "gemm.o"), "-save-temps=obj"]
+    subprocess.run(cmd, check=True, cwd=str(out), capture_output=True, timeout=600)
+    asm = [f for f in os.listdir(out) if f.endswith("gfx950.s")]
+    assert asm, os.listdir(out)
+    return open(out / asm[0]).read()
+
+
+def _kernel(isa, prec, epi):
+    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dEEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi), isa, re.S | re.M)
+    assert m, "gemm_pp_kernel<%d,%d> not found" % (prec, epi)
+    return m.group(0)
+
+
+@pytest.mark.parametrize("prec", [0, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("epi", [0, 1], ids=["store", "gelu"])
+def test_pingpong_16bit_kernels_have_no_scratch_and_only_the_two_hand_written_waits(gemm_isa, prec, epi):
+    body = _kernel(gemm_isa, prec, epi)
+    assert "scratch_" not in body
+    assert len(re.findall(r"s_waitcnt vmcnt", body)) == 2  # prologue + end of the compute phase
+    assert len(re.findall(r"v_mfma_f32_16x16x32", body)) == 64  # one compute phase, no duplicated loop bodies
+
+
+@pytest.mark.parametrize("prec", [0, 2], ids=["bf16", "fp16"])
+def test_pingpong_residual_kernel_spills_only_inside_its_epilogue(gemm_isa, prec):
+    body = _kernel(gemm_isa, prec, 2)
+    lines = body.splitlines()
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32" in l]
+    dma = [i for i, l in enumerate(lines) if "global_load_lds_dwordx4" in l]
+    assert len(mfma) == 64
+    # the hot loop = from the last block of LDS-DMA issues before the MFMAs to the last MFMA: no scratch there,
+    # and no vmcnt wait between the DMA issues and the MFMAs
+    start = max(i for i in dma if i < mfma[0]) - 200
+    hot = lines[start:mfma[-1] + 1]
+    assert not any("scratch_" in l for l in hot)
+    between = lines[max(i for i in dma if i < mfma[0]):mfma[0]]
+    assert not any("s_waitcnt vmcnt" in l for l in between)
+    assert sum("scratch_" in l for l in lines) <= 8
