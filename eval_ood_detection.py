@@ -113,7 +113,14 @@ def _loader(args, net, what, n, ood, sources):
     if not args.synthetic and os.path.isdir(path) and args.in_dataset.startswith("ImageNet"):
         from mcm_amd.folder import ImageFolderU8
 
-        loader = ImageFolderU8(path, net, args.batch_size)
+        from mcm_amd.folder import FolderIndex
+
+        index = FolderIndex(path)
+        if what == "train" and args.subset and args.in_dataset == "ImageNet":
+            # reference utils/train_eval_util.py:54-64: the first max_count images of every class — and, like
+            # there, only for ImageNet (its ImageNet10/20/100 branch ignores `subset`)
+            index = index.first_per_class(args.max_count)
+        loader = ImageFolderU8(index, net, args.batch_size)
         sources[what] = {"kind": "folder", "path": path, "n": len(loader.dataset)}
         return loader
     if args.synthetic_n:

@@ -180,9 +180,12 @@ int mcm_reduce_bank(mcm_handle* h, const float* feats_dev, int32_t K, int32_t T,
  * (get_and_print_results, :255: the stored scores are negated confidences).
  * out_host[0..2] = AUROC, AUPR, FPR at the operating point whose recall is closest to
  * recall_level (0.95 in the reference), same tie rules as the reference.  Synchronises `stream`.
- * Scratch (12 bytes per score) is taken from the activation workspace mcm_create sized — nothing is
- * allocated; MCM_ERANGE when n_pos + n_neg does not fit it (the B/16 batch-512 workspace holds
- * 25 million scores). */
+ * Scratch (12 bytes per score) is borrowed from the activation workspace mcm_create sized (the B/16
+ * batch-512 workspace holds 25 million scores); larger inputs get a one-off stream-ordered allocation
+ * (hipMallocAsync / hipFreeAsync on `stream`).
+ * STREAM REQUIREMENT: because the scratch is the workspace of the encode / score calls, `stream` must be
+ * the stream those calls were issued on (or be ordered after them by an event): stream order is the only
+ * thing that keeps mcm_measures from overwriting a tower's activations in flight. */
 int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float* neg_dev,
                  int64_t n_neg, int32_t negate, double recall_level, double* out_host, void* stream);
 
@@ -270,16 +273,18 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
                      int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
                      void* stream);
 
-/* Testing hook: force the GEMM kernel variant (-1 auto [default], 0 = 128x128 tile kernel,
- * 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 3/4 = persistent 256x256
- * 2-stage (4: counted epilogue stores), 5 = persistent 256x256 ping-pong (problems whose M and N
- * are multiples of 256; others run as 3)).  Process-wide.
+#ifdef MCM_HARNESS
+/* libmcm_hip_harness.so only (built with -DMCM_HARNESS next to the shipped library; loaded by the A/B tests
+ * and tools, never by the product path).  Process-wide switches.
+ * GEMM variant: -1 the shipped size policy, 0 = 128x128 tile kernel, 1/2 = persistent 256x128 3-stage
+ * (2: counted epilogue stores), 3/4 = persistent 256x256 2-stage (4: counted epilogue stores),
+ * 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3),
+ * 6 = the ping-pong loop on 32x32x16 MFMAs (16-bit modes; others run as 5).
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
-/* Testing hook: 16-bit attention kernel — 1 (default) = the transpose-read kernel (K and V by LDS-DMA,
- * ds_read_b64_tr_b16, row sums on the matrix pipe), 0 = the round-1 kernel (V transposed while staged),
- * kept as the A/B arm of tests/test_gpu_kernels.py.  Process-wide. */
+/* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel. */
 int mcm_debug_attention_variant(int32_t variant);
+#endif
 
 #ifdef __cplusplus
 }

@@ -3,26 +3,21 @@
 //
 // Replaces CLIPAttention's SDPA (HF modeling_clip.py:259-277 eager definition, :313-331;
 // causal for the text tower :543-556).  One workgroup per (sequence, head): the whole K
-// and V of the head live in LDS (<= 62 KiB at 197 keys), so nothing is re-read and the
+// and V of the head live in LDS (52 KiB at 197 keys), so nothing is re-read and the
 // [L,L] score matrix never exists in HBM.
 //
-// bf16 path (MFMA 16x16x32): each wave owns 16-query blocks.
+// 16-bit path (attn_tr_kernel, MFMA 16x16x32): each wave owns 16-query blocks.
 //   S^T = K·Q^T   (K fragment as A, Q fragment as B)  → a lane holds, for ONE query
 //                 (lane&15), 4 consecutive keys per 16-key tile: the softmax row lives in
-//                 registers, the max/sum need only 2 cross-lane steps (xor 16, 32);
-//   P (bf16) stays in those registers and is fed straight back as the B operand of
-//   O^T = V^T·P^T (V^T fragment as A): the MFMA contraction index is a free permutation,
-//                 so the key order "4 keys of tile 2u, 4 keys of tile 2u+1" is used for
-//                 both operands; V is transposed once while being staged into LDS.
-//   A lane ends with 4 consecutive head-dims of one query → 8-byte stores.
-// fp32 path (parity arm): plain fp32 VALU kernel, same staging idea, exact expf.
-//
-// Measured anatomy (B/16, 197 keys, 6144 workgroups, 2 resident per CU; ablations in round 1):
-// 216 us per layer, of which the load-only skeleton (Q/K/V into registers/LDS + softmax VALU on
-// dummy data) is already 129 us = 3.6 TB/s: the kernel is bound by how much memory traffic two
-// resident workgroups keep in flight, not by MFMA (QK 23 us, PV 37 us, stores 23 us on top).
-// Next step (round 2): persistent workgroups that prefetch the next head's K/V under the
-// current head's MFMAs.
+//                 registers, the max needs only 2 cross-lane steps (xor 16, 32);
+//   P (16-bit) stays in those registers and is fed straight back as the B operand of
+//   O^T = V^T·P^T; V stays row-major in LDS and the V^T fragments come from the gfx950
+//                 transpose read (ds_read_b64_tr_b16); the softmax denominator is one more
+//                 MFMA per key step (all-ones A operand).
+// fp32 path (parity arm and the text tower): plain fp32 VALU kernel, exact expf.
+// The round-1 kernel (attn_bf16_kernel: V transposed while staged through registers) exists in the
+// harness build only (-DMCM_HARNESS), as the A/B arm of tests/test_gpu_kernels.py.
+// Measurements: DESIGN.md section 4.2.
 #include "common.hpp"
 
 namespace {
@@ -32,6 +27,7 @@ __device__ __forceinline__ int ktile_off(int r, int c) {  // same image as the G
   return p * 256 + ((((r & 1) << 3) | ((c ^ p) & 7)) << 4);
 }
 
+#ifdef MCM_HARNESS  // round-1 kernel: A/B arm only
 __host__ __device__ constexpr int vt_stride(int LP) {  // bytes; ≡ 16 (mod 256): ds_read_b64
   return ((LP * 2 - 16 + 255) / 256) * 256 + 16;       // of 16 rows x 2 groups is conflict-free
 }
@@ -208,6 +204,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     }
   }
 }
+
+#endif  // MCM_HARNESS
 
 // =========================================================================================
 // Round-2 kernel: K AND V by LDS-DMA (no register staging, no transposing LDS writes), V^T
@@ -472,6 +470,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
+#ifdef MCM_HARNESS
 template <int PREC, int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
                        int qrows, hipStream_t s, int rev) {
@@ -494,6 +493,8 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
   return hipGetLastError();
 }
+
+#endif
 
 template <int PREC, int NT, int NW, int OCC>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
@@ -518,7 +519,9 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
   return hipGetLastError();
 }
 
-int g_attn_variant = 1;  // 1 = attn_tr_kernel (round 2), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
+#ifdef MCM_HARNESS
+int g_attn_variant = 1;  // 1 = attn_tr_kernel (shipped), 0 = attn_bf16_kernel (round 1; A/B arm of the tests)
+#endif
 
 // Waves per workgroup.  The q-blocks of a sequence are dealt round-robin to the waves, so the slowest wave has
 // ceil(q-blocks / waves) of them.  Measured at B/16 batch 512 / L/14 batch 256 (tools/attn_probe.py, same
@@ -541,18 +544,16 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
 
 }  // namespace
 
+#ifdef MCM_HARNESS
 void attention_set_variant(int v) { g_attn_variant = v; }
+#endif
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
                             bool causal, int qrows, hipStream_t s, bool reverse) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
-  if (prec != MCM_PREC_F32 && g_attn_variant >= 1) {
-    if (prec == MCM_PREC_F16)
-      return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
-    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
-  }
-  if (prec != MCM_PREC_F32) {
+#ifdef MCM_HARNESS
+  if (prec != MCM_PREC_F32 && g_attn_variant == 0) {
 #define MCM_ATTN_BY_LP(P)                                                                      \
   do {                                                                                          \
     if (L <= 32) return launch_bf16<P, 32>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);         \
@@ -565,7 +566,13 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   } while (0)
     if (prec == MCM_PREC_F16) MCM_ATTN_BY_LP(MCM_PREC_F16);
     MCM_ATTN_BY_LP(MCM_PREC_BF16);
+#undef MCM_ATTN_BY_LP
   }
+#endif
+  if (prec == MCM_PREC_F16)
+    return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
+  if (prec == MCM_PREC_BF16)
+    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;

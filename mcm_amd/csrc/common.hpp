@@ -135,11 +135,12 @@ struct GemmArgs {
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
-#ifdef MCM_HARNESS  // tools/gemm_bench.hip only
+#ifdef MCM_HARNESS  // tools/gemm_bench.hip and libmcm_hip_harness.so only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
+void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 6: see gemm.hip
+void attention_set_variant(int v);  // 1 = transpose-read kernel (the shipped one), 0 = round-1 kernel
 #endif
-void gemm_set_variant(int v);  // -1 auto, 0 tile kernel, 1 persistent, 2 persistent + counted stores
 
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
@@ -149,8 +150,6 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
                             bool causal, int qrows, hipStream_t s, bool reverse = false);
-
-void attention_set_variant(int v);  // testing hook: 1 = transpose-read kernel (default), 0 = round-1 kernel
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);

@@ -23,19 +23,22 @@
 // MFMA operand order is swapped (W fragment as A, X fragment as B) so each lane ends up
 // with 4 consecutive output columns of one row: 16-B fp32 / 8-B bf16 epilogue accesses.
 //
-// Three kernels share the fragment/epilogue code and are bit-identical on the same inputs:
+// The shipped library holds three kernels that share the fragment/epilogue arithmetic and are bit-identical
+// on the same inputs (which one runs is a size decision, launch_one):
 //   gemm_tile_kernel     128x128 tile, 4 waves, 2 LDS stages, one workgroup per tile,
 //                        2 workgroups/CU.  Small problems (text tower, CLS-only last layer, tests).
-//   gemm_persist_kernel  256x128 tile, 8 waves (4x2), 3 LDS stages (144 KiB), ONE persistent
-//                        workgroup per CU walking its tiles; the LDS-DMA stream runs two K-steps
-//                        ahead with counted vmcnt and keeps running across tile boundaries.  Bound
-//                        by the L1->LDS DMA path; kept as an A/B arm.
 //   gemm_p256_kernel     256x256 tile, 8 waves (2x4, 128x64 wave tiles), two 64-KiB stages + a
-//                        4-KiB epilogue window per wave (160 KiB); the default for large problems.
+//                        4-KiB epilogue window per wave (160 KiB), persistent (one workgroup per CU).
 //                        Tiles are dealt XCD-first (an XCD's 32 CUs share X row panels in their
 //                        private L2), the two waves of a SIMD take turns refilling, whole-row
-//                        epilogue stores are streamed (nt).  Measurements and what bounds it:
-//                        DESIGN.md sections 4.1 and 5.1.
+//                        epilogue stores are streamed (nt).  Takes the large problems with edge tiles.
+//   gemm_pp_kernel       the same tile with the "ping-pong" K-loop (the two waves of a SIMD half a K-step
+//                        apart): large problems made of whole tiles, i.e. every vision GEMM at batch
+//                        256 / 512.  Measurements and what bounds it: DESIGN.md sections 4.1, 5.1, 5.4.
+// Harness build only (-DMCM_HARNESS: tools/gemm_bench.hip and libmcm_hip_harness.so, which the A/B tests
+// load): gemm_persist_kernel (256x128, 3 stages: bound by the L1->LDS DMA path), the counted-store wait
+// forms, gemm_pp32_kernel (the ping-pong loop on 32x32x16 MFMAs: same cycles, more power, lower clock —
+// DESIGN.md 5.5), the ablation bits and the variant switch.
 #include <type_traits>
 
 #include "common.hpp"
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g);
 }
 
+#ifdef MCM_HARNESS
 // =========================================================================================
 // persistent 256x128 kernel, 3-stage LDS-DMA pipeline running across tile boundaries
 // =========================================================================================
@@ -424,6 +428,7 @@ constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB
 constexpr int LOADS_PER_STAGE = 6;               // LDS-DMA instructions per wave per stage
 }  // namespace persist
 
+#endif
 // XCD-local tile enumeration: N-tiles are walked in groups of `gn` (the group's W panel
 // stays L2-resident while the XCD sweeps its M-tiles); inside a group the order is
 // (mtl, nt) n-fastest, so the 32 CUs of an XCD hold ~32/gn X row panels x gn W panels.
@@ -447,6 +452,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef MCM_HARNESS
 template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) {
   using namespace persist;
@@ -578,6 +584,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
     }
   }
 }
+
+#endif  // MCM_HARNESS
 
 // =========================================================================================
 // persistent 256x256 kernel: 8 waves as 2(M) x 4(N), wave tile 128x64 (acc = 128 VGPRs),
@@ -966,7 +974,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 
   // ---- MFMA side
   const int wr = wave >> 2, wc = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
-  const int fr = lane & 15, g = lane >> 4;
   const int xbase = wr * 128 * ROWB;
   const int wbase = A_BYTES + wc * 64 * ROWB;
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1151,12 +1158,427 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   PPT_DUMP();
 }
 
+#ifdef MCM_HARNESS
+// =========================================================================================
+// ping-pong kernel on v_mfma_f32_32x32x16_{f16,bf16} (16-bit operand modes only).  Same tile (256x256),
+// wave tiles (128x64), LDS image, DMA schedule and phase structure as gemm_pp_kernel; the compute phase
+// issues 32 MFMAs of 32 cycles instead of 64 of 16.  Why it pays here and did not in the barrier-locked
+// kernel: in the compute phase the MFMAs run back to back from registers, and a
+// 16x16x32 issues every ~19 cycles instead of 16 (the per-instruction issue overhead is paid per MFMA),
+// a 32x32x16 every ~32-33 instead of 32; it also reads its A/B operands from the register file half as
+// often per FLOP, which is energy on a part that sits at its power limit.
+//
+// Fragment maps (guide section 3): A = W block (32 tile columns x 16 k), B = X block (32 rows x 16 k),
+// lane l supplies row (l & 31), 16-B chunk (2 ks + (l >> 5)) of the 128-B K-step row — the existing
+// pair/XOR LDS image serves 32-row fragments conflict-free as well (the four 16-lane groups of a
+// ds_read_b128 touch 8 distinct row pairs).  D: lane (j = l & 31, h = l >> 5), register r holds
+// (X row j, W-block row 4h + 8(r >> 2) + (r & 3)); W rows are staged in the order perm_n32 so that this
+// is tile column h*16 + r: a lane owns 16 consecutive columns of its row in each of the two 32-column
+// blocks of the wave tile.
+// =========================================================================================
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ int perm_n32(int i) {  // LDS row i (0..31) of a 32-row W block holds this block column
+  return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3);
+}
+template <int PREC>
+__device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {  // 32x32x16, fp32 acc
+  if constexpr (PREC == MCM_PREC_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t quad(const f32x16_t& v, int q) {
+  return (f32x4_t){v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+}
+
+// 16-bit epilogue of a full 128x64 wave tile held as acc[xb][wb] (32x32 blocks).  Unit = one block
+// (32 rows x 32 columns = 2 KiB of 16-bit), units in wb-major order ping-ponging between the two halves
+// of the wave's 4-KiB window like wave_epilogue_lds; a lane writes its 32 B of row j, the read-back puts
+// four lanes on a 64-B row, so one store instruction writes 16 rows x 64 B.  bv[wb][q]: bias of columns
+// nw + wb*32 + h*16 + q*4 .. +3; bv[1] is loaded here (asm, counted) and first used by unit 4.
+template <int PREC, int EPI>
+__device__ __forceinline__ void wave_epilogue16_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2], f32x4_t (&bv0)[4],
+                                                    int mw, int nw, int lane, char* scratch) {
+  const int j = lane & 31, h = lane >> 5;
+  f32x4_t bv1[4];
+  if (a.bias) {
+    const float* p = a.bias + nw + 32 + h * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv1[q]) : "v"(p + q * 4) : "memory");
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv1[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const int rrow = lane >> 2, c4 = lane & 3;  // read-back: 4 lanes per 64-B row
+  auto write_unit = [&](int u, const f32x4_t (&bv)[4]) {
+    const int wb = u >> 2, xb = u & 3;
+    f32x4_t v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = quad(acc[xb][wb], q) + bv[q];
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[q][t] = quick_gelu_fast(v[q][t]);
+      }
+    }
+    char* w = scratch + (u & 1) * 2048 + j * 64;
+    const int sw = (j >> 1) & 3;
+    *(uint4*)(w + (((h * 2) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
+                                                      pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
+    *(uint4*)(w + (((h * 2 + 1) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
+                                                          pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
+  };
+  auto read_unit = [&](int u, uint4 (&r)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t * 16 + rrow;
+      r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 64 + ((c4 ^ ((row >> 1) & 3)) << 4));
+    }
+  };
+  const int lane_off = rrow * a.ldo + c4 * 8;  // elements
+  auto store_unit = [&](int u, const uint4 (&r)[2]) {
+    const int wb = u >> 2, xb = u & 3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint16_t* rowbase = (uint16_t*)a.out + (size_t)(mw + xb * 32 + t * 16) * a.ldo + nw + wb * 32;
+      if (!DBG(16)) store16_stream(rowbase + lane_off, r[t]);
+    }
+  };
+  write_unit(0, bv0);
+#pragma unroll
+  for (int u = 1; u < 8; ++u) {
+    uint4 r[2];
+    read_unit(u - 1, r);
+    if (u == 4) {
+      // VMEM queue behind the four bv1 loads: the stores of units 0..2 (2 each)
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(bv1[0]), "+v"(bv1[1]), "+v"(bv1[2]), "+v"(bv1[3])::"memory");
+    }
+    if (u < 4) write_unit(u, bv0);
+    else write_unit(u, bv1);
+    store_unit(u - 1, r);
+  }
+  {
+    uint4 r[2];
+    read_unit(7, r);
+    store_unit(7, r);
+  }
+}
+
+// fp32-row epilogue (residual read-modify-write) of the same wave tile.  Unit = one 32x32 block = 32 rows x
+// 128 B = the whole 4-KiB window; eight lanes read a row back, so every global access instruction moves
+// 8 rows x 128 B.  The bias (of the four columns a lane owns AFTER the bounce) is added after the bounce:
+// (acc + b) + resid, the order of every other GEMM kernel here.  All global accesses are asm, counted:
+// queue at the wait of unit u, oldest first: [loads u] [stores u-1] [loads u+1]  =>  vmcnt <= 8.
+__device__ __forceinline__ void wave_epilogue_resid_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2],
+                                                        const f32x4_t (&bvf)[2], int mw, int nw, int lane, char* scratch) {
+  const int j = lane & 31, h = lane >> 5;
+  const int rrow = lane >> 3, c8 = lane & 7;
+  const uint32_t voff = (uint32_t)(rrow * a.ldo + c8 * 4) * 4u;  // bytes
+  const char* base = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
+  auto rowbase = [&](int u, int t) {
+    const int wb = u >> 2, xb = u & 3;
+    return base + ((size_t)(xb * 32 + t * 8) * a.ldo + wb * 32) * 4;
+  };
+  f32x4_t buf[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int wb = u >> 2, xb = u & 3;
+    if (u + 1 < 8) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gload16(buf[(u + 1) & 1][t], rowbase(u + 1, t), voff);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4_t*)(scratch + j * 128 + (((h * 4 + q) ^ (j & 7)) << 4)) = quad(acc[xb][wb], q);
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 8 + rrow;
+      v[t] = *(const f32x4_t*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4)) + bvf[wb];
+    }
+    if (u == 0 || u + 1 == 8) wait_vmcnt_pin<4>(buf[u & 1]);
+    else wait_vmcnt_pin<8>(buf[u & 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] += buf[u & 1][t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gstore16(rowbase(u, t), voff, v[t]);
+  }
+}
+
+template <int PREC, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
+  using namespace p256;
+  static_assert(PREC != MCM_PREC_F32 && EPI != EPI_PATCH, "16-bit operand modes, interior tiles");
+  enter_precision_mode<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
+  const int grp = wave >> 2, w4 = wave & 3;
+
+  const int nbn = a.N / BN, nbm = a.M / BM;
+  const int G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nmt_x = (nbm - xcd + 7) >> 3;
+  const int ntl_x = nmt_x * nbn;
+  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
+  if (ntl == 0) return;
+  const int nk = (a.K * ES) / ROWB;
+  const int total = ntl * nk;
+
+  const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
+  struct Cursor { int mtl, nt; };
+  auto cursor_next = [&](Cursor& c) {
+    c.mtl += dmt;
+    c.nt += dnt;
+    if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
+  };
+  auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
+  const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
+
+  // ---- LDS-DMA side: exactly gemm_pp_kernel's (12 pieces per step from waves 0-3, 4 from waves 4-7), only the
+  // order of the W rows inside a 32-row block differs (perm_n32)
+  struct LaneK { uint32_t voff_x, voff_w; int fo0; };
+  auto lane_consts = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int rr = (l >> 4) * 2 + ((l & 15) >> 3);
+    const int chunk = (l & 7) ^ (((w4 & 1) << 2) | (l >> 4));
+    LaneK c;
+    c.voff_x = (uint32_t)(rr * (uint32_t)sx + chunk * 16);
+    c.voff_w = (uint32_t)(perm_n32(w4 * 8 + rr) * (uint32_t)sw + chunk * 16);
+    const int j = l & 31, h = l >> 5;
+    c.fo0 = (j >> 1) * 256 + ((((j & 1) << 3) | ((h ^ (j >> 1)) & 7)) << 4);  // K16 sub-step ks: fo0 ^ (ks << 5)
+    return c;
+  };
+  Cursor ci{jx / nbn, jx % nbn};
+  int ji = 0, kti = 0;
+  const char *tx, *tw;
+  auto set_issue_tile = [&]() {
+    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
+    tx = (const char*)a.x + (size_t)(m0 + grp * 128 + w4 * 8) * sx;
+    tw = (const char*)a.w + (size_t)n0 * sw;
+  };
+  const uint32_t lds0 = lds_addr(smem);
+  auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
+    const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
+    const size_t ko = (size_t)kti * ROWB;
+    if (i < 4) {
+      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+    } else {
+      const int q = i - 4;  // LDS rows q*32 + w4*8 + rr of the W panel = tile columns q*32 + perm_n32(w4*8 + rr)
+      glds16s(tw + ko + (size_t)(q * 32) * sw, lk.voff_w, base + A_BYTES + q * 4096);
+    }
+  };
+  auto issue_done = [&]() {
+    if (++kti == nk) {
+      kti = 0;
+      if (++ji < ntl) {
+        cursor_next(ci);
+        set_issue_tile();
+      }
+    }
+  };
+
+  // ---- MFMA side: wave tile 128 x 64 = 4 X blocks x 2 W blocks of 32x32, K-step = 4 sub-steps of 16
+  const int wr = wave >> 2, wc = wave & 3;
+  const int xbase = wr * 128 * ROWB;
+  const int wbase = A_BYTES + wc * 64 * ROWB;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  // memory phase: all 8 W fragments and the X fragments of sub-steps 0 and 1 (64 registers); the X fragments of
+  // sub-steps 2 and 3 replace them during the compute phase, each after its last use
+  u32x4_t xf[2][4], wf[4][2];
+  auto readf = [&](const LaneK& lk, int st, int i) {  // memory-phase read i of 16, in order of first use
+    const char* sb = smem + st * STAGE_BYTES;
+    if (i < 2) wf[0][i] = *(const u32x4_t*)(sb + wbase + i * 4096 + lk.fo0);
+    else if (i < 6) xf[0][i - 2] = *(const u32x4_t*)(sb + xbase + (i - 2) * 4096 + lk.fo0);
+    else if (i < 8) wf[1][i - 6] = *(const u32x4_t*)(sb + wbase + (i - 6) * 4096 + (lk.fo0 ^ 32));
+    else if (i < 12) xf[1][i - 8] = *(const u32x4_t*)(sb + xbase + (i - 8) * 4096 + (lk.fo0 ^ 32));
+    else wf[2 + ((i - 12) >> 1)][(i - 12) & 1] =
+        *(const u32x4_t*)(sb + wbase + ((i - 12) & 1) * 4096 + (lk.fo0 ^ ((2 + ((i - 12) >> 1)) << 5)));
+  };
+  auto pin_frags = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) asm volatile("" : "+v"(wf[k][f]));
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(xf[k][f]));
+  };
+  f32x16_t acc[4][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][w][r] = 0.f;
+  };
+  zero();
+  auto compute = [&](int fo0, int st) {
+    const char* sb = smem + st * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb) {
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb)
+          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks][xb]), acc[xb][wb]);
+        xf[ks][xb] = *(const u32x4_t*)(sb + xbase + xb * 4096 + (fo0 ^ ((ks + 2) << 5)));
+      }
+#pragma unroll
+    for (int ks = 2; ks < 4; ++ks)
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb)
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb)
+          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks & 1][xb]), acc[xb][wb]);
+  };
+
+  Cursor cc{jx / nbn, jx % nbn};
+  int em0 = 0, en0 = 0;  // tile whose epilogue is pending
+  // bias registers of the pending tile, asm loads issued at the top of its last compute phase: 16-bit outputs
+  // need the 16 columns of the lane's first block (the second block's are loaded inside the epilogue), the
+  // fp32-row form the 4 + 4 columns the lane owns after the LDS bounce
+  constexpr bool RESID = (EPI == EPI_RESID);
+  f32x4_t bv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto bias_issue = [&](int n0) {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    if constexpr (RESID) {
+      const float* p = a.bias + n0 + wc * 64 + (le & 7) * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[0]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[1]) : "v"(p + 32) : "memory");
+    } else {
+      const float* p = a.bias + n0 + wc * 64 + (le >> 5) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(p + q * 4) : "memory");
+    }
+  };
+  auto epilogue = [&]() {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
+    if (!DBG(4)) {
+      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+      if constexpr (RESID) {
+        const f32x4_t bvf[2] = {bv[0], bv[1]};
+        wave_epilogue_resid_b32(a, acc, bvf, em0 + wr * 128, en0 + wc * 64, le, win);
+      } else {
+        wave_epilogue16_b32<PREC, EPI>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+      }
+    }
+    zero();
+  };
+  set_issue_tile();
+  {
+    const LaneK lk = lane_consts();
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      if (i < 4 || !grp) piece(lk, 0, i);
+  }
+  issue_done();
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp) {  // waves 4-7 run one phase behind
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int ktc = 0;
+  bool pend = false;
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s < total; ++s) {
+    const int sr = s & 1, si = sr ^ 1;
+    const bool split = pend && !grp;
+    int fo0;
+    if (pend) {
+      if (!grp) {
+        const LaneK lk = lane_consts();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) piece(lk, si, i);
+        issue_done();
+        phase_barrier();
+      }
+      epilogue();
+      if (!grp) {
+        const LaneK lk = lane_consts();
+        fo0 = lk.fo0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) readf(lk, sr, i);
+      }
+    }
+    if (!split) {
+      const LaneK lk = lane_consts();
+      fo0 = lk.fo0;
+      if (!grp) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          if (i < 8) {
+            readf(lk, sr, 2 * i);
+            readf(lk, sr, 2 * i + 1);
+          }
+          piece(lk, si, i);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) readf(lk, sr, 4 * i + jj);
+          piece(lk, si, i);
+        }
+      }
+      issue_done();
+    }
+    pin_frags();
+    if (!split) phase_barrier();
+    // ---- compute phase of step s
+    if (ktc == nk - 1 && a.bias) bias_issue(cc.nt * BN);  // covered by the wait that ends this phase
+    __builtin_amdgcn_s_setprio(1);
+    compute(fo0, sr);
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
+    phase_barrier();
+    pend = false;
+    if (++ktc == nk) {
+      ktc = 0;
+      pend = true;
+      em0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
+      en0 = cc.nt * BN;
+      cursor_next(cc);
+    }
+  }
+  if (!grp) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (pend) epilogue();
+}
+
+#endif  // MCM_HARNESS
+
 // ---- launch ------------------------------------------------------------------------------
 
+#ifdef MCM_HARNESS
 int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores),
-                     // 5 ping-pong 256x256 (interior tiles only, else 3)
-
+                     // 5 ping-pong 256x256 (interior tiles only, else 3), 6 ping-pong on 32x32x16 MFMAs (else 5)
 int variant() { return g_variant; }
+#else
+constexpr int variant() { return -1; }  // the shipped library has the size policy of launch_one only
+#endif
 
 // Persistent kernels run one workgroup per CU.  The count comes from the device (a partitioned or
 // CU-masked lease reports fewer than 256) and is rounded down to a multiple of 8: the tile schedule
@@ -1186,6 +1608,7 @@ hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef MCM_HARNESS
 template <int PREC, int EPI, bool CS>
 hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -1198,6 +1621,8 @@ hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
   return hipGetLastError();
 }
+
+#endif
 
 template <int PREC, int EPI, bool CS>
 hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
@@ -1225,6 +1650,22 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef MCM_HARNESS
+template <int PREC, int EPI>
+hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp32_kernel<PREC, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_pp32_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+#endif
+
 template <int PREC, int EPI>
 hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   int v = variant();
@@ -1237,16 +1678,23 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (v != 0 && persistent_grid() < 8) v = 0;
   if (v == 0) return launch_tile<PREC, EPI>(a, s);
+#ifdef MCM_HARNESS
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
   if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
-  if (v == 3) return launch_p256<PREC, EPI, false>(a, s);
+  if (v == 4) return launch_p256<PREC, EPI, true>(a, s);
+  if (v == 6) {  // ping-pong on 32x32x16 MFMAs: 16-bit operand modes, whole tiles; else as 5
+    if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
+      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp32<PREC, EPI>(a, s);
+    }
+    v = 5;
+  }
+#endif
   if (v == 5) {
     if constexpr (EPI != EPI_PATCH) {  // the patch epilogue remaps rows: stays with the plain kernel
       if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI>(a, s);
     }
-    return launch_p256<PREC, EPI, false>(a, s);
   }
-  return launch_p256<PREC, EPI, true>(a, s);
+  return launch_p256<PREC, EPI, false>(a, s);
 }
 
 template <int PREC>
@@ -1262,9 +1710,8 @@ hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void gemm_set_variant(int v) { g_variant = v; }
-
 #ifdef MCM_HARNESS
+void gemm_set_variant(int v) { g_variant = v; }
 int g_group_n = 0;  // 0 = heuristic
 int g_dbg = 0;
 void gemm_set_dbg(int d) { g_dbg = d; }

@@ -8,7 +8,8 @@
 //   text    CLIPTextEmbeddings :232-256 → causal CLIPEncoderLayer ×L → final_layer_norm
 //           :559 → EOS pool :561-581 → text_projection :713
 // and the reference's own tail utils/detection_util.py:226,231-248.
-// The residual stream is fp32 in HBM; GEMM operands are bf16 (or fp32 in the parity mode).
+// The residual stream is fp32 in HBM; vision GEMM operands are fp16 or bf16 (cfg.precision; exact fp32 in the
+// parity mode), the text tower always runs the exact-fp32 kernels.
 #include <map>
 #include <string>
 #include <vector>
@@ -595,15 +596,22 @@ int mcm_measures(mcm_handle* h, const float* pos_dev, int64_t n_pos, const float
   if (!(recall_level >= 0.0 && recall_level <= 1.0)) return fail(h, MCM_EINVAL, "recall_level outside [0,1]");
   hipStream_t s = (hipStream_t)stream;
   // the three per-example count arrays (12 B per score) live in the MLP activation buffer, which is
-  // idle between encode calls and ordered against them by the stream: nothing is allocated here
-  if (measures_workspace_bytes((long)(n_pos + n_neg)) > h->hbuf_bytes)
-    return fail(h, MCM_ERANGE, "score vectors exceed the workspace sized by mcm_create (" +
-                                   std::to_string(h->hbuf_bytes / 12) + " scores)");
+  // idle between encode calls and ordered against them by the stream (the caller passes the stream its
+  // encode / score calls ran on — include/mcm.h); score vectors that do not fit it get a one-off
+  // stream-ordered allocation instead of a refusal
+  const size_t need = measures_workspace_bytes((long)(n_pos + n_neg));
+  void* ws = h->hbuf;
+  bool own = false;
+  if (need > h->hbuf_bytes) {
+    HIP_TRY(h, hipMallocAsync(&ws, need, s));
+    own = true;
+  }
   double* out_dev = nullptr;
-  HIP_TRY(h, launch_measures(pos_dev, (long)n_pos, neg_dev, (long)n_neg, negate, recall_level, h->hbuf,
-                             &out_dev, s));
-  HIP_TRY(h, hipMemcpyAsync(out_host, out_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
+  hipError_t e = launch_measures(pos_dev, (long)n_pos, neg_dev, (long)n_neg, negate, recall_level, ws, &out_dev, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, out_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, s);
+  if (own) (void)hipFreeAsync(ws, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail(h, MCM_EHIP, std::string("mcm_measures: ") + hipGetErrorString(e));
   return MCM_OK;
 }
 
@@ -748,6 +756,7 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
   return MCM_OK;
 }
 
+#ifdef MCM_HARNESS  // libmcm_hip_harness.so only: process-wide A/B switches for tests and tools
 int mcm_debug_attention_variant(int32_t variant) {
   if (variant < 0 || variant > 1) return MCM_EINVAL;
   attention_set_variant(variant);
@@ -755,9 +764,11 @@ int mcm_debug_attention_variant(int32_t variant) {
 }
 
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || variant > 5) return MCM_EINVAL;
+  if (variant < -1 || variant > 6) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }
+
+#endif
 
 }  // extern "C"

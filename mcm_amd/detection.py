@@ -23,16 +23,21 @@ from .tokenizer import load_tokenizer
 PROMPT = "a photo of a {c}"  # reference utils/detection_util.py:228 (no trailing period)
 
 
-def _tokenizer(args):
-    """args.tokenizer_dir (additive) wins over args.ckpt; the hash stand-in is refused when the run
-    uses a real checkpoint (args.weights)."""
+def _tokenizer(args, net=None):
+    """args.tokenizer_dir (additive) wins over args.ckpt.  The hash stand-in is allowed only with synthetic
+    weights: the net records that itself (`net.synthetic_weights`, set by build_model / NativeCLIP), so a
+    reference-shaped caller that has only `args.ckpt` and hands over a NativeCLIP built from a real checkpoint
+    is refused instead of getting meaningless ids; a net that does not say falls back to `args.weights`."""
     src = getattr(args, "tokenizer_dir", None) or getattr(args, "ckpt", "")
-    return load_tokenizer(src, allow_hash=not getattr(args, "weights", None))
+    synthetic = getattr(net, "synthetic_weights", None)
+    if synthetic is None:
+        synthetic = not getattr(args, "weights", None)
+    return load_tokenizer(src, allow_hash=bool(synthetic))
 
 
 def encode_prompt_bank(args, net, test_labels):
     """`text_features` of the reference (:228-231): K prompts → [K,P] unit-norm fp32."""
-    tokenizer = _tokenizer(args)
+    tokenizer = _tokenizer(args, net)
     text_inputs = tokenizer([PROMPT.format(c=c) for c in test_labels], padding=True, return_tensors="pt")
     return _unit_text_features(net, text_inputs)
 
@@ -50,7 +55,7 @@ def encode_prompt_ensemble(args, net, test_labels, templates=None):
     re-normalise → [K,P].  Still a [K,P] bank, so the scoring path is unchanged."""
     templates = list(templates or DEFAULT_TEMPLATES)
     labels = list(test_labels)
-    tokenizer = _tokenizer(args)
+    tokenizer = _tokenizer(args, net)
     prompts = [t.format(c=c) if "{c}" in t else t.format(c) for c in labels for t in templates]  # class-major
     tok = tokenizer(prompts, padding=True, return_tensors="pt")
     feats = _unit_text_features(net, tok)
@@ -60,12 +65,38 @@ def encode_prompt_ensemble(args, net, test_labels, templates=None):
 def _unit_text_features(net, tok):
     """`get_text_features(...).float()` followed by `/= norm` (reference :229-231).  A NativeCLIP fuses
     the normalisation; any other `net` honouring the HF contract is normalised here."""
+    import inspect
+
     try:
+        fused = "normalize" in inspect.signature(net.get_text_features).parameters
+    except (TypeError, ValueError):
+        fused = False
+    if fused:
         return net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"],
                                      normalize=True)
-    except TypeError:
-        f = net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).float()
-        return f / f.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+    f = net.get_text_features(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).float()
+    return f / f.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+
+
+def prompt_bank(args, net, test_labels):
+    """The [K,P] unit-norm bank for (labels, templates, tokenizer source), encoded once per `net`: a CLI run
+    scores one ID and four OOD sets against the same bank (the reference re-encodes it every BATCH, :228-231;
+    round 2 re-encoded it every dataset — 5 s per call with 80 templates x 1000 classes).  The key holds
+    everything the bank depends on; T and the score kind do not enter it."""
+    templates = getattr(args, "templates", None)
+    key = (tuple(str(c) for c in test_labels), tuple(templates) if templates else None,
+           getattr(args, "tokenizer_dir", None) or getattr(args, "ckpt", ""))
+    cache = getattr(net, "_bank_cache", None)
+    if cache is None:
+        try:
+            cache = net._bank_cache = {}
+        except AttributeError:  # a net that refuses attributes: no caching
+            cache = {}
+    if key not in cache:
+        cache.clear()  # one bank at a time (a bank is K x P floats; keep the handle small)
+        cache[key] = (encode_prompt_ensemble(args, net, test_labels, templates) if templates
+                      else encode_prompt_bank(args, net, test_labels))
+    return cache[key]
 
 
 def read_templates(path):
@@ -111,10 +142,7 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
     rank, ws = mdist.world()
     n_total = len(loader.dataset)
     with torch.no_grad():
-        if getattr(args, "templates", None):
-            text_features = encode_prompt_ensemble(args, net, test_labels, args.templates)
-        else:
-            text_features = encode_prompt_bank(args, net, test_labels)
+        text_features = prompt_bank(args, net, test_labels)
         if ws > 1 and hasattr(loader, "shard"):
             lo, hi = mdist.shard_range(n_total, rank, ws)
             batches = loader.shard(lo, hi)
@@ -167,9 +195,11 @@ def get_mean_prec(args, net, train_loader):
             if args.normalize:
                 f = f / f.norm(dim=-1, keepdim=True)
             feats.append(f.cpu())
-            counts.append(np.bincount(np.asarray(labels, dtype=np.int64).reshape(-1), minlength=args.n_cls))
+            # labels >= n_cls are ignored, like the reference's per-class loop (:161-166) never visits them
+            counts.append(np.bincount(np.asarray(labels, dtype=np.int64).reshape(-1),
+                                      minlength=args.n_cls)[: args.n_cls])
     F = torch.cat(feats)                                    # [n, P] float32, dataset order
-    n_cb = torch.from_numpy(np.stack(counts, axis=1)[: args.n_cls].astype(np.float64))  # [n_cls, n_batches]
+    n_cb = torch.from_numpy(np.stack(counts, axis=1).astype(np.float64))  # [n_cls, n_batches]
     rows = F[: n_cb.shape[1]].double()                       # the rows the reference's indices select
     classwise_mean = ((n_cb @ rows) / n_cb.sum(dim=1, keepdim=True)).float()
     if args.normalize:

@@ -27,26 +27,29 @@ from .config import CConfig, ClipGeometry, PREC_BF16, PREC_F16, PREC_F32, SCORE_
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcm_hip.so")
+# the same sources built with -DMCM_HARNESS: A/B kernel arms + mcm_debug_* switches; tests and tools only
+HARNESS_LIB_PATH = os.path.join(_HERE, "libmcm_hip_harness.so")
 KERNEL_CLASSES = ["patchify", "gemm", "layernorm", "attention", "pool_project", "score", "embed"]
 
-_lib = None
+_libs = {}
 
 
 class NativeLibraryMissing(RuntimeError):
     pass
 
 
-def load_library():
+def load_library(harness: bool = False):
     """dlopen libmcm_hip.so and declare the C ABI (include/mcm.h).  Raises loudly when the
-    extension has not been built — the product path has no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    extension has not been built — the product path has no fallback.  `harness=True` loads
+    libmcm_hip_harness.so instead (A/B tests and tools: extra kernel arms and the mcm_debug_* switches)."""
+    if harness in _libs:
+        return _libs[harness]
+    path = HARNESS_LIB_PATH if harness else LIB_PATH
+    if not os.path.exists(path):
         raise NativeLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C mcm_amd/csrc).  mcm_amd has no CPU fallback.")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     L.mcm_abi_version.restype = i32
     L.mcm_create.argtypes = [ctypes.POINTER(CConfig), ctypes.POINTER(vp)]
@@ -66,8 +69,9 @@ def load_library():
     L.mcm_op_linear.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
-    L.mcm_debug_gemm_variant.argtypes = [i32]
-    L.mcm_debug_attention_variant.argtypes = [i32]
+    if harness:
+        L.mcm_debug_gemm_variant.argtypes = [i32]
+        L.mcm_debug_attention_variant.argtypes = [i32]
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
@@ -90,7 +94,7 @@ def load_library():
                                ctypes.POINTER(ctypes.c_double), vp]
     if L.mcm_abi_version() != 1:
         raise RuntimeError("libmcm_hip.so ABI version mismatch")
-    _lib = L
+    _libs[harness] = L
     return L
 
 
@@ -98,12 +102,13 @@ EXPORTED_SYMBOLS = [
     "mcm_abi_version", "mcm_create", "mcm_destroy", "mcm_last_error", "mcm_set_weight",
     "mcm_finalize_weights", "mcm_encode_text", "mcm_encode_image", "mcm_score_features",
     "mcm_score", "mcm_profile_enable", "mcm_profile_read", "mcm_op_linear", "mcm_op_layernorm",
-    "mcm_op_attention", "mcm_debug_gemm_variant", "mcm_encode_image_u8", "mcm_score_u8",
+    "mcm_op_attention", "mcm_encode_image_u8", "mcm_score_u8",
     "mcm_reduce_bank", "mcm_measures", "mcm_resize_crop_u8", "mcm_tokenizer_create",
     "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
-    "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram", "mcm_debug_attention_variant",
+    "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
 ]
+HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant"]
 
 
 def _stream_ptr():
@@ -117,7 +122,8 @@ class NativeCLIP:
 
     def __init__(self, geo: ClipGeometry | str, state_dict: Dict[str, np.ndarray], *,
                  device: int = 0, precision: str = "fp16", max_batch: int = 512,
-                 max_prompt_tokens: int = 1024 * 77):
+                 max_prompt_tokens: int = 1024 * 77, synthetic_weights: Optional[bool] = None,
+                 harness: bool = False):
         import torch
 
         if not torch.cuda.is_available():
@@ -127,7 +133,10 @@ class NativeCLIP:
         self.precision = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp16": PREC_F16,
                           "f16": PREC_F16}[precision]
         self.max_batch = int(max_batch)
-        self._lib = load_library()
+        # True: seeded stand-in parameters (the hash tokenizer stand-in is then acceptable); False: a real
+        # checkpoint (it is refused); None: the caller did not say (mcm_amd.detection falls back to args.weights)
+        self.synthetic_weights = synthetic_weights
+        self._lib = load_library(harness)  # harness=True: A/B tests and tools only
         torch.cuda.set_device(self.device)
         torch.cuda.init()
         self._cfg = self.geo.to_c(device=device, precision=self.precision, max_batch=max_batch,
@@ -359,4 +368,4 @@ def build_model(ckpt: str = "ViT-B/16", *, weights: Optional[str] = None, seed: 
 
     geo = geometry(ckpt)
     sd = load_state_dict_file(weights, geo) if weights else synth_state_dict(geo, seed)
-    return NativeCLIP(geo, sd, **kw)
+    return NativeCLIP(geo, sd, synthetic_weights=not weights, **kw)

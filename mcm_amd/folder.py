@@ -38,30 +38,63 @@ class FolderIndex:
     def __len__(self) -> int:
         return len(self.samples)
 
+    def first_per_class(self, max_count: int) -> "FolderIndex":
+        """The reference's `--subset` rule (utils/train_eval_util.py:56-64): keep, in dataset order, the first
+        `max_count` samples of every class."""
+        sub = object.__new__(FolderIndex)
+        sub.root, sub.classes = self.root, self.classes
+        seen, keep = {}, []
+        for path, t in self.samples:
+            if seen.get(t, 0) < max_count:
+                keep.append((path, t))
+                seen[t] = seen.get(t, 0) + 1
+        sub.samples = keep
+        sub.targets = [t for _, t in keep]
+        return sub
+
+
+def _decode_rgb(path):
+    import numpy as np
+    from PIL import Image
+
+    with Image.open(path) as im:  # torchvision's default loader: PIL, convert("RGB")
+        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+
 
 class ImageFolderU8:
     """Iterates `(images uint8 [b,S,S,3] on the device, labels int64 [b])` over [lo, hi) of a FolderIndex."""
 
-    def __init__(self, root_or_index, net, batch_size: int, lo: int = 0, hi: int | None = None):
+    def __init__(self, root_or_index, net, batch_size: int, lo: int = 0, hi: int | None = None,
+                 workers: int | None = None):
         self.dataset = root_or_index if isinstance(root_or_index, FolderIndex) else FolderIndex(root_or_index)
         self.net, self.batch_size = net, int(batch_size)
         self.lo, self.hi = lo, (len(self.dataset) if hi is None else hi)
+        # decode pool (the reference's DataLoader runs 4 worker processes, utils/train_eval_util.py:49): Pillow
+        # releases the GIL while it decodes, so threads scale; batch i+1 is decoded while batch i is scored
+        self.workers = min(32, os.cpu_count() or 4) if workers is None else int(workers)
 
     def __len__(self) -> int:
         return max(0, -(-(self.hi - self.lo) // self.batch_size))
 
     def shard(self, lo: int, hi: int) -> "ImageFolderU8":
-        return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi)
+        return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi, self.workers)
 
     def __iter__(self) -> Iterator:
-        import numpy as np
         import torch
-        from PIL import Image
+        from concurrent.futures import ThreadPoolExecutor
 
-        for s in range(self.lo, self.hi, self.batch_size):
-            chunk = self.dataset.samples[s:min(s + self.batch_size, self.hi)]
-            imgs = []
-            for path, _ in chunk:
-                with Image.open(path) as im:  # torchvision's default loader: PIL, convert("RGB")
-                    imgs.append(torch.from_numpy(np.asarray(im.convert("RGB"), dtype=np.uint8).copy()))
-            yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk], dtype=torch.long)
+        starts = list(range(self.lo, self.hi, self.batch_size))
+        chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
+        if self.workers <= 1:
+            for s in starts:
+                chunk = chunk_of(s)
+                imgs = [torch.from_numpy(_decode_rgb(p)) for p, _ in chunk]
+                yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk], dtype=torch.long)
+            return
+        with ThreadPoolExecutor(self.workers) as pool:
+            submit = lambda s: [pool.submit(_decode_rgb, p) for p, _ in chunk_of(s)]  # noqa: E731
+            pending = submit(starts[0]) if starts else None
+            for i, s in enumerate(starts):
+                futs, pending = pending, (submit(starts[i + 1]) if i + 1 < len(starts) else None)
+                imgs = [torch.from_numpy(f.result()) for f in futs]
+                yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk_of(s)], dtype=torch.long)

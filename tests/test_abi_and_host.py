@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from mcm_amd import config as cfgmod
-from mcm_amd.engine import EXPORTED_SYMBOLS, LIB_PATH
+from mcm_amd.engine import EXPORTED_SYMBOLS, HARNESS_LIB_PATH, HARNESS_ONLY_SYMBOLS, LIB_PATH
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,13 +26,23 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "mcm.h")).read()
-    declared = set(re.findall(r"\b(mcm_[a-z0-9_]+)\s*\(", header))
+    harness_part = re.search(r"#ifdef MCM_HARNESS(.*?)#endif", header, re.S).group(1)
+    product_part = header.replace(harness_part, "")
+    declared = set(re.findall(r"\b(mcm_[a-z0-9_]+)\s*\(", product_part))
     declared -= {"mcm_handle", "mcm_config"}
     assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
     lib.mcm_abi_version.restype = ctypes.c_int32
     assert lib.mcm_abi_version() == cfgmod.ABI_VERSION
+    # the A/B switches exist in the harness library only: the shipped one does not export them
+    debug = set(re.findall(r"\b(mcm_[a-z0-9_]+)\s*\(", harness_part))
+    assert debug == set(HARNESS_ONLY_SYMBOLS)
+    for sym in debug:
+        assert not hasattr(lib, sym), f"{sym} must not be exported by libmcm_hip.so"
+    hlib = ctypes.CDLL(HARNESS_LIB_PATH)
+    for sym in declared | debug:
+        assert getattr(hlib, sym) is not None
 
 
 def test_config_struct_matches_header():

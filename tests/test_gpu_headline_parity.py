@@ -1,6 +1,9 @@
 """North-star parity on the headline configuration: full CLIP-ViT-B/16, K = 1000 prompts, 50 000 ID + 10 000 OOD
-images (ImageNet-1k vs one OOD set), the 16-bit operand modes against the exact-fp32 MFMA arm, which is itself
-pinned to the CPU oracle and to HF (test_gpu_model.py).  AUROC / AUPR / FPR95 by the device metric kernels.
+images (ImageNet-1k vs one OOD set).  Every native arm is compared with (a) the exact-fp32 MFMA arm and (b) the
+reference's own arithmetic on the SAME images: HF transformers `CLIPModel`, fp32 eager, running on this device
+(oracle/hf_reference.py — the checker; BASELINE.json north_star: "identical AUROC/FPR95 to the HF-CLIP
+reference").  AUROC / AUPR / FPR95 by the device metric kernels.  Both weight regimes are asserted: fp16-exact
+seeded weights (the reference's checkpoints were released in fp16) and fp32-valued seeded weights.
 Numbers and the regimes they were measured in: DESIGN.md §2."""
 import json
 
@@ -9,22 +12,54 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_headline_drift_of_the_benchmarked_dtype():
+def _external():
+    from oracle.hf_reference import hf_available, hf_scorer_factory
+
+    why = hf_available()
+    if why is not None:
+        pytest.skip(f"transformers unavailable: {why}")
+    return {"hf": hf_scorer_factory()}
+
+
+@pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
+def test_headline_parity_vs_hf_reference(weights):
     from bench import DEFAULT_PRECISION
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
+    assert DEFAULT_PRECISION == "fp16"
     d = measure_drift("ViT-B/16", K=1000, n_id=50000, n_ood=10000, batch=512, arms=("fp16", "bf16"),
-                      **HEADLINE_PIXELS)
-    print("headline drift:", json.dumps(d))
+                      amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights, external=_external())
+    print(f"headline parity ({weights} weights):", json.dumps(d))
     ref = d["reference"]
     assert 0.02 < ref["auroc"] < 0.98 and 0.0 < ref["fpr95"] < 1.0          # non-degenerate operating point
-    arm = d["arms"][DEFAULT_PRECISION]
-    assert DEFAULT_PRECISION == "fp16"
-    # the bar of BASELINE.json's north_star; FPR95's quantum at 10 000 OOD images is exactly 1e-4
-    assert arm["d_auroc"] <= 1e-4, d
-    assert arm["d_fpr95"] <= 1e-4 + 1e-12, d
-    assert arm["d_aupr"] <= 1e-4, d
-    # the text tower is fp32 in every mode, so bf16 differs only by its vision-side operand rounding; it is
-    # the documented ~10x coarser arm and is bounded here so a regression is visible
-    assert d["arms"]["bf16"]["d_auroc"] <= 3e-3, d
+    # (a) the exact-fp32 arm IS the HF computation, to the metric quantum
+    r = ref["vs_external"]["hf"]
+    assert r["d_auroc"] <= 1e-5 and r["d_aupr"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12, r
+    assert r["rms_dscore"] <= 1e-9, r
+    # (b) the benchmarked dtype against HF: the bar of BASELINE.json's north_star; FPR95's quantum at 10 000
+    # OOD images is exactly 1e-4
+    arm = d["arms"]["fp16"]
+    for vs in (arm, arm["vs_external"]["hf"]):
+        assert vs["d_auroc"] <= 1e-4, (weights, vs)
+        assert vs["d_aupr"] <= 1e-4, (weights, vs)
+        assert vs["d_fpr95"] <= 1e-4 + 1e-12, (weights, vs)
+    # bf16 (the dtype BASELINE configs 2/3/5 name) does NOT meet 1e-4 in either regime — measured 2.2e-4 /
+    # 1.1e-3 in AUROC; bounded here so a regression is visible, and reported by bench.py
+    b = d["arms"]["bf16"]["vs_external"]["hf"]
+    assert b["d_auroc"] <= 3e-3 and b["d_fpr95"] <= 3e-3, b
     assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
+
+
+def test_l14_parity_vs_hf_reference():
+    """BASELINE config 4 (ViT-L/14 fp16, batch 256) with 10 000 OOD images, so that FPR95's quantum is 1e-4
+    (round 2 ran 5 000: one sample = 2e-4)."""
+    from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
+
+    d = measure_drift("ViT-L/14", K=1000, n_id=20000, n_ood=10000, batch=256, arms=("fp16",),
+                      amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp16-exact",
+                      external=_external())
+    print("L/14 parity (fp16-exact weights):", json.dumps(d))
+    r = d["reference"]["vs_external"]["hf"]
+    assert r["d_auroc"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12, r
+    for vs in (d["arms"]["fp16"], d["arms"]["fp16"]["vs_external"]["hf"]):
+        assert vs["d_auroc"] <= 1e-4 and vs["d_aupr"] <= 1e-4 and vs["d_fpr95"] <= 1e-4 + 1e-12, vs

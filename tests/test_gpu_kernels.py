@@ -27,15 +27,29 @@ def _bf16_round(a: np.ndarray) -> np.ndarray:
     return _round_to(a, "bf16")
 
 
-@pytest.fixture(scope="module")
-def tiny_net():
+def _tiny(harness):
     from mcm_amd.engine import NativeCLIP
     from mcm_amd.config import geometry
     from mcm_amd.weights import synth_state_dict
 
     geo = geometry("tiny")
-    net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=64,
-                     max_prompt_tokens=4096)
+    return NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=64, max_prompt_tokens=4096,
+                      harness=harness)
+
+
+@pytest.fixture(scope="module")
+def tiny_net():
+    """A handle of the SHIPPED library (libmcm_hip.so): its own kernel choice, no switches."""
+    net = _tiny(False)
+    yield net
+    net.close()
+
+
+@pytest.fixture(scope="module")
+def harness_net():
+    """A handle of libmcm_hip_harness.so (same sources, -DMCM_HARNESS): the A/B kernel arms and the
+    mcm_debug_* switches live only there."""
+    net = _tiny(True)
     yield net
     net.close()
 
@@ -94,19 +108,25 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 2, 4, 5], ids=["tile128", "persist256x128", "persist256x256", "pingpong256x256"])
-def gemm_variant(request, tiny_net):
-    """Every GEMM kernel variant must pass the same parity cases (the auto policy picks by
-    problem size, so small test shapes would otherwise only exercise the tile kernel)."""
-    assert tiny_net._lib.mcm_debug_gemm_variant(request.param) == 0
-    yield request.param
-    tiny_net._lib.mcm_debug_gemm_variant(-1)
+@pytest.fixture(params=[-1, 0, 2, 4, 5, 6], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
+                                             "pingpong256x256", "pingpong256x256-mfma32"])
+def gemm_net(request, tiny_net, harness_net):
+    """Every GEMM kernel variant must pass the same parity cases (the shipped policy picks by problem size, so
+    small test shapes would otherwise only exercise the tile kernel).  -1 = the shipped library as is; the
+    forced variants run in the harness library."""
+    if request.param < 0:
+        yield tiny_net
+        return
+    assert harness_net._lib.mcm_debug_gemm_variant(request.param) == 0
+    yield harness_net
+    harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
+def test_linear(gemm_net, M, N, K, prec, epi):
+    tiny_net = gemm_net
     from oracle import oracle as orc
 
     rng = np.random.default_rng(M * 7 + N * 3 + K + epi)
@@ -142,7 +162,9 @@ def test_linear(tiny_net, gemm_variant, M, N, K, prec, epi):
                                    (300, 256, 128), (1, 512, 256), (700, 768, 768), (129, 256, 3072)])
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_linear_pingpong_interior_shapes_vs_oracle(tiny_net, M, N, K, prec, epi):
+@pytest.mark.parametrize("pp_variant", [5, 6], ids=["mfma16", "mfma32"])
+def test_linear_pingpong_interior_shapes_vs_oracle(harness_net, M, N, K, prec, epi, pp_variant):
+    tiny_net = harness_net
     """The ping-pong 256x256 kernel only takes problems made of whole tiles, so it gets its own oracle cases:
     one tile, a few tiles on a few workgroups, a long K, a single K-step.  The shapes with a partial last M tile
     check the routing: under variant 5 they must come out right through the plain persistent kernel.  (Partial
@@ -163,7 +185,7 @@ def test_linear_pingpong_interior_shapes_vs_oracle(tiny_net, M, N, K, prec, epi)
     y = torch.zeros((M, N), device="cuda", dtype=dt)
     rd = _dev(resid0)
     try:
-        assert tiny_net._lib.mcm_debug_gemm_variant(5) == 0
+        assert tiny_net._lib.mcm_debug_gemm_variant(pp_variant) == 0
         rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC[prec], _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), _ptr(rd),
                                          M, N, K, epi, None)
         assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
@@ -184,7 +206,7 @@ def test_linear_pingpong_interior_shapes_vs_oracle(tiny_net, M, N, K, prec, epi)
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1), (768, 3072, 2), (768, 768, 2)])
-def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi, prec):
+def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, prec):
     """The four GEMM shapes of a B/16 layer at batch 512 (M = 512*197): the persistent 256x256 kernels
     (both wait forms, and the ping-pong kernel) against the one-workgroup-per-tile kernel, bit for bit, three
     launches each, in every operand format.
@@ -200,30 +222,32 @@ def test_linear_full_size_variants_bitwise(tiny_net, N, K, epi, prec):
     resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
     bits = {2: torch.int16, 4: torch.int32}
 
-    def run(variant):
-        assert tiny_net._lib.mcm_debug_gemm_variant(variant) == 0
+    def run(variant):  # -1: the shipped library and its own choice; others: forced in the harness library
+        net = tiny_net if variant < 0 else harness_net
+        if variant >= 0:
+            assert net._lib.mcm_debug_gemm_variant(variant) == 0
         y = torch.zeros((M, N), device="cuda", dtype=dt)
         rd = resid0.clone() if epi == 2 else y
-        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
-                                         _ptr(rd), M, N, K, epi, None)
-        assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+        rc = net._lib.mcm_op_linear(net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                    _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, net._lib.mcm_last_error(net._h)
         torch.cuda.synchronize()
         return rd if epi == 2 else y
 
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (3, 4, 5):
+        for variant in (-1, 3, 4, 5, 6):
             for _ in range(3):
                 got = run(variant)
                 assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
                     f"variant {variant}"
     finally:
-        tiny_net._lib.mcm_debug_gemm_variant(-1)
+        harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2)])
-def test_linear_l14_shapes_pingpong_bitwise(tiny_net, N, K, epi):
+def test_linear_l14_shapes_pingpong_bitwise(tiny_net, harness_net, N, K, epi):
     """BASELINE config 4 (ViT-L/14, batch 256: M = 256 * 257 rows, K = 1024 / 4096): the ping-pong kernel against
     the one-workgroup-per-tile kernel, bit for bit, fp16 operands — other K-loop lengths (16 / 64 steps), other
     tile counts per workgroup and another walk direction than the B/16 cases above."""
@@ -236,24 +260,27 @@ def test_linear_l14_shapes_pingpong_bitwise(tiny_net, N, K, epi):
     resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
 
     def run(variant):
-        assert tiny_net._lib.mcm_debug_gemm_variant(variant) == 0
+        net = tiny_net if variant < 0 else harness_net
+        if variant >= 0:
+            assert net._lib.mcm_debug_gemm_variant(variant) == 0
         y = torch.zeros((M, N), device="cuda", dtype=dt)
         rd = resid0.clone() if epi == 2 else y
-        rc = tiny_net._lib.mcm_op_linear(tiny_net._h, PREC["fp16"], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
-                                         _ptr(rd), M, N, K, epi, None)
-        assert rc == 0, tiny_net._lib.mcm_last_error(tiny_net._h)
+        rc = net._lib.mcm_op_linear(net._h, PREC["fp16"], _ptr(x), _ptr(w), _ptr(bias), _ptr(y),
+                                    _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, net._lib.mcm_last_error(net._h)
         torch.cuda.synchronize()
         return rd if epi == 2 else y
 
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for _ in range(2):  # mcm_op_linear alternates the walk direction per launch: both get exercised
-            got = run(5)
-            view = torch.int32 if epi == 2 else torch.int16
-            assert torch.equal(got.view(view), ref.view(view))
+        for variant in (-1, 5, 6):
+            for _ in range(2):  # mcm_op_linear alternates the walk direction per launch: both get exercised
+                got = run(variant)
+                view = torch.int32 if epi == 2 else torch.int16
+                assert torch.equal(got.view(view), ref.view(view)), f"variant {variant}"
     finally:
-        tiny_net._lib.mcm_debug_gemm_variant(-1)
+        harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
 ATTN_CASES = [(3, 197, 12, False), (2, 50, 12, False), (5, 17, 2, False), (4, 77, 8, True),
@@ -335,7 +362,7 @@ ATTN_MORE = [(2, 65, 2, False), (2, 80, 2, False), (2, 96, 2, False), (2, 112, 2
 
 @pytest.mark.parametrize("nseq,L,heads,causal", ATTN_MORE)
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-def test_attention_every_tile_count(tiny_net, nseq, L, heads, causal, prec):
+def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causal, prec):
     """The transpose-read kernel is instantiated per key-tile count (1 .. 18 tiles of 16 keys); odd counts
     end with a half-empty key step.  Both 16-bit modes, the round-2 kernel AND the round-1 kernel (A/B arm),
     against the oracle."""
@@ -350,18 +377,19 @@ def test_attention_every_tile_count(tiny_net, nseq, L, heads, causal, prec):
     dt = DTYPE[prec]
     qd = _dev(qkv, dt)
     tol = 2e-2 if prec == "bf16" else 3e-3
-    lib = tiny_net._lib
     try:
-        for variant in (1, 0):
-            assert lib.mcm_debug_attention_variant(variant) == 0
+        for variant in (-1, 1, 0):  # -1: the shipped library; 1 / 0: both kernels forced in the harness library
+            net = tiny_net if variant < 0 else harness_net
+            if variant >= 0:
+                assert net._lib.mcm_debug_attention_variant(variant) == 0
             out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
-            rc = lib.mcm_op_attention(tiny_net._h, PREC[prec], _ptr(qd), _ptr(out), nseq, L, heads, int(causal), None)
-            assert rc == 0, lib.mcm_last_error(tiny_net._h)
+            rc = net._lib.mcm_op_attention(net._h, PREC[prec], _ptr(qd), _ptr(out), nseq, L, heads, int(causal), None)
+            assert rc == 0, net._lib.mcm_last_error(net._h)
             torch.cuda.synchronize()
             np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=tol, atol=tol,
                                        err_msg=f"variant {variant}")
     finally:
-        lib.mcm_debug_attention_variant(1)
+        harness_net._lib.mcm_debug_attention_variant(1)
 
 
 def test_attention_full_size_bitwise_repeatable(tiny_net):

@@ -88,7 +88,7 @@ def test_towers_vs_hf_fixture(golden_dir, name, fixture, n_extra, precision):
         net.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
 def test_get_ood_scores_clip_vs_reference_outputs(golden_dir, precision):
     """Drive the re-written hot function exactly as the reference was driven when the
     fixture was captured (same weights, pixels, token ids, batch size)."""
@@ -128,6 +128,12 @@ def test_get_ood_scores_clip_vs_reference_outputs(golden_dir, precision):
                         np.testing.assert_allclose(got, want, atol=1e-4)
                     else:  # 88 samples: one rank swap moves AUROC by 5e-4; report, bound loosely
                         np.testing.assert_allclose(got, want, atol=2e-2)
+                if precision == "fp16":  # the default dtype against the reference's own scores
+                    tol = {"MCM": dict(rtol=2e-4, atol=1e-6), "max-logit": dict(rtol=0, atol=2e-4),
+                           "energy": dict(rtol=2e-4, atol=2e-4), "entropy": dict(rtol=2e-4, atol=1e-5),
+                           "var": dict(rtol=5e-2, atol=1e-8)}[score]
+                    np.testing.assert_allclose(s_in, g[f"{score}_T{T}_in"], **tol)
+                    np.testing.assert_allclose(s_out, g[f"{score}_T{T}_out"], **tol)
     finally:
         detection.load_tokenizer = old
         net.close()
@@ -168,18 +174,26 @@ def _auroc_case(name, K, n, precisions, fp16_exact_weights=False):
     return report
 
 
-def test_auroc_parity_vs_oracle_large_sample():
+@pytest.mark.parametrize("fp16_exact", [True, False], ids=["fp16-exact-weights", "fp32-valued-weights"])
+def test_auroc_parity_vs_oracle_large_sample(fp16_exact):
     """North-star bar |ΔAUROC|, |ΔAUPR|, |ΔFPR95| ≤ 1e-4 vs the fp32 ORACLE (CPU), on a sample large enough that
     1e-4 is above the metric quantum of every metric (tiny geometry, 2 x 20 000 images: FPR95 moves in steps
-    of 5e-5).  fp32 mode and fp16 mode (the benchmarked dtype) are held to the bar; bf16 is the documented
-    coarser arm and is bounded so a regression shows.  Seeded weights are rounded to fp16 for the oracle and
-    every arm alike — the case of the reference's checkpoints, whose weights were released in fp16; with
-    fp32-valued random weights the fp16 arm measured ΔAUROC 2.3e-6, ΔFPR95 2e-4 (4 of 20 000 samples)."""
-    rep = _auroc_case("tiny", K=20, n=20000, precisions=("fp32", "fp16", "bf16"), fp16_exact_weights=True)
-    print("tiny n=20000:", rep)
+    of 5e-5).  Both weight regimes are asserted:
+      * fp16-exact — seeded weights rounded to fp16 for the oracle and every arm alike, the case of the reference's
+        checkpoints (released in fp16): fp32 mode and fp16 mode (the benchmarked dtype) are held to the bar;
+      * fp32-valued seeded weights — the fp16 arm additionally rounds its operand copies of the weights: AUROC and
+        AUPR are held to the bar, FPR95 to the MEASURED bound of 3e-4 (round 2 measured 2e-4 = 4 of 20 000
+        samples on this geometry; it does not meet 1e-4 here and the test says so instead of hiding the regime).
+    bf16 is the documented coarser arm and is bounded so a regression shows."""
+    rep = _auroc_case("tiny", K=20, n=20000, precisions=("fp32", "fp16", "bf16"), fp16_exact_weights=fp16_exact)
+    print("tiny n=20000, fp16-exact weights =", fp16_exact, ":", rep)
     assert 0.05 < rep["fp32"]["oracle"][0] < 0.95  # non-degenerate AUROC
     assert rep["fp32"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
-    assert rep["fp16"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
+    d16 = rep["fp16"]["d_auroc_aupr_fpr"]
+    if fp16_exact:
+        assert d16.max() <= 1e-4, rep
+    else:
+        assert d16[0] <= 1e-4 and d16[1] <= 1e-4 and d16[2] <= 3e-4, rep
     d = rep["bf16"]["d_auroc_aupr_fpr"]
     assert d[0] <= 1e-3 and d[2] <= 5e-3, rep  # bf16 operands: measured drift, see DESIGN.md
 
@@ -193,9 +207,10 @@ def test_auroc_parity_vs_oracle_b16_2l():
     assert rep["bf16"]["d_auroc_aupr_fpr"][0] <= 5e-3, rep
 
 
-@pytest.fixture(scope="module")
-def b16():
-    net = _net("ViT-B/16", "bf16", max_batch=512, max_prompt_tokens=1000 * 20)
+@pytest.fixture(scope="module", params=["fp16", "bf16"])
+def b16(request):
+    """Full-size B/16 handle in the default dtype (fp16) and in BASELINE's bf16."""
+    net = _net("ViT-B/16", request.param, max_batch=512, max_prompt_tokens=1000 * 20)
     yield net
     net.close()
 
@@ -241,8 +256,8 @@ def test_full_size_bf16_vs_oracle_small_sample(b16):
     want = o.encode_image(px)
     got = b16.get_image_features(pixel_values=torch.from_numpy(px).cuda(), normalize=True).cpu().numpy()
     c = _cos(got, want)
-    print("bf16 vs fp32-oracle cosine (full B/16):", c, "max|d|", np.abs(got - want).max())
-    assert c.min() > 0.999
+    print("16-bit vs fp32-oracle cosine (full B/16):", c, "max|d|", np.abs(got - want).max())
+    assert c.min() > (0.999 if b16.precision == 0 else 0.99998)  # bf16 / fp16 (3 more significand bits)
 
 
 def test_errors_match_reference_behaviour(b16):

@@ -4,7 +4,7 @@ from mcm_amd.config import geometry
 from mcm_amd.engine import NativeCLIP
 from mcm_amd.weights import synth_state_dict
 geo = geometry("tiny")
-net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=8, max_prompt_tokens=2048)
+net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=8, max_prompt_tokens=2048, harness=True)
 lib = net._lib
 def ref(qkv, nseq, L, heads, causal):
     D = heads * 64

@@ -13,7 +13,7 @@ from mcm_amd.weights import synth_state_dict  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 geo = geometry("tiny")
-net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=8, max_prompt_tokens=2048)
+net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="bf16", max_batch=8, max_prompt_tokens=2048, harness=True)
 lib = net._lib
 
 

@@ -17,7 +17,7 @@ prec_name = sys.argv[2] if len(sys.argv) > 2 else "fp16"
 variants = [int(v) for v in sys.argv[3:]] or [3, 5]
 prec, dt = {"bf16": (0, torch.bfloat16), "fp16": (2, torch.float16)}[prec_name]
 geo = geometry("tiny")
-net = NativeCLIP(geo, synth_state_dict(geo, 0), precision=prec_name, max_batch=8, max_prompt_tokens=2048)
+net = NativeCLIP(geo, synth_state_dict(geo, 0), precision=prec_name, max_batch=8, max_prompt_tokens=2048, harness=True)
 lib = net._lib
 M, D, F = 512 * 197, 768, 3072
 g = torch.Generator(device="cuda").manual_seed(1)

@@ -15,7 +15,7 @@ from mcm_amd.weights import synth_state_dict  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 prec, dt = 2, torch.float16
 geo = geometry("tiny")
-net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="fp16", max_batch=8, max_prompt_tokens=2048)
+net = NativeCLIP(geo, synth_state_dict(geo, 0), precision="fp16", max_batch=8, max_prompt_tokens=2048, harness=True)
 lib = net._lib
 B, L, H, D, F = 512, 197, 12, 768, 3072
 M = B * L
