@@ -196,6 +196,7 @@ def parity_leg(args, K, B, device):
                           external=external)
         r = {"auroc_fp32_arm": d["reference"]["auroc"], "fpr95_fp32_arm": d["reference"]["fpr95"],
              "score_std_id": d["reference"]["score_std_id"], "seconds": time.perf_counter() - t0,
+             "fp16_saturation_events": d["fp16_saturation_events"].get("fp16"),
              "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys} for p in arms}}
         if "external" in d:
             r["auroc_hf"], r["fpr95_hf"] = d["external"]["hf"]["auroc"], d["external"]["hf"]["fpr95"]

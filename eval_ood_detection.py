@@ -10,8 +10,9 @@ Data.  `--root-dir` is honoured the way the reference's loaders read it (utils/t
 `<root>/ImageNet_OOD_dataset/{iNaturalist,SUN,Places,dtd/images}` for the OOD sets, read by
 mcm_amd.folder.ImageFolderU8 (Pillow decode on the host; Resize + CenterCrop + ToTensor + Normalize on the
 GPU, bit-exact with the reference's transform).  When a folder is missing — always the case offline — that
-set is the seeded synthetic set of mcm_amd.synth with the reference's dataset size, every set with its
-own seed, and the log, the console and `<log_directory>/data_sources.json` say so per set.  The fine-grained
+set is the seeded synthetic set of mcm_amd.synth with the reference's dataset size (generated in HBM, image i a
+function of (seed, i) only, so per-rank shards see the same pixels), every set with its own seed, and the log,
+the console and `<log_directory>/data_sources.json` say so per set.  The fine-grained
 ID suites (bird200 / car196 / food101 / pet37) have their own archive formats in the reference
 (dataloaders/*.py); only their synthetic form exists here.
 Under `torchrun` each rank scores a contiguous shard and the shards are all-gathered (rank 0 reports)."""
@@ -103,7 +104,7 @@ SEEDS = {"id": 1, "train": 7, "iNaturalist": 11, "SUN": 12, "places365": 13, "dt
 def _loader(args, net, what, n, ood, sources):
     """The loader for one set: the real folder when it exists under --root-dir, else the seeded synthetic
     set (recorded in `sources`, which ends up in the log and in data_sources.json)."""
-    from mcm_amd.synth import SyntheticImageSet, SyntheticLoader
+    from mcm_amd.synth import DevicePatternLoader
 
     if what in ("id", "train"):
         sub = (args.in_dataset, "val" if what == "id" else "train")
@@ -127,7 +128,7 @@ def _loader(args, net, what, n, ood, sources):
         n = min(n, args.synthetic_n)
     seed = SEEDS[what]
     sources[what] = {"kind": "synthetic", "n": n, "seed": seed, "why": f"{path} not found"}
-    return SyntheticLoader(SyntheticImageSet(n, net.geo.image_size, args.n_cls, ood, seed=seed), args.batch_size)
+    return DevicePatternLoader(n, net.geo.image_size, args.n_cls, args.batch_size, net.device, ood=ood, seed=seed)
 
 
 def main(argv=None):
@@ -142,10 +143,14 @@ def main(argv=None):
 
     args = process_args(argv)
     setup_seed(args.seed)
-    rank, ws, local = mdist.init_from_env()
-    log = setup_log(args)
     assert torch.cuda.is_available()
-    dev = local if ws > 1 else args.gpu
+    ndev = torch.cuda.device_count()
+    ws_env = int(os.environ.get("WORLD_SIZE", "1"))
+    # more ranks than devices (a 1-GPU box running the 2-rank logic check): the ranks share devices and the
+    # score all-gather goes over gloo with a host bounce, because RCCL refuses two ranks on one device
+    rank, ws, local = mdist.init_from_env(backend="gloo" if ws_env > ndev else None)
+    log = setup_log(args)
+    dev = (local % ndev) if ws > 1 else args.gpu
     torch.cuda.set_device(dev)
     net = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision=args.dtype,
                       max_batch=args.batch_size)
@@ -182,7 +187,10 @@ def main(argv=None):
         in_score = get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True)
     else:
         in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
+    net.warn_if_saturated(f"the ID set {args.in_dataset}")
     auroc_list, aupr_list, fpr_list = [], [], []
+    result = {"in_score": in_score, "out_scores": {}, "rank": rank, "world_size": ws, "sources": sources,
+              "log_directory": args.log_directory}
     for out_dataset in out_datasets:
         log.debug(f"Evaluting OOD dataset {out_dataset}")
         ood_loader = _loader(args, net, out_dataset, N_OOD[out_dataset], True, sources)
@@ -191,8 +199,11 @@ def main(argv=None):
             out_score = get_Mahalanobis_score(args, net, ood_loader, classwise_mean, precision, in_dist=False)
         else:
             out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
+        result["out_scores"][out_dataset] = out_score
+        net.warn_if_saturated(out_dataset)
         if rank == 0:
             get_and_print_results(args, log, in_score, out_score, auroc_list, aupr_list, fpr_list, net=net)
+    result["measures"] = {d: (a, p, f) for d, a, p, f in zip(out_datasets, auroc_list, aupr_list, fpr_list)}
     if rank == 0:
         log.debug("\n\nMean Test Results")
         print_measures(log, np.mean(auroc_list), np.mean(aupr_list), np.mean(fpr_list), method_name=args.score)
@@ -209,7 +220,12 @@ def main(argv=None):
                       "checks, not the paper's accuracy")
         with open(os.path.join(args.log_directory, "data_sources.json"), "w") as f:
             json.dump({"weights": args.weights or "seeded synthetic", "sets": sources}, f, indent=1)
+    # programmatic callers (tests) get the scores back; as device tensors they outlive the handle (torch owns them)
     net.close()
+    if ws > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

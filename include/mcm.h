@@ -273,6 +273,18 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
                      int32_t nseq, int32_t seq_len, int32_t heads, int32_t causal,
                      void* stream);
 
+/* fp16 saturation watch.  In MCM_PREC_F16 every 16-bit activation write saturates at +-65504 instead of
+ * overflowing to inf (MODE.FP16_OVFL) — which keeps a row finite but costs that element's precision.  So that
+ * this never happens unnoticed (a real checkpoint has outlier channels the seeded weights do not), the GEMM
+ * epilogues and the LayerNorm that write fp16 activations track the largest magnitude they packed and bump a
+ * sticky per-handle device counter once per wave that packed a saturating value (|v| >= 65520).
+ * mcm_saturation_count: *count_host = events since the last reset (0 = no activation of any call left the fp16
+ * range); synchronises `stream`; reset != 0 clears the counter.  mcm_saturation_check(h, 0) stops the kernels
+ * from reporting (the tracking itself is a handful of VALU instructions per tile and is always compiled in).
+ * Always 0 in MCM_PREC_BF16 / MCM_PREC_F32 (fp32 exponent range). */
+int mcm_saturation_check(mcm_handle* h, int32_t on);
+int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, void* stream);
+
 #ifdef MCM_HARNESS
 /* libmcm_hip_harness.so only (built with -DMCM_HARNESS next to the shipped library; loaded by the A/B tests
  * and tools, never by the product path).  Process-wide switches.

@@ -72,6 +72,29 @@ __device__ __forceinline__ void enter_precision_mode() {
   if constexpr (PREC == MCM_PREC_F16) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
 }
 
+// fp16 saturation watch.  FP16_OVFL makes an out-of-range activation cost that element's precision instead
+// of turning a row into NaN — silently.  Every kernel that packs fp32 values into fp16 activations therefore
+// keeps, per lane, the running max |value| it packed (one v_max3_f32 with |.| modifiers per PAIR, fp16 mode
+// only) and reports at its end: if any lane of a wave packed a value that saturated (|v| >= 65520, the first
+// value that rounds above 65504), one lane adds 1 to the handle's sticky device counter (mcm_saturation_count).
+// The atomic is inline asm like every other global access of the GEMM epilogues (invisible to hipcc's waitcnt
+// pass) and is the last VMEM instruction of its wave.
+template <int PREC>
+__device__ __forceinline__ void sat_track(float& amax, float a, float b) {
+  if constexpr (PREC == MCM_PREC_F16) amax = fmaxf(fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
+}
+template <int PREC>
+__device__ __forceinline__ void sat_report(float amax, unsigned int* counter) {
+  if constexpr (PREC == MCM_PREC_F16) {
+    if (counter != nullptr && __builtin_amdgcn_ballot_w64(amax >= 65520.0f) != 0) {
+      if ((threadIdx.x & 63) == 0) {
+        const unsigned int one = 1u;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(counter), "v"(one) : "memory");
+      }
+    }
+  }
+}
+
 // 16-bit operand modes: PREC selects the element format of MFMA operands and 16-bit outputs
 template <int PREC>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -133,6 +156,7 @@ struct GemmArgs {
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
   int rev;            // persistent kernel: walk the M tiles from the last to the first
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
+  unsigned int* sat;  // fp16 saturation counter of the handle (nullptr: not reported), see sat_report
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip and libmcm_hip_harness.so only
@@ -145,7 +169,8 @@ void attention_set_variant(int v);  // 1 = transpose-read kernel (the shipped on
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s,
-                            size_t x_stride = 0, size_t y_stride = 0, bool reverse = false);
+                            size_t x_stride = 0, size_t y_stride = 0, bool reverse = false,
+                            unsigned int* sat = nullptr);
 
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,

@@ -108,7 +108,7 @@ __device__ __forceinline__ int perm_n(int lr) {
 // epilogue of a (MF*16)x64 wave tile at (mw, nw)
 template <int PREC, int EPI, int MF>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
-                                              const f32x4_t (&bv)[4], int mw, int nw, int fr, int g) {
+                                              const f32x4_t (&bv)[4], int mw, int nw, int fr, int g, float& amax) {
   const int n = nw + g * 16;
   if (n >= a.N) return;
 #pragma unroll
@@ -139,6 +139,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) dst[fj] = v[fj] + pr[fj];
     } else if constexpr (PREC != MCM_PREC_F32) {
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        sat_track<PREC>(amax, v[fj][0], v[fj][1]);
+        sat_track<PREC>(amax, v[fj][2], v[fj][3]);
+      }
       uint4* dst = (uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n);
       dst[0] = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
                           pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
@@ -177,7 +182,7 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
 template <int PREC, int EPI, int MF, bool INTERIOR = false>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
-                                                  char* scratch) {
+                                                  char* scratch, float& amax) {
   const int fr = lane & 15, g = lane >> 4;
   if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
@@ -194,6 +199,8 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
         }
+        sat_track<PREC>(amax, v[fj][0], v[fj][1]);
+        sat_track<PREC>(amax, v[fj][2], v[fj][3]);
       }
       char* w = scratch + (u & 1) * 2048 + fr * 128;
       const int sw = fr & 7;
@@ -411,7 +418,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   }
   f32x4_t bv[4];
   load_bias(a, n0 + wc * 64 + g * 16, bv);
-  wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g);
+  float amax = 0.f;
+  wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
+  sat_report<PREC>(amax, a.sat);
 }
 
 #ifdef MCM_HARNESS
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
 
   f32x4_t acc[4][4];
   zero_acc(acc);
+  float amax = 0.f;
 
   set_issue_tile(0);
   int issued = 0;
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
       if (!counted) wait_vmcnt<0>();  // bias was issued in this very tile's first step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!DBG(4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g);
+      if (!DBG(4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g, amax);
       zero_acc(acc);
       // only a full tile issues exactly STORES_PER_EPI stores per wave; ragged tiles fall back
       // to waiting for the stores as well
@@ -583,6 +593,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
       }
     }
   }
+  sat_report<PREC>(amax, a.sat);
 }
 
 #endif  // MCM_HARNESS
@@ -711,6 +722,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 
   f32x4_t acc[4][8];
   zero_acc<8>(acc);
+  float amax = 0.f;
   f32x4_t bv[4];
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
         const int em0 = DBG(8) ? (int)(blockIdx.x & 63) * BM : cm0;
         const int en0 = DBG(8) ? 0 : cn0;
         wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
-                                        smem + 2 * STAGE_BYTES + wave * 4096);
+                                        smem + 2 * STAGE_BYTES + wave * 4096, amax);
       }
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
@@ -775,6 +787,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       }
     }
   }
+  sat_report<PREC>(amax, a.sat);
 }
 
 // fp32-row epilogue of a full (interior) 128x64 wave tile for the ping-pong kernel: the same LDS bounce and
@@ -999,6 +1012,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   };
   f32x4_t acc[4][8];
   zero_acc<8>(acc);
+  float amax = 0.f;  // fp16 saturation watch (sat_track / sat_report, common.hpp)
   auto mfma_pair = [&](const u32x4_t& wv4, const u32x4_t& xv4, f32x4_t& c) {
     if constexpr (PREC != MCM_PREC_F32) {
       c = mfma16<PREC>(__builtin_bit_cast(uint4, wv4), __builtin_bit_cast(uint4, xv4), c);
@@ -1038,7 +1052,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     if (!DBG(4)) {
       char* win = smem + 2 * STAGE_BYTES + wave * 4096;
       if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
-        wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+        wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
       else
         wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
     }
@@ -1155,6 +1169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
+  if constexpr (EPI <= EPI_GELU) sat_report<PREC>(amax, a.sat);
   PPT_DUMP();
 }
 
@@ -1199,7 +1214,7 @@ __device__ __forceinline__ f32x4_t quad(const f32x16_t& v, int q) {
 // nw + wb*32 + h*16 + q*4 .. +3; bv[1] is loaded here (asm, counted) and first used by unit 4.
 template <int PREC, int EPI>
 __device__ __forceinline__ void wave_epilogue16_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2], f32x4_t (&bv0)[4],
-                                                    int mw, int nw, int lane, char* scratch) {
+                                                    int mw, int nw, int lane, char* scratch, float& amax) {
   const int j = lane & 31, h = lane >> 5;
   f32x4_t bv1[4];
   if (a.bias) {
@@ -1221,6 +1236,8 @@ __device__ __forceinline__ void wave_epilogue16_b32(const GemmArgs& a, const f32
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[q][t] = quick_gelu_fast(v[q][t]);
       }
+      sat_track<PREC>(amax, v[q][0], v[q][1]);
+      sat_track<PREC>(amax, v[q][2], v[q][3]);
     }
     char* w = scratch + (u & 1) * 2048 + j * 64;
     const int sw = (j >> 1) & 3;
@@ -1411,6 +1428,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
       for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(xf[k][f]));
   };
   f32x16_t acc[4][2];
+  float amax = 0.f;
   auto zero = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1473,7 +1491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
         const f32x4_t bvf[2] = {bv[0], bv[1]};
         wave_epilogue_resid_b32(a, acc, bvf, em0 + wr * 128, en0 + wc * 64, le, win);
       } else {
-        wave_epilogue16_b32<PREC, EPI>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+        wave_epilogue16_b32<PREC, EPI>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
       }
     }
     zero();
@@ -1566,6 +1584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
+  if constexpr (!RESID) sat_report<PREC>(amax, a.sat);
 }
 
 #endif  // MCM_HARNESS

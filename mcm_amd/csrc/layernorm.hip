@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, void* y,
                                                         int M, int D, float eps, size_t xs,
-                                                        size_t ys, int rev, int nt) {
+                                                        size_t ys, int rev, int nt, unsigned int* sat) {
   enter_precision_mode<OUT>();
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int d = (i * 64 + lane) * 4;
@@ -66,19 +67,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
         uint2 pk;
         pk.x = pack2<OUT>(o.x, o.y);
         pk.y = pack2<OUT>(o.z, o.w);
+        sat_track<OUT>(amax, o.x, o.y);
+        sat_track<OUT>(amax, o.z, o.w);
         *(uint2*)((uint16_t*)y + (size_t)row * ys + d) = pk;
       } else {
         *(float4*)((float*)y + (size_t)row * ys + d) = o;
       }
     }
   }
+  sat_report<OUT>(amax, sat);
 }
 
 }  // namespace
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,
-                            size_t y_stride, bool reverse) {
+                            size_t y_stride, bool reverse, unsigned int* sat) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
   const size_t xs = x_stride ? x_stride : (size_t)D, ys = y_stride ? y_stride : (size_t)D;
   if (xs % 4 || ys % 4) return hipErrorInvalidValue;
@@ -89,10 +93,10 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
   // (measured: GEMM time -4 %, +3.3 % end to end).
   constexpr int nt = 1;
   if (prec == MCM_PREC_BF16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt, sat);
   else if (prec == MCM_PREC_F16 && !out_f32)
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt, sat);
   else
-    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt);
+    hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt, sat);
   return hipGetLastError();
 }

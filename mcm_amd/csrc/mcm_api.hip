@@ -73,6 +73,8 @@ struct mcm_handle {
   int64_t launches[MCM_KC_COUNT] = {0};
   double flops[MCM_KC_COUNT] = {0};
   bool flip = false;  // walk direction of the next kernel (next_dir)
+  unsigned int* sat_dev = nullptr;  // sticky fp16 saturation counter (common.hpp sat_report)
+  bool sat_on = true;
   std::string err;
 };
 
@@ -162,13 +164,15 @@ bool next_dir(mcm_handle* h) {
 hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs& a_in) {
   GemmArgs a = a_in;
   a.rev = next_dir(h) ? 1 : 0;
+  a.sat = h->sat_on ? h->sat_dev : nullptr;
   Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);
   return launch_gemm(prec, epi, a, s);
 }
 hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b,
                  void* y, int M, int D, bool out_f32) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
-  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s, 0, 0, next_dir(h));
+  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s, 0, 0, next_dir(h),
+                          h->sat_on ? h->sat_dev : nullptr);
 }
 hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int heads, bool causal,
                 int qrows = 0) {
@@ -179,7 +183,8 @@ hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int hea
 hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g,
                          const float* b, void* y, int M, int D, size_t xs, size_t ys) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
-  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys);
+  return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys, false,
+                          h->sat_on ? h->sat_dev : nullptr);
 }
 
 // CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place).
@@ -367,6 +372,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc rowidx");
   if (!rc) rc = dev_alloc(h, (void**)&h->prep_dev, (size_t)c.max_batch * sizeof(PrepImage));
+  if (!rc) rc = dev_alloc(h, (void**)&h->sat_dev, 16);
+  if (!rc && hipMemset(h->sat_dev, 0, 16) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset saturation counter");
   if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)c.max_batch * sizeof(PrepImage)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc prep");
   if (rc) {
@@ -699,6 +706,23 @@ int mcm_score(mcm_handle* h, const float* pixels_dev, int32_t B, const float* te
   return mcm_score_features(h, h->feat, B, text_feat_dev, K, T, kind, scores_dev, stream);
 }
 
+int mcm_saturation_check(mcm_handle* h, int32_t on) {
+  if (!h) return MCM_EINVAL;
+  h->sat_on = on != 0;
+  return MCM_OK;
+}
+
+int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, void* stream) {
+  if (!h || !count_host) return fail(h, MCM_EINVAL, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned int v = 0;
+  HIP_TRY(h, hipMemcpyAsync(&v, h->sat_dev, sizeof(v), hipMemcpyDeviceToHost, s));
+  if (reset) HIP_TRY(h, hipMemsetAsync(h->sat_dev, 0, sizeof(v), s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  *count_host = v;
+  return MCM_OK;
+}
+
 int mcm_profile_enable(mcm_handle* h, int32_t on) {
   if (!h) return MCM_EINVAL;
   h->prof = on != 0;
@@ -735,6 +759,7 @@ int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_
   GemmArgs a{};
   a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.out = y_dev; a.resid = resid_dev;
   a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
+  a.sat = h->sat_on ? h->sat_dev : nullptr;
   HIP_TRY(h, launch_gemm(prec, epi, a, (hipStream_t)stream));
   return MCM_OK;
 }
@@ -744,7 +769,7 @@ int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const floa
                      void* stream) {
   if (!h) return MCM_EINVAL;
   HIP_TRY(h, launch_layernorm(prec, x_dev, gamma_dev, beta_dev, y_dev, M, D, eps, out_f32 != 0,
-                              (hipStream_t)stream));
+                              (hipStream_t)stream, 0, 0, false, h->sat_on ? h->sat_dev : nullptr));
   return MCM_OK;
 }
 

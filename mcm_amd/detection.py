@@ -196,8 +196,8 @@ def get_mean_prec(args, net, train_loader):
                 f = f / f.norm(dim=-1, keepdim=True)
             feats.append(f.cpu())
             # labels >= n_cls are ignored, like the reference's per-class loop (:161-166) never visits them
-            counts.append(np.bincount(np.asarray(labels, dtype=np.int64).reshape(-1),
-                                      minlength=args.n_cls)[: args.n_cls])
+            lab = labels.detach().cpu().numpy() if hasattr(labels, "detach") else np.asarray(labels)
+            counts.append(np.bincount(lab.astype(np.int64).reshape(-1), minlength=args.n_cls)[: args.n_cls])
     F = torch.cat(feats)                                    # [n, P] float32, dataset order
     n_cb = torch.from_numpy(np.stack(counts, axis=1).astype(np.float64))  # [n_cls, n_batches]
     rows = F[: n_cb.shape[1]].double()                       # the rows the reference's indices select
@@ -249,6 +249,9 @@ def _gather_batch_shards(local, n_total, ws):
     import torch
     import torch.distributed as dist
 
+    home = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:  # ranks sharing a device (logic checks): host bounce
+        local = local.cpu()
     cnt = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
     cnts = torch.empty(ws, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(cnts, cnt)
@@ -260,7 +263,7 @@ def _gather_batch_shards(local, n_total, ws):
     buf[: local.numel()] = local
     out = torch.empty(ws * cap, dtype=torch.float32, device=local.device)
     dist.all_gather_into_tensor(out, buf)
-    return torch.cat([out[r * cap: r * cap + cnts[r]] for r in range(ws)])
+    return torch.cat([out[r * cap: r * cap + cnts[r]] for r in range(ws)]).to(home)
 
 
 def print_measures(log, auroc, aupr, fpr, method_name="Ours", recall_level=0.95):

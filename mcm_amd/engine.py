@@ -92,6 +92,8 @@ def load_library(harness: bool = False):
     L.mcm_maha_score_features.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
     L.mcm_measures.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, i32, ctypes.c_double,
                                ctypes.POINTER(ctypes.c_double), vp]
+    L.mcm_saturation_check.argtypes = [vp, i32]
+    L.mcm_saturation_count.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64), vp]
     if L.mcm_abi_version() != 1:
         raise RuntimeError("libmcm_hip.so ABI version mismatch")
     _libs[harness] = L
@@ -107,6 +109,7 @@ EXPORTED_SYMBOLS = [
     "mcm_tokenizer_destroy", "mcm_tokenizer_last_error", "mcm_tokenizer_vocab_size", "mcm_tokenizer_encode",
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
+    "mcm_saturation_check", "mcm_saturation_count",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant"]
 
@@ -344,6 +347,28 @@ class NativeCLIP:
         self._check(self._lib.mcm_score_histogram(self._h, x.data_ptr(), x.numel(), e.data_ptr(),
                                                   e.numel() - 1, out.data_ptr(), _stream_ptr()))
         return out
+
+    # -- fp16 saturation watch ---------------------------------------------------------------
+    def saturation_count(self, reset: bool = True) -> int:
+        """Waves that packed an fp16 activation at the saturation value (±65504) since the last reset, over
+        every call on this handle; 0 = nothing left the fp16 range.  Always 0 in bf16 / fp32 mode."""
+        out = ctypes.c_uint64(0)
+        self._check(self._lib.mcm_saturation_count(self._h, int(reset), ctypes.byref(out), _stream_ptr()))
+        return int(out.value)
+
+    def saturation_check(self, on: bool):
+        self._check(self._lib.mcm_saturation_check(self._h, int(on)))
+
+    def warn_if_saturated(self, what: str = "") -> int:
+        """RuntimeWarning when any fp16 activation saturated since the last call (the CLI calls this per set)."""
+        n = self.saturation_count(reset=True)
+        if n:
+            import warnings
+
+            warnings.warn(f"fp16 activations saturated at +-65504 in {n} wave(s){' while scoring ' + what if what else ''}: "
+                          "those elements lost precision (outlier channels?) — rerun with --dtype bf16 or fp32 to compare",
+                          RuntimeWarning, stacklevel=2)
+        return n
 
     # -- per-kernel timing -------------------------------------------------------------------
     def profile(self, on: bool):

@@ -75,6 +75,8 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                 scores[p][tag] = torch.cat(parts[p])
         out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood, "batch": batch, "score": score,
                "T": T, "reference_arm": ref, "pixels": {"amp": amp, "tile": tile}, "weights": weights, "arms": {}}
+        # fp16 activations that hit +-65504 anywhere in the run (sticky per-handle counters; 0 = none)
+        out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in names if p == "fp16"}
         m_ref = nets[ref].measures(scores[ref]["id"], scores[ref]["ood"], negate=True)
         sid = scores[ref]["id"]
         out["reference"] = {"auroc": m_ref[0], "aupr": m_ref[1], "fpr95": m_ref[2],

@@ -143,9 +143,11 @@ class DevicePatternLoader:
     """Headline-scale ID / OOD sets generated in HBM: the same construction as `make_pixels`
     (unit noise + a class-conditional low-frequency pattern from the ID or the OOD frequency
     family) with torch's device generator, so 50k + 10k 224-px images cost no host time and no
-    PCIe traffic.  Batch `s` is seeded by (seed, ood, s): any precision arm that walks the same
-    loader sees bit-identical pixels, and a sharded walk sees the same samples as a full one as
-    long as shard boundaries fall on batch boundaries."""
+    PCIe traffic.  The noise is drawn in aligned blocks of `BLOCK` images, block b seeded by
+    (seed, ood, b): image i depends only on (seed, ood, i), so any batching and any sharding of the
+    index range — per-rank shards under torchrun included — sees bit-identical pixels."""
+
+    BLOCK = 64
 
     def __init__(self, n: int, size: int, n_classes: int, batch_size: int, device, *, ood: bool,
                  seed: int = 1, amp: float = 1.5, noise: float = 1.0, tile: float = 0.0,
@@ -173,10 +175,15 @@ class DevicePatternLoader:
         yy, xx = ax.view(1, 1, S, 1), ax.view(1, 1, 1, S)
         ch = torch.arange(3, device=dev, dtype=torch.float32).view(1, 3, 1, 1)
         w = 2 * math.pi / S
+        B = self.BLOCK
         for s in range(self.lo, self.hi, self.batch_size):
             n = min(self.batch_size, self.hi - s)
-            g.manual_seed((d.seed << 24) ^ (fam << 23) ^ s)
-            x = torch.randn((n, 3, S, S), generator=g, device=dev, dtype=torch.float32) * self.noise
+            parts = []
+            for b in range(s // B, (s + n - 1) // B + 1):
+                g.manual_seed(((d.seed << 24) ^ (fam << 23)) + b)
+                blk = torch.randn((B, 3, S, S), generator=g, device=dev, dtype=torch.float32)
+                parts.append(blk[max(s - b * B, 0): min(s + n - b * B, B)])
+            x = (torch.cat(parts) if len(parts) > 1 else parts[0].clone()) * self.noise
             lab = (torch.arange(s, s + n, device=dev) % d.n_classes)
             c = (lab + (1000 if d.ood else 0)).to(torch.float32).view(n, 1, 1, 1)
             fx = (1 + torch.remainder(c * 3 + ch, 5) + 5 * fam) * w

@@ -1,0 +1,131 @@
+"""BASELINE.json configs 1 and 2 run VERBATIM through the command line on the HIP path (never run):
+
+  C1  `--in_dataset ImageNet10 --CLIP_ckpt ViT-B/16 -b 64`  (ImageNet-10 ID vs ImageNet-20 OOD, the full 500 + 1 000
+      images, K = 10; reference eval_ood_detection.py:63-68, utils/common.py:36-60) in fp32 and in fp16: the first 16
+      ID scores against the C oracle on the same pixels and prompts, device metrics == host (sklearn) metrics;
+  C2  `--in_dataset ImageNet100 --dtype bf16`  (5 000 ID + iNaturalist / SUN / Places / Textures at 10 000 / 10 000 /
+      10 000 / 5 640, K = 100, batch 512): the size-independent invariants of test_full_size_properties at K = 100, and
+      bf16's (and fp16's) AUROC / FPR95 difference to the exact-fp32 arm per OOD set — bf16 is the dtype BASELINE names
+      for this config and it does NOT meet 1e-4; the test records by how much and bounds it.
+  plus the same CLI under `torchrun --nproc-per-node 2` (two ranks sharing the one GPU, gloo): the CSV equals the 1-rank CSV.
+
+No dataset exists offline: every set is the seeded synthetic set of the reference's size (mcm_amd.synth), generated in
+HBM; weights are the seeded stand-ins."""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_config1_imagenet10_vs_imagenet20_b16_batch64(tmp_path, monkeypatch, dtype):
+    import pandas as pd
+
+    import eval_ood_detection as cli
+    from mcm_amd import detection
+    from mcm_amd.config import geometry
+    from mcm_amd.metrics import get_measures
+    from mcm_amd.synth import DevicePatternLoader
+    from mcm_amd.weights import synth_state_dict
+    from oracle import oracle as orc
+    from utils.common import get_test_labels
+
+    monkeypatch.chdir(tmp_path)
+    r = cli.main(["--in_dataset", "ImageNet10", "--CLIP_ckpt", "ViT-B/16", "-b", "64", "--dtype", dtype,
+                  "--name", "c1", "--synthetic"])
+    s_in, s_out = _np(r["in_score"]), _np(r["out_scores"]["ImageNet20"])
+    assert s_in.shape == (500,) and s_out.shape == (1000,)          # the full sets of config 1
+    assert s_in.dtype == np.float32 and np.isfinite(s_in).all() and np.isfinite(s_out).all()
+    assert (s_in <= -1.0 / 10 + 1e-6).all() and (s_in >= -1.0).all()  # MCM = -max softmax over K = 10
+    # first 16 ID images against the C oracle: same pixels (regenerated: image i = f(seed, i)), same prompts
+    geo = geometry("ViT-B/16")
+    args = types.SimpleNamespace(in_dataset="ImageNet10", ckpt="openai/clip-vit-base-patch16", weights=None)
+    labels = get_test_labels(args)
+    tok = detection._tokenizer(args, None)
+    ids = tok([detection.PROMPT.format(c=c) for c in labels], padding=True, return_tensors="pt")["input_ids"].numpy()
+    px = next(iter(DevicePatternLoader(500, 224, 10, 64, torch.device("cuda", 0), ood=False, seed=cli.SEEDS["id"])))[0]
+    o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
+    want = orc.score_features(o.encode_image(px[:16].cpu().numpy()), o.encode_text(ids), 1.0, 0)
+    tol = dict(rtol=0, atol=2e-7) if dtype == "fp32" else dict(rtol=0, atol=2e-5)
+    np.testing.assert_allclose(s_in[:16], want, **tol)
+    # device metrics (the CLI's default route) == host metrics (sklearn, the reference's route) on the same scores
+    a, p, f = r["measures"]["ImageNet20"]
+    ha, hp, hf = get_measures(-s_in, -s_out)
+    assert abs(a - ha) <= 1e-12 and abs(p - hp) <= 1e-12 and f == hf
+    df = pd.read_csv(tmp_path / "results/ImageNet10/MCM/CLIP_ViT-B/16_T_1_ID_c1/c1.csv", index_col=0)
+    assert list(df.index) == ["ImageNet20", "AVG"]
+    np.testing.assert_allclose(df.loc["ImageNet20"].values, np.round([100 * f, 100 * a, 100 * p], 2), atol=1e-9)
+
+
+def test_config2_imagenet100_bf16_full_size(tmp_path, monkeypatch):
+    import eval_ood_detection as cli
+    from mcm_amd.metrics import get_measures
+
+    monkeypatch.chdir(tmp_path)
+    common = ["--in_dataset", "ImageNet100", "--CLIP_ckpt", "ViT-B/16", "--synthetic"]
+    sizes = {"iNaturalist": 10000, "SUN": 10000, "places365": 10000, "dtd": 5640}
+    runs = {}
+    with pytest.warns(RuntimeWarning):  # ImageNet-100's class-name files are not on this box: placeholder names
+        for dt in ("bf16", "fp32", "fp16"):
+            runs[dt] = cli.main(common + ["--dtype", dt, "--name", f"c2_{dt}"])
+    r = runs["bf16"]
+    s_in = _np(r["in_score"])
+    assert s_in.shape == (5000,)
+    K = 100
+    assert (s_in <= -1.0 / K + 1e-7).all() and (s_in >= -1.0).all() and np.isfinite(s_in).all()
+    for name, n in sizes.items():
+        s = _np(r["out_scores"][name])
+        assert s.shape == (n,) and np.isfinite(s).all() and (s <= -1.0 / K + 1e-7).all()
+        a, p, f = r["measures"][name]
+        ha, hp, hf = get_measures(-s_in, -s)                       # device metrics == host metrics
+        assert abs(a - ha) <= 1e-12 and abs(p - hp) <= 1e-12 and f == hf
+        assert 0.0 < a < 1.0
+    # determinism at size: a second bf16 run writes bit-identical scores
+    again = cli.main(common + ["--dtype", "bf16", "--name", "c2_bf16_again"])
+    assert torch.equal(again["in_score"], r["in_score"])
+    assert all(torch.equal(again["out_scores"][k], r["out_scores"][k]) for k in sizes)
+    # drift of the 16-bit modes against the exact-fp32 arm, per OOD set (quantum of FPR95: 1e-4, dtd 1.8e-4)
+    report = {}
+    for dt in ("bf16", "fp16"):
+        report[dt] = {k: tuple(abs(x - y) for x, y in zip(runs[dt]["measures"][k], runs["fp32"]["measures"][k]))
+                      for k in sizes}
+    print("config 2 drift vs the fp32 arm (dAUROC, dAUPR, dFPR95):", report)
+    for k in sizes:
+        da, dp, df = report["fp16"][k]
+        assert da <= 1e-4 and dp <= 1e-4 and df <= 2e-4, (k, report["fp16"][k])   # <= one sample of the OOD set
+        da, dp, df = report["bf16"][k]
+        assert da <= 5e-3 and df <= 1e-2, (k, report["bf16"][k])                  # the documented coarser arm
+
+
+def test_cli_two_ranks_equal_one_rank(tmp_path):
+    """eval_ood_detection.py under torchrun, world size 2 (both ranks on the one GPU of the test box, gloo): rank-0
+    reporting, per-rank shards of the device-generated sets, device metrics after the gather — CSV == the 1-rank CSV."""
+    import pandas as pd
+
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = [os.path.join(ROOT, "eval_ood_detection.py"), "--in_dataset", "ImageNet10", "--CLIP_ckpt", "ViT-B/32",
+              "-b", "64", "--synthetic", "--synthetic-n", "333"]
+    one = subprocess.run([sys.executable] + common + ["--name", "ws1"], cwd=tmp_path, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533"] + common + ["--name", "ws2"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    base = tmp_path / "results" / "ImageNet10" / "MCM"
+    a = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws1" / "ws1.csv", index_col=0)
+    b = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws2" / "ws2.csv", index_col=0)
+    assert list(a.index) == ["ImageNet20", "AVG"] and a.equals(b), (a, b)

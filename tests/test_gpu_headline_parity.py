@@ -48,6 +48,7 @@ def test_headline_parity_vs_hf_reference(weights):
     b = d["arms"]["bf16"]["vs_external"]["hf"]
     assert b["d_auroc"] <= 3e-3 and b["d_fpr95"] <= 3e-3, b
     assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
+    assert d["fp16_saturation_events"] == {"fp16": 0}, d["fp16_saturation_events"]  # nothing left the fp16 range
 
 
 def test_l14_parity_vs_hf_reference():

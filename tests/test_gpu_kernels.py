@@ -434,6 +434,7 @@ def test_fp16_outputs_saturate_instead_of_overflowing(tiny_net, epi):
         want = want / (1.0 + np.exp(-1.702 * want.astype(np.float64)))
     y = torch.zeros((M, N), device="cuda", dtype=torch.float16)
     xd, wd, bd = _dev(x, torch.float16), _dev(w, torch.float16), _dev(b)   # keep the operands alive
+    tiny_net.saturation_count(reset=True)
     rc = tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), None, M, N, K, epi, None)
     assert rc == 0
     torch.cuda.synchronize()
@@ -444,6 +445,48 @@ def test_fp16_outputs_saturate_instead_of_overflowing(tiny_net, epi):
         assert got[3, 6] == -65504.0
     ok = np.abs(want) < 6e4
     np.testing.assert_allclose(got[ok], np.asarray(want, np.float32)[ok], rtol=2e-3, atol=2e-3)
+    # ... and not silently: the handle's sticky counter saw it (mcm_saturation_count), once, then reads 0 again
+    assert tiny_net.saturation_count(reset=True) >= 1
+    assert tiny_net.saturation_count() == 0
+    with pytest.warns(RuntimeWarning, match="saturated"):
+        tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(xd), _ptr(wd), _ptr(bd), _ptr(y), None, M, N, K, epi, None)
+        assert tiny_net.warn_if_saturated("a test") >= 1
+    # the same product in bf16 mode (fp32 exponent range) and an in-range fp16 launch report nothing
+    yb = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+    xb, wb = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16)
+    assert tiny_net._lib.mcm_op_linear(tiny_net._h, 0, _ptr(xb), _ptr(wb), _ptr(bd), _ptr(yb), None, M, N, K, epi, None) == 0
+    xs = _dev(x * 1e-3, torch.float16)
+    assert tiny_net._lib.mcm_op_linear(tiny_net._h, 2, _ptr(xs), _ptr(wd), _ptr(bd), _ptr(y), None, M, N, K, epi, None) == 0
+    assert tiny_net.saturation_count() == 0
+
+
+def test_fp16_saturation_counter_in_the_persistent_gemm_kernels(tiny_net, harness_net):
+    """The same watch in the 256x256 persistent kernels (plain and ping-pong), on a problem made of whole tiles with
+    one saturating element, through the shipped library (its own kernel choice) and every forced variant."""
+    M, N, K = 1024, 512, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.float16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.float16)
+    bias = torch.zeros(N, device="cuda")
+    y = torch.zeros((M, N), device="cuda", dtype=torch.float16)
+    xs = x.clone()
+    xs[777, :] = 250.0
+    ws = w.clone()
+    ws[300, :] = 250.0     # 250 * 250 * 128 = 8e6
+    try:
+        for variant in (-1, 0, 3, 5, 6):
+            net = tiny_net if variant < 0 else harness_net
+            if variant >= 0:
+                assert net._lib.mcm_debug_gemm_variant(variant) == 0
+            net.saturation_count(reset=True)
+            assert net._lib.mcm_op_linear(net._h, 2, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), None, M, N, K, 0, None) == 0
+            assert net.saturation_count() == 0, variant
+            assert net._lib.mcm_op_linear(net._h, 2, _ptr(xs), _ptr(ws), _ptr(bias), _ptr(y), None, M, N, K, 0, None) == 0
+            assert net.saturation_count() >= 1, variant
+            torch.cuda.synchronize()
+            assert float(y[777, 300]) == 65504.0 and torch.isfinite(y).all()
+    finally:
+        harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
 def test_fp16_layernorm_and_attention_saturate(tiny_net):
@@ -453,9 +496,11 @@ def test_fp16_layernorm_and_attention_saturate(tiny_net):
     gamma = torch.full((128,), 3e4, device="cuda")   # (x - mean) / std ~ 11.3 at column 0 -> 3.4e5
     beta = torch.zeros(128, device="cuda")
     y = torch.zeros((8, 128), device="cuda", dtype=torch.float16)
+    tiny_net.saturation_count(reset=True)
     assert lib.mcm_op_layernorm(tiny_net._h, 2, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), 8, 128, 1e-5, 0, None) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and float(y[0, 0]) == 65504.0
+    assert tiny_net.saturation_count() >= 1   # the LayerNorm reports it too
 
 
 @pytest.mark.parametrize("P,geo_name", [(512, "ViT-B/16"), (768, "ViT-L/14")])
