@@ -50,17 +50,20 @@ DEFAULT_PRECISION = "fp16"  # the 16-bit mode that holds AUROC/FPR95 to the fp32
 
 
 def pmc_traffic(family="gemm"):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, written by tools/traffic_json.py); None when absent."""
+    """L2<->fabric bytes per launch of a kernel family (and per GEMM shape class) from the committed rocprofv3
+    PMC passes (profiles/*_traffic.json, written by tools/traffic_json.py); None when absent."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     try:
-        return json.load(open(files[-1]))["per_launch_bytes"][family]["hbm_bytes"], os.path.basename(files[-1])
+        per = json.load(open(files[-1]))["per_launch_bytes"]
+        shapes = {k: {"l2_fabric_bytes": v["hbm_bytes"], "algorithmic_bytes": v.get("algorithmic_bytes"),
+                      "ratio": v.get("ratio")} for k, v in per.items() if k.startswith("gemm_") and "text" not in k}
+        return per[family]["hbm_bytes"], os.path.basename(files[-1]), shapes or None
     except Exception:
-        return None, None
+        return None, None, None
 
 
 class SmiSampler(threading.Thread):
@@ -251,6 +254,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=-1,
                     help="A/B hook: >= 0 loads libmcm_hip_harness.so and forces a GEMM kernel variant "
                          "(mcm_debug_gemm_variant); -1 = the shipped library and its own choice")
+    ap.add_argument("--qkv-chunks", type=int, default=1, help="A/B hook (harness library): QKV + attention per batch chunk")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
@@ -283,11 +287,13 @@ def main():
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), harness=args.gemm_variant >= 0)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), harness=args.gemm_variant >= 0 or args.qkv_chunks > 1)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
                                 normalize=True)
+    if args.qkv_chunks > 1 and net._lib.mcm_debug_qkv_chunks(args.qkv_chunks) != 0:
+        raise SystemExit("bad --qkv-chunks")
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     nbuf = min(4, max(1, args.steps))
@@ -371,6 +377,8 @@ def main():
                        "batch_per_gpu": B, "prompts": K, "parallelism": f"image-sharded x{ws}"},
             "gflop_per_image": nominal,
         }
+        if args.qkv_chunks > 1:
+            line["harness_qkv_chunks"] = args.qkv_chunks
         if args.gemm_variant >= 0:
             line["harness"] = f"libmcm_hip_harness.so, GEMM variant {args.gemm_variant} forced (A/B run, not the shipped policy)"
         if ws > 1:
@@ -384,16 +392,25 @@ def main():
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            traffic, traffic_src = pmc_traffic("gemm") if B == 512 else (None, None)
+            traffic, traffic_src, traffic_shapes = pmc_traffic("gemm") if B == 512 else (None, None, None)
             line["roofline"] = {
                 "bound": "mfma", "kernel": "persistent 256x256 GEMM family: gemm_pp_kernel + gemm_p256_kernel (all GEMM launches of a step)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak if ach else None,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_unit": "HBM bytes per launch = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC, profiles/",
+                "traffic_unit": "L2<->fabric bytes per launch (L2 misses + write-backs, Infinity-Cache hits included: an "
+                                "upper bound on HBM bytes) = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC, profiles/",
+                "traffic_per_shape": traffic_shapes,
                 "avg_launch_us": 1e3 * g["ms"] / g["launches"] if g["launches"] else None,
                 "flop_per_launch": g["flops"] / g["launches"] if g["launches"] else None,
             }
+            if sustained and "sclk_mhz_mean" in sustained:
+                # the part runs this kernel family at its package power limit: the clock it sustains, not the
+                # 2.4 GHz the 2.5 PF/s peak assumes, is what `frac` is achieved at
+                line["roofline"]["sustained_sclk_mhz"] = sustained["sclk_mhz_mean"]
+                line["roofline"]["sustained_power_w"] = sustained["power_w_mean"]
+                line["roofline"]["frac_of_peak_at_sustained_clock"] = \
+                    (ach / (peak * sustained["sclk_mhz_mean"] / 2400.0)) if ach else None
             tot = sum(v["ms"] for v in prof.values())
             executed = sum(v["flops"] for v in prof.values()) / n_prof / B / 1e9
             line["kernel_ms_per_step"] = {k: round(v["ms"] / n_prof, 4) for k, v in prof.items()}

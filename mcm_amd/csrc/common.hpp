@@ -81,7 +81,9 @@ __device__ __forceinline__ void enter_precision_mode() {
 // pass) and is the last VMEM instruction of its wave.
 template <int PREC>
 __device__ __forceinline__ void sat_track(float& amax, float a, float b) {
+#ifndef MCM_NO_SAT_TRACK  // (defined only for the overhead A/B build of tools/_call.sh)
   if constexpr (PREC == MCM_PREC_F16) amax = fmaxf(fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
+#endif
 }
 template <int PREC>
 __device__ __forceinline__ void sat_report(float amax, unsigned int* counter) {

@@ -174,12 +174,20 @@ hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const f
   return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, out_f32, s, 0, 0, next_dir(h),
                           h->sat_on ? h->sat_dev : nullptr);
 }
+// seq0: first sequence of the launch (a chunk of the batch starts there)
 hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int heads, bool causal,
-                int qrows = 0) {
+                int qrows = 0, int seq0 = 0) {
   const int q = qrows > 0 ? qrows : L;
   Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)q * L * 64 * (causal ? 0.5 : 1.0));
-  return launch_attention(prec, h->qkv, h->att, nseq, L, heads, causal, qrows, s, next_dir(h));
+  const size_t es = prec_esize(prec), D = (size_t)heads * 64, row0 = (size_t)seq0 * L;
+  return launch_attention(prec, (const char*)h->qkv + row0 * 3 * D * es, (char*)h->att + row0 * D * es, nseq, L,
+                          heads, causal, qrows, s, next_dir(h));
 }
+#ifdef MCM_HARNESS
+int g_qkv_chunks = 1;  // A/B: QKV projection + attention per chunk of the batch (qkv of a chunk stays in the Infinity Cache)
+#else
+constexpr int g_qkv_chunks = 1;
+#endif
 hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g,
                          const float* b, void* y, int M, int D, size_t xs, size_t ys) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
@@ -201,11 +209,16 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
     HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
     if (!cls) {
-      GemmArgs a{};
-      a.x = h->ln; a.w = w.wqkv; a.bias = w.bqkv; a.out = h->qkv;
-      a.M = M; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
-      HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
-      HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal));
+      const int nch = (g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
+      for (int c = 0; c < nch; ++c) {
+        const int sq = nseq / nch, r0 = c * sq * L;
+        GemmArgs a{};
+        a.x = (const char*)h->ln + (size_t)r0 * D * es; a.w = w.wqkv; a.bias = w.bqkv;
+        a.out = (char*)h->qkv + (size_t)r0 * 3 * D * es;
+        a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
+        HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
+        HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq));
+      }
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
       kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * D * es; kv.bias = w.bqkv + D;
@@ -783,8 +796,14 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
 
 #ifdef MCM_HARNESS  // libmcm_hip_harness.so only: process-wide A/B switches for tests and tools
 int mcm_debug_attention_variant(int32_t variant) {
-  if (variant < 0 || variant > 1) return MCM_EINVAL;
+  if (variant < 0 || variant > 4) return MCM_EINVAL;
   attention_set_variant(variant);
+  return MCM_OK;
+}
+
+int mcm_debug_qkv_chunks(int32_t n) {
+  if (n < 1 || n > 16) return MCM_EINVAL;
+  g_qkv_chunks = n;
   return MCM_OK;
 }
 
