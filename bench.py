@@ -171,7 +171,7 @@ def parity_leg(args, K, B, device):
     """AUROC / AUPR / FPR95 of every native arm against the exact-fp32 arm AND against the HF CLIPModel fp32
     reference running on the same device over the same 50 000 + 10 000 device-generated images, in both weight
     regimes.  Outside the timed region; the HF scorer is the checker (oracle/hf_reference.py), never measured."""
-    from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
+    from mcm_amd.parity import CONFIG3_OOD_SETS, HEADLINE_PIXELS, measure_drift
 
     external, hf_note = None, None
     if not args.no_hf:
@@ -186,8 +186,15 @@ def parity_leg(args, K, B, device):
         except Exception as e:
             hf_note = f"HF reference scorer unavailable ({type(e).__name__}: {e}): vs_hf not measured"
     arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16")))
-    out = {"n_id": args.drift_n[0], "n_ood": args.drift_n[1], "pixels": {k: HEADLINE_PIXELS[k] for k in ("amp", "tile")},
-           "bar": "north_star: |dAUROC|, |dFPR95| <= 1e-4 (FPR95 quantum at 10 000 OOD images = 1e-4)",
+    c3 = tuple(args.drift_n) == (50000, 10000)  # default: BASELINE config 3 — ImageNet-1k vs the four OOD sets
+    ood_sets = CONFIG3_OOD_SETS if c3 else None
+    out = {"config": "BASELINE config 3: ImageNet-1k-sized ID set (50 000) vs iNaturalist / SUN / Places / Textures-sized "
+                     "OOD sets (10 000 / 10 000 / 10 000 / 5 640), K = 1000; headline keys = the AVG row of the reference's "
+                     "CSV, per_set = every OOD set on its own" if c3 else "one ID and one OOD set (--drift-n)",
+           "n_id": args.drift_n[0], "n_ood": {n: c for n, c, _ in CONFIG3_OOD_SETS} if c3 else args.drift_n[1],
+           "pixels": {k: HEADLINE_PIXELS[k] for k in ("amp", "tile")},
+           "bar": "north_star: |dAUROC|, |dFPR95| <= 1e-4.  FPR95 of ONE set is a count of images on the ID side of one "
+                  "threshold (quantum 1e-4 at 10 000 images): per_set carries it as d_fpr95_images",
            "reference_arms": "exact-fp32 MFMA arm of this library; HF transformers CLIPModel fp32 eager on this device"}
     if hf_note:
         out["vs_hf_note"] = hf_note
@@ -196,11 +203,11 @@ def parity_leg(args, K, B, device):
         t0 = time.perf_counter()
         d = measure_drift(args.ckpt, K=K, n_id=args.drift_n[0], n_ood=args.drift_n[1], batch=B, arms=arms,
                           device=device, amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights,
-                          external=external)
+                          external=external, ood_sets=ood_sets)
         r = {"auroc_fp32_arm": d["reference"]["auroc"], "fpr95_fp32_arm": d["reference"]["fpr95"],
              "score_std_id": d["reference"]["score_std_id"], "seconds": time.perf_counter() - t0,
              "fp16_saturation_events": d["fp16_saturation_events"].get("fp16"),
-             "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys} for p in arms}}
+             "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys + (("per_set",) if c3 else ())} for p in arms}}
         if "external" in d:
             r["auroc_hf"], r["fpr95_hf"] = d["external"]["hf"]["auroc"], d["external"]["hf"]["fpr95"]
             r["vs_hf"] = {"fp32_arm": d["reference"]["vs_external"]["hf"],

@@ -25,16 +25,25 @@ from typing import Callable, Dict, Optional, Sequence
 # and are therefore exact as fp16 MFMA operands.  See DESIGN.md §2 for the other regimes measured.
 HEADLINE_PIXELS = dict(amp=1.5, tile=0.0, weights="fp16-exact")
 
+# BASELINE config 3 — the configuration the metric is quoted on: ImageNet-1k ID (50 000 images) against the four OOD
+# sets of the reference's default run, (name, size, seed): eval_ood_detection.py:63-68, sizes SURVEY.md §8a-A9.
+# `measure_drift(ood_sets=CONFIG3_OOD_SETS)` scores the ID set once and reports every OOD set and the AVG row, like
+# the reference's CSV.
+CONFIG3_OOD_SETS = (("iNaturalist", 10000, 11), ("SUN", 10000, 12), ("places365", 10000, 13), ("dtd", 5640, 14))
+
 
 def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n_ood: int = 10000,
                   batch: int = 512, arms: Sequence[str] = ("bf16", "fp16"), ref: str = "fp32",
                   device: int = 0, score: str = "MCM", T: float = 1.0, amp: float = 1.5,
                   tile: float = 0.0, weights: str = "fp32", seed: int = 1,
-                  external: Optional[Dict[str, Callable]] = None) -> Dict:
+                  external: Optional[Dict[str, Callable]] = None,
+                  ood_sets: Optional[Sequence] = None) -> Dict:
     """weights="fp16-exact": every parameter of the seeded state dict is rounded to the nearest fp16 value
     first (for ALL arms, the fp32 reference included) — the situation of the reference's checkpoints, whose
     Linear / conv / projection weights were trained and released in fp16, so an fp16 operand copy of them is
-    lossless and only activation rounding separates the fp16 arm from the fp32 one."""
+    lossless and only activation rounding separates the fp16 arm from the fp32 one.
+    ood_sets = ((name, size, seed), ...): several OOD sets against the one ID set; d_auroc / d_aupr / d_fpr95 of an
+    arm are then the differences of the AVG row (mean of the per-set metrics), `per_set` holds each set's own."""
     import torch
 
     from .config import geometry
@@ -62,9 +71,13 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             nets[p] = NativeCLIP(geo, sd, device=device, precision=p, max_batch=batch,
                                  max_prompt_tokens=max(K * ids.shape[1], 77))
             banks[p] = nets[p].get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+        # one OOD set (the default) or several: BASELINE config 3 scores the ID set once against four OOD sets and
+        # reports every set plus their average (the reference's CSV, eval_ood_detection.py:86-98)
+        sets = [("ood", n_ood, seed)] if not ood_sets else [(str(n), int(c), int(sd_)) for n, c, sd_ in ood_sets]
+        tags = ["id"] + [n for n, _, _ in sets]
         scores = {p: {} for p in names + list(ext)}
-        for tag, n, ood in (("id", n_id, False), ("ood", n_ood, True)):
-            loader = DevicePatternLoader(n, geo.image_size, K, batch, dev, ood=ood, seed=seed, amp=amp, tile=tile)
+        for tag, n, ood, sd_ in [("id", n_id, False, seed)] + [(n, c, True, s_) for n, c, s_ in sets]:
+            loader = DevicePatternLoader(n, geo.image_size, K, batch, dev, ood=ood, seed=sd_, amp=amp, tile=tile)
             parts = {p: [] for p in names + list(ext)}
             for px, _ in loader:
                 for p in names:
@@ -73,33 +86,45 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                     parts[e].append(fn(px).to(device=dev, dtype=torch.float32).reshape(-1))
             for p in parts:
                 scores[p][tag] = torch.cat(parts[p])
-        out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood, "batch": batch, "score": score,
-               "T": T, "reference_arm": ref, "pixels": {"amp": amp, "tile": tile}, "weights": weights, "arms": {}}
+        out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood if not ood_sets else {n: c for n, c, _ in sets},
+               "batch": batch, "score": score, "T": T, "reference_arm": ref, "pixels": {"amp": amp, "tile": tile},
+               "weights": weights, "arms": {}}
         # fp16 activations that hit +-65504 anywhere in the run (sticky per-handle counters; 0 = none)
         out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in names if p == "fp16"}
-        m_ref = nets[ref].measures(scores[ref]["id"], scores[ref]["ood"], negate=True)
+
+        def measures(p):  # per OOD set, and the AVG row (mean over the sets) — what the metrics are quoted on
+            per = {n: nets[ref].measures(scores[p]["id"], scores[p][n], negate=True) for n, _, _ in sets}
+            avg = tuple(sum(m[i] for m in per.values()) / len(per) for i in range(3))
+            return per, avg
+
+        def delta(p, q):
+            (pp, pa), (qp, qa) = meas[p], meas[q]
+            d = torch.cat([(scores[p][t] - scores[q][t]).abs() for t in tags])
+            r = {"d_auroc": abs(pa[0] - qa[0]), "d_aupr": abs(pa[1] - qa[1]), "d_fpr95": abs(pa[2] - qa[2]),
+                 "max_abs_dscore": float(d.max()), "rms_dscore": float(d.pow(2).mean().sqrt())}
+            if len(sets) > 1:  # the keys above are the AVG row; every set on its own, FPR95 also as an image count
+                r["per_set"] = {n: {"d_auroc": abs(pp[n][0] - qp[n][0]), "d_aupr": abs(pp[n][1] - qp[n][1]),
+                                    "d_fpr95": abs(pp[n][2] - qp[n][2]),
+                                    "d_fpr95_images": round(abs(pp[n][2] - qp[n][2]) * c)} for n, c, _ in sets}
+            return r
+
+        meas = {p: measures(p) for p in names + list(ext)}
+        m_ref = meas[ref][1]
         sid = scores[ref]["id"]
+        sood = torch.cat([scores[ref][n] for n, _, _ in sets])
         out["reference"] = {"auroc": m_ref[0], "aupr": m_ref[1], "fpr95": m_ref[2],
                             "score_mean_id": float(sid.mean()), "score_std_id": float(sid.std()),
-                            "score_mean_ood": float(scores[ref]["ood"].mean()),
-                            "score_std_ood": float(scores[ref]["ood"].std())}
-        def delta(p, q, m_p, m_q):
-            d = torch.cat([(scores[p][t] - scores[q][t]).abs() for t in ("id", "ood")])
-            return {"d_auroc": abs(m_p[0] - m_q[0]), "d_aupr": abs(m_p[1] - m_q[1]),
-                    "d_fpr95": abs(m_p[2] - m_q[2]), "max_abs_dscore": float(d.max()),
-                    "rms_dscore": float(d.pow(2).mean().sqrt())}
-
-        meas = {ref: m_ref}
-        for p in names[1:] + list(ext):
-            meas[p] = nets[ref].measures(scores[p]["id"], scores[p]["ood"], negate=True)
+                            "score_mean_ood": float(sood.mean()), "score_std_ood": float(sood.std())}
+        if len(sets) > 1:
+            out["reference"]["per_set"] = {n: dict(zip(("auroc", "aupr", "fpr95"), meas[ref][0][n])) for n, _, _ in sets}
         for p in names[1:]:
-            m = meas[p]
-            out["arms"][p] = {"auroc": m[0], "aupr": m[1], "fpr95": m[2], **delta(p, ref, m, m_ref)}
+            m = meas[p][1]
+            out["arms"][p] = {"auroc": m[0], "aupr": m[1], "fpr95": m[2], **delta(p, ref)}
         if ext:
-            out["external"] = {e: {"auroc": meas[e][0], "aupr": meas[e][1], "fpr95": meas[e][2]} for e in ext}
-            out["reference"]["vs_external"] = {e: delta(ref, e, m_ref, meas[e]) for e in ext}
+            out["external"] = {e: dict(zip(("auroc", "aupr", "fpr95"), meas[e][1])) for e in ext}
+            out["reference"]["vs_external"] = {e: delta(ref, e) for e in ext}
             for p in names[1:]:
-                out["arms"][p]["vs_external"] = {e: delta(p, e, meas[p], meas[e]) for e in ext}
+                out["arms"][p]["vs_external"] = {e: delta(p, e) for e in ext}
         return out
     finally:
         for n in nets.values():
