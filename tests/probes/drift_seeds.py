@@ -1,11 +1,11 @@
 """Distribution of the fp16 arm's AUROC / AUPR / FPR95 difference to the exact-fp32 arm over independent draws of the
 headline sets (the FPR95 difference is a count of images crossing one threshold: 0, 1, 2 ... x 1e-4):
-python tools/drift_seeds.py [weights] [n_seeds] [tile]  ->  one JSON line"""
+python tests/probes/drift_seeds.py [weights] [n_seeds] [tile]  ->  one JSON line"""
 import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mcm_amd.parity import measure_drift  # noqa: E402
 
 weights = sys.argv[1] if len(sys.argv) > 1 else "fp16-exact"

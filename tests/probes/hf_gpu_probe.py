@@ -1,11 +1,11 @@
 """HF CLIPModel fp32 on the GPU box's device vs the native arms, same device-generated images
-(tools probe for the parity.vs_hf leg): python tools/hf_gpu_probe.py [ckpt n_id n_ood batch weights arms K]"""
+(tools probe for the parity.vs_hf leg): python tests/probes/hf_gpu_probe.py [ckpt n_id n_ood batch weights arms K]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from mcm_amd.parity import measure_drift  # noqa: E402

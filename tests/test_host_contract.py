@@ -112,7 +112,141 @@ def test_device_pattern_loader_is_deterministic_and_shardable():
     assert torch.equal(a, b) and a.shape == (20, 3, 32, 32)
     parts = torch.cat([x for x, _ in full.shard(0, 8)] + [x for x, _ in full.shard(8, 20)])
     assert torch.equal(a, parts)                      # shard boundaries on batch boundaries
+    # ... and anywhere else: image i is a function of (seed, i) only (noise drawn in aligned 64-image blocks), so the
+    # per-rank shards of mcm_amd.dist.shard_range and any other batch size see the same pixels
+    big = DevicePatternLoader(150, 16, 7, 64, dev, ood=False)
+    whole = torch.cat([x for x, _ in big])
+    odd = torch.cat([x for x, _ in big.shard(0, 75)] + [x for x, _ in big.shard(75, 150)])
+    rebatched = torch.cat([x for x, _ in DevicePatternLoader(150, 16, 7, 37, dev, ood=False)])
+    assert torch.equal(whole, odd) and torch.equal(whole, rebatched)
     ood = torch.cat([x for x, _ in DevicePatternLoader(20, 32, 7, 8, dev, ood=True, tile=1.0)])
     assert not torch.equal(a, ood)
     labs = torch.cat([y for _, y in full])
     assert labs.tolist() == [i % 7 for i in range(20)]
+
+
+def test_folder_subset_is_the_reference_rule(tmp_path):
+    """`--subset`: the first max_count samples of every class in dataset order (reference
+    utils/train_eval_util.py:56-64)."""
+    from mcm_amd.folder import FolderIndex
+
+    for c, n in (("a", 5), ("b", 2), ("c", 3)):
+        for i in range(n):
+            p = tmp_path / c / f"{i}.png"
+            p.parent.mkdir(parents=True, exist_ok=True)
+            p.write_bytes(b"x")
+    idx = FolderIndex(str(tmp_path))
+    sub = idx.first_per_class(3)
+    assert len(idx) == 10 and len(sub) == 8 and sub.classes == idx.classes
+    assert sub.targets == [0, 0, 0, 1, 1, 2, 2, 2]
+    assert [os.path.basename(p) for p, _ in sub.samples] == ["0.png", "1.png", "2.png", "0.png", "1.png", "0.png",
+                                                             "1.png", "2.png"]
+
+
+def test_image_folder_decode_pool_keeps_order(tmp_path):
+    """The threaded decode (batch i+1 decoded while batch i is scored) yields the same batches, in order, as the
+    serial path."""
+    torch = pytest.importorskip("torch")
+    from PIL import Image
+
+    from mcm_amd.folder import ImageFolderU8
+
+    rng = np.random.default_rng(0)
+    for c in ("x", "y"):
+        for i in range(5):
+            p = tmp_path / c / f"{i}.png"
+            p.parent.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (8 + i, 9, 3), dtype=np.uint8)).save(p)
+
+    class Net:  # resize_crop stand-in: hand the decoded images back
+        def resize_crop(self, imgs):
+            return [im.clone() for im in imgs]
+
+    def walk(workers):
+        out = []
+        for imgs, labels in ImageFolderU8(str(tmp_path), Net(), 3, workers=workers):
+            out.append(([im.numpy() for im in imgs], labels.tolist()))
+        return out
+
+    serial, pooled = walk(1), walk(4)
+    assert len(serial) == len(pooled) == 4
+    for (a, la), (b, lb) in zip(serial, pooled):
+        assert la == lb and len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_hash_tokenizer_is_refused_by_a_net_with_real_weights():
+    """A reference-shaped caller has only args.ckpt; whether the hash stand-in is acceptable is decided by what the
+    net says about its weights, falling back to args.weights for nets that do not say."""
+    from mcm_amd import detection
+    from mcm_amd.tokenizer import TokenizerUnavailable
+
+    args = types.SimpleNamespace(ckpt="openai/clip-vit-base-patch16")
+    real = types.SimpleNamespace(synthetic_weights=False)
+    synth = types.SimpleNamespace(synthetic_weights=True)
+    with pytest.raises(TokenizerUnavailable):
+        detection._tokenizer(args, real)
+    with pytest.warns(RuntimeWarning, match="HashTokenizer"):
+        assert detection._tokenizer(args, synth) is not None
+    args.weights = "clip.safetensors"          # a net that does not say: the old rule
+    with pytest.raises(TokenizerUnavailable):
+        detection._tokenizer(args, types.SimpleNamespace())
+
+
+def test_prompt_bank_is_encoded_once_per_net_and_key():
+    torch = pytest.importorskip("torch")
+    from mcm_amd import detection
+
+    class Net:
+        synthetic_weights = True
+        calls = 0
+
+        def get_text_features(self, input_ids, attention_mask=None, normalize=False):
+            Net.calls += 1
+            assert normalize is True   # the fused form is detected from the signature, not by catching TypeError
+            return torch.ones(input_ids.shape[0], 4)
+
+    class Plain:   # a net honouring only the HF contract: normalised here
+        synthetic_weights = True
+
+        def get_text_features(self, input_ids, attention_mask=None):
+            return torch.full((input_ids.shape[0], 4), 2.0)
+
+    args = types.SimpleNamespace(ckpt="x", templates=None)
+    net = Net()
+    with pytest.warns(RuntimeWarning):
+        a = detection.prompt_bank(args, net, ["cat", "dog"])
+        b = detection.prompt_bank(args, net, ["cat", "dog"])
+        assert a is b and Net.calls == 1
+        detection.prompt_bank(args, net, ["cat", "dog", "eel"])     # another bank: re-encoded
+        assert Net.calls == 2
+        args.templates = ["a {c}", "the {c}"]
+        net.reduce_bank = lambda f, K, T: f.view(K, T, -1).mean(1)
+        assert detection.prompt_bank(args, net, ["cat", "dog", "eel"]).shape == (3, 4) and Net.calls == 3
+        f = detection.prompt_bank(types.SimpleNamespace(ckpt="x", templates=None), Plain(), ["cat"])
+    assert torch.allclose(f.norm(dim=1), torch.ones(1))
+
+
+def test_get_mean_prec_ignores_labels_beyond_n_cls(tmp_path):
+    """A batch holding a label >= n_cls used to make the per-batch count arrays ragged; the reference's
+    per-class loop simply never visits such labels."""
+    torch = pytest.importorskip("torch")
+    from mcm_amd import detection
+
+    rng = np.random.default_rng(0)
+    feats = torch.from_numpy(rng.standard_normal((12, 6)).astype(np.float32))
+
+    class Net:
+        def __init__(self):
+            self.i = 0
+
+        def get_image_features(self, pixel_values):
+            out = feats[self.i:self.i + pixel_values.shape[0]]
+            self.i += pixel_values.shape[0]
+            return out
+
+    batches = [(torch.zeros(4, 1), torch.tensor([0, 1, 2, 7])), (torch.zeros(4, 1), torch.tensor([1, 1, 0, 2])),
+               (torch.zeros(4, 1), torch.tensor([2, 0, 9, 1]))]
+    args = types.SimpleNamespace(n_cls=3, normalize=False, template_dir=None, model="CLIP", in_dataset="x",
+                                 max_count=250)
+    mean, prec = detection.get_mean_prec(args, Net(), batches)
+    assert mean.shape == (3, 6) and prec.shape == (6, 6) and torch.isfinite(mean).all()
