@@ -61,11 +61,11 @@ def test_headline_parity_vs_hf_reference(weights):
 def test_l14_parity_vs_hf_reference():
     """BASELINE config 4 (ViT-L/14 fp16, batch 256) with 10 000 OOD images, so that FPR95's quantum is 1e-4
     (round 2 ran 5 000: one sample = 2e-4).  The full 50 000 + 10 000 run is profiles/r03_parity_L14_50k_vs_hf.json
-    (fp16 vs HF: dAUROC 1.2e-5, dFPR95 0; 4 minutes); here 20 000 + 10 000.  FPR95 as an image count, see above:
-    measured 0 and 4 images on two draws."""
+    (fp16 vs HF: dAUROC 1.2e-5, dFPR95 0; 4 minutes); here 10 000 + 10 000 (80 s).  FPR95 as an image count, see
+    above: measured 0 and 4 images on two draws of a 20 000 + 10 000 set."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-L/14", K=1000, n_id=20000, n_ood=10000, batch=256, arms=("fp16",),
+    d = measure_drift("ViT-L/14", K=1000, n_id=10000, n_ood=10000, batch=256, arms=("fp16",),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp16-exact",
                       external=_external())
     print("L/14 parity (fp16-exact weights):", json.dumps(d))
