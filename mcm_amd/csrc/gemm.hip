@@ -968,6 +968,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
     const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
     const size_t ko = (size_t)kti * ROWB;
+    if (DBG(1)) return;  // harness ablation: no LDS-DMA
     if (i < 4) {
       glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
     }
     __builtin_amdgcn_s_setprio(1);
-    compute(fo1, sr);
+    if (!DBG(2)) compute(fo1, sr);  // harness ablation 2: no MFMAs (and none of the compute phase's fragment reads)
     __builtin_amdgcn_s_setprio(0);
     PPT(2);
     wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago

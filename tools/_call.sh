@@ -1,7 +1,9 @@
 #!/bin/bash
-# scratch driver (round 3, call 10): the whole GPU suite on the final tree + smoke
-mkdir -p gpurun_out/r3c10
-O=$PWD/gpurun_out/r3c10
-( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=12 ) > $O/pytest.txt 2>&1
-grep -E "passed|failed|^E |slowest" -A13 $O/pytest.txt | tail -22
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
+# scratch driver (round 3, call 12): energy per component of the ping-pong GEMM (ablation bits x power / clock sampling)
+mkdir -p gpurun_out/r3c12
+O=$PWD/gpurun_out/r3c12
+for sh in "2304 768 0 qkv" "3072 768 1 fc1" "768 3072 2 fc2"; do set -- $sh
+  for dbg in 0 4 16 5 6 7; do
+    bash tools/smi_sample.sh $4_$dbg tools/gemm_bench 100864 $1 $2 $3 3000 0 $dbg 3 0x20 2>&1 | grep -E "BEST|busy samples" | tr '\n' ' '; echo
+  done
+done 2>&1 | tee $O/energy.txt
