@@ -1,4 +1,4 @@
-"""BASELINE.json configs 1 and 2 run VERBATIM through the command line on the HIP path (never run):
+"""BASELINE.json configs 1, 2 and 5 run through the command line on the HIP path (1 and 2 were never run):
 
   C1  `--in_dataset ImageNet10 --CLIP_ckpt ViT-B/16 -b 64`  (ImageNet-10 ID vs ImageNet-20 OOD, the full 500 + 1 000
       images, K = 10; reference eval_ood_detection.py:63-68, utils/common.py:36-60) in fp32 and in fp16: the first 16
@@ -7,6 +7,8 @@
       10 000 / 5 640, K = 100, batch 512): the size-independent invariants of test_full_size_properties at K = 100, and
       bf16's (and fp16's) AUROC / FPR95 difference to the exact-fp32 arm per OOD set — bf16 is the dtype BASELINE names
       for this config and it does NOT meet 1e-4; the test records by how much and bounds it.
+  C5  `--in_dataset {bird200,food101,pet37,car196} --templates FILE` (the fine-grained ID suites at their test-split sizes,
+      80 templates x K prompts) against the four OOD sets;
   plus the same CLI under `torchrun --nproc-per-node 2` (two ranks sharing the one GPU, gloo): the CSV equals the 1-rank CSV.
 
 No dataset exists offline: every set is the seeded synthetic set of the reference's size (mcm_amd.synth), generated in
@@ -135,3 +137,36 @@ def test_cli_two_ranks_equal_one_rank(tmp_path):
     a = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws1" / "ws1.csv", index_col=0)
     b = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws2" / "ws2.csv", index_col=0)
     assert list(a.index) == ["ImageNet20", "AVG"] and a.equals(b), (a, b)
+
+
+@pytest.mark.parametrize("suite,K,n_id", [("bird200", 200, 5794), ("food101", 101, 25250), ("pet37", 37, 3669),
+                                          ("car196", 196, 8041)])
+def test_config5_finegrained_suite_with_80_template_bank(tmp_path, monkeypatch, suite, K, n_id):
+    """BASELINE config 5 through the command line at the suites' own sizes: CUB-200 / Food-101 / Pets / Cars as the ID
+    set (K = 200 / 101 / 37 / 196 concepts; test-split sizes of SURVEY.md §8d), the bank built from 80 templates x K
+    prompts (`--templates FILE`), against the four OOD sets.  Size-independent checks: shapes, range of -max softmax
+    over K, device metrics == host metrics per set, and that the 80-template bank differs from the single-prompt one."""
+    import pandas as pd
+
+    import eval_ood_detection as cli
+    from mcm_amd.metrics import get_measures
+
+    monkeypatch.chdir(tmp_path)
+    t = tmp_path / "templates80.txt"
+    t.write_text("\n".join(f"a photo of a {{c}}, rendition {i}." if i % 2 else f"style {i}: the {{c}}" for i in range(80)) + "\n")
+    common = ["--in_dataset", suite, "--CLIP_ckpt", "ViT-B/16", "--synthetic"]
+    with pytest.warns(RuntimeWarning):   # the suites' class names come from their archives, which are not on this box
+        r = cli.main(common + ["--name", "c5", "--templates", str(t)])
+        single = cli.main(common + ["--name", "c5_single", "--synthetic-n", "512"])
+    s_in = _np(r["in_score"])
+    assert s_in.shape == (n_id,) and np.isfinite(s_in).all()
+    assert (s_in <= -1.0 / K + 1e-7).all() and (s_in >= -1.0).all()
+    for name, n in {"iNaturalist": 10000, "SUN": 10000, "places365": 10000, "dtd": 5640}.items():
+        s = _np(r["out_scores"][name])
+        assert s.shape == (n,) and np.isfinite(s).all()
+        a, p, f = r["measures"][name]
+        ha, hp, hf = get_measures(-s_in, -s)
+        assert abs(a - ha) <= 1e-12 and abs(p - hp) <= 1e-12 and f == hf
+    assert not np.array_equal(s_in[:512], _np(single["in_score"])[:512])   # the ensemble bank is another bank
+    df = pd.read_csv(tmp_path / f"results/{suite}/MCM/CLIP_ViT-B/16_T_1_ID_c5/c5.csv", index_col=0)
+    assert list(df.index) == ["iNaturalist", "SUN", "places365", "dtd", "AVG"] and np.isfinite(df.values).all()
