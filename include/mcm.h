@@ -296,6 +296,8 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
 int mcm_debug_gemm_variant(int32_t variant);
 /* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel. */
 int mcm_debug_attention_variant(int32_t variant);
+/* A/B and ablation bits of the GEMM kernels (gemm.hip, GemmArgs::dbg; 0 = shipped behaviour). */
+int mcm_debug_gemm_dbg(int32_t bits);
 /* A/B: run the QKV projection + attention of every layer per chunk of the batch (n chunks; 1 = shipped). */
 int mcm_debug_qkv_chunks(int32_t n);
 #endif

@@ -874,6 +874,19 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
       : "memory");
 }
 
+#ifdef MCM_HARNESS
+// the same with the non-temporal hint (harness A/B, dbg bit 32: X pieces streamed so that W stays L2-resident)
+__device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+#endif
+
 // harness-only phase timing of the ping-pong kernel: s_memtime deltas accumulated in scalar registers (stamps
 // only where the wave has to drain lgkmcnt anyway), split into mid-tile steps and steps that carry an epilogue;
 // written out once at the end (a.pos = uint32 buffer [block][wave][2][5]: 4 sums + step count)
@@ -970,6 +983,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     const size_t ko = (size_t)kti * ROWB;
     if (DBG(1)) return;  // harness ablation: no LDS-DMA
     if (i < 4) {
+#ifdef MCM_HARNESS
+      if (DBG(32)) {
+        glds16s_nt(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+        return;
+      }
+#endif
       glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
       const int q = i - 4;

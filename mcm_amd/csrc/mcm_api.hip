@@ -801,6 +801,11 @@ int mcm_debug_attention_variant(int32_t variant) {
   return MCM_OK;
 }
 
+int mcm_debug_gemm_dbg(int32_t bits) {  // ablation / A-B bits of gemm.hip (GemmArgs::dbg)
+  gemm_set_dbg(bits);
+  return MCM_OK;
+}
+
 int mcm_debug_qkv_chunks(int32_t n) {
   if (n < 1 || n > 16) return MCM_EINVAL;
   g_qkv_chunks = n;

@@ -73,6 +73,7 @@ def load_library(harness: bool = False):
         L.mcm_debug_gemm_variant.argtypes = [i32]
         L.mcm_debug_attention_variant.argtypes = [i32]
         L.mcm_debug_qkv_chunks.argtypes = [i32]
+        L.mcm_debug_gemm_dbg.argtypes = [i32]
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
@@ -112,7 +113,8 @@ EXPORTED_SYMBOLS = [
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
     "mcm_saturation_check", "mcm_saturation_count",
 ]
-HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks"]
+HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
+                        "mcm_debug_gemm_dbg"]
 
 
 def _stream_ptr():
