@@ -54,6 +54,14 @@ constexpr int ROWB = 128;  // bytes of K per row per K-step
 #else
 #define DBG(bit) false
 #endif
+// Ablation bits INSIDE the ping-pong K-loop (1 no LDS-DMA, 2 no MFMA, 32 X panels with the nt hint) cost the loop
+// registers and branches even when they are off (-2 ... -10 % on the harness kernel, measured), so they exist only
+// in a dedicated build of tools/gemm_bench (-DMCM_HARNESS -DMCM_GEMM_ABLATE), not in libmcm_hip_harness.so.
+#if defined(MCM_HARNESS) && defined(MCM_GEMM_ABLATE)
+#define ABL(bit) (a.dbg & (bit))
+#else
+#define ABL(bit) false
+#endif
 
 __device__ __forceinline__ int frag_off(int fr, int g, int kk) {
   return (fr >> 1) * 256 + ((((fr & 1) << 3) | (((kk * 4 + g) ^ (fr >> 1)) & 7)) << 4);
@@ -567,12 +575,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) 
     asm volatile("" ::: "memory");
     if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
     if (issued < total) {  // refill the stage that step s-1 just finished reading
-      if (!DBG(1)) issue(ist);
+      if (!ABL(1)) issue(ist);
       ist = ist == NSTAGE - 1 ? 0 : ist + 1;
       ++issued;
     }
     const char* sb = smem + st * STAGE_BYTES;
-    if (!DBG(2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
+    if (!ABL(2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
     st = st == NSTAGE - 1 ? 0 : st + 1;
     ++since_epi;
     if (++ktc == nk) {
@@ -756,15 +764,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
     // priority 1) compute the first K half, refill, compute the second.
     const bool refill = issued < total;
-    if (refill && !late && !DBG(1)) issue(issued & 1);
+    if (refill && !late && !ABL(1)) issue(issued & 1);
     TRACE(3);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
-    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
+    if (!ABL(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
     TRACE(4);
-    if (refill && late && !DBG(1)) issue(issued & 1);
+    if (refill && late && !ABL(1)) issue(issued & 1);
     if (refill) ++issued;
     TRACE(5);
-    if (!DBG(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
+    if (!ABL(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
     TRACE(6);
     if (++ktc == nk) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
@@ -981,10 +989,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
     const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
     const size_t ko = (size_t)kti * ROWB;
-    if (DBG(1)) return;  // harness ablation: no LDS-DMA
+    if (ABL(1)) return;  // ablation build: no LDS-DMA
     if (i < 4) {
-#ifdef MCM_HARNESS
-      if (DBG(32)) {
+#if defined(MCM_HARNESS) && defined(MCM_GEMM_ABLATE)
+      if (ABL(32)) {
         glds16s_nt(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
         return;
       }
@@ -1169,7 +1177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
     }
     __builtin_amdgcn_s_setprio(1);
-    if (!DBG(2)) compute(fo1, sr);  // harness ablation 2: no MFMAs (and none of the compute phase's fragment reads)
+    if (!ABL(2)) compute(fo1, sr);  // ablation build: no MFMAs (and none of the compute phase's fragment reads)
     __builtin_amdgcn_s_setprio(0);
     PPT(2);
     wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago

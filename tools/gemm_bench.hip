@@ -1,5 +1,5 @@
 // gemm_bench.hip — standalone A/B harness for the GEMM kernels of mcm_amd/csrc/gemm.hip.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMCM_HARNESS [-DMCM_GEMM_TRACE] -I mcm_amd/csrc tools/gemm_bench.hip \
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMCM_HARNESS [-DMCM_GEMM_TRACE] [-DMCM_GEMM_ABLATE: in-loop ablation bits 1 / 2 / 32] -I mcm_amd/csrc tools/gemm_bench.hip \
 //        mcm_amd/csrc/gemm.hip -o /tmp/gemm_bench
 // Run:   gemm_bench M N K epi [iters]   → per-variant time / TFLOP/s, max |diff| vs variant 0
 #include <stdio.h>
