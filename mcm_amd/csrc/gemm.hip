@@ -927,7 +927,11 @@ __device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uin
 #define PPT_DUMP()
 #endif
 
-template <int PREC, int EPI>
+// BAL (balanced DMA): waves 0-3 stage their X half and W rows 0-127, waves 4-7 their X half and W rows 128-255 —
+// 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
+// waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
+// was last read (W fragments, by these very waves) a whole step earlier, so no ring of three is needed.
+template <int PREC, int EPI, bool BAL = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   using namespace p256;
   enter_precision_mode<PREC>();
@@ -999,10 +1003,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 #endif
       glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
-      const int q = i - 4;
+      const int q = BAL ? grp * 4 + (i - 4) : i - 4;
       glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
     }
   };
+  constexpr int NP0 = BAL ? 8 : 12;  // pieces per step of waves 0-3
   auto issue_done = [&]() {
     if (++kti == nk) {
       kti = 0;
@@ -1096,8 +1101,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   {
     const LaneK lk = lane_consts();
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
-      if (i < 4 || !grp) piece(lk, 0, i);
+    for (int i = 0; i < NP0; ++i)
+      if (BAL || i < 4 || !grp) piece(lk, 0, i);
   }
   issue_done();
   wait_vmcnt<0>();
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       if (!grp) {
         const LaneK lk = lane_consts();
 #pragma unroll
-        for (int i = 0; i < 12; ++i) piece(lk, si, i);
+        for (int i = 0; i < NP0; ++i) piece(lk, si, i);
         issue_done();
         phase_barrier();
       }
@@ -1149,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       fo1 = lk.fo1;
       if (!grp) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < NP0; ++i) {
           if (i < 8) {
             readf(lk, sr, 2 * i);
             readf(lk, sr, 2 * i + 1);
@@ -1157,16 +1162,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
           piece(lk, si, i);
         }
       } else {
+        if constexpr (BAL) {  // W first: it has to land within this phase
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+          for (int i = 4; i < 8; ++i) {
+            readf(lk, sr, 2 * (i - 4));
+            readf(lk, sr, 2 * (i - 4) + 1);
+            piece(lk, si, i);
+          }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
-          piece(lk, si, i);
+          for (int i = 0; i < 4; ++i) {
+            readf(lk, sr, 8 + 2 * i);
+            readf(lk, sr, 8 + 2 * i + 1);
+            piece(lk, si, i);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
+            piece(lk, si, i);
+          }
         }
       }
       issue_done();
     }
     pin_frags();
+    if constexpr (BAL) {
+      if (grp) wait_vmcnt<4>();  // everything older than this phase's 4 X pieces: the W pieces waves 0-3 read next
+    }
     PPT(0);
     if (!split) phase_barrier();
     PPT(1);
@@ -1684,16 +1707,16 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI>
+template <int PREC, int EPI, bool BAL = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1729,6 +1752,12 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
   if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
   if (v == 4) return launch_p256<PREC, EPI, true>(a, s);
+  if (v == 7) {  // ping-pong with balanced DMA (8 + 8 pieces); else as 5
+    if constexpr (EPI != EPI_PATCH) {
+      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI, true>(a, s);
+    }
+    v = 5;
+  }
   if (v == 6) {  // ping-pong on 32x32x16 MFMAs: 16-bit operand modes, whole tiles; else as 5
     if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
       if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp32<PREC, EPI>(a, s);
