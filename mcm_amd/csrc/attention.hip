@@ -550,6 +550,10 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
   if (nt == 13 && g_attn_variant == 3) return launch_tr<PREC, 13, 8, 3, 2>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
   if (nt == 13 && g_attn_variant == 4) return launch_tr<PREC, 13, 8, 3, 3>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  // wave-count arms: one q-block per wave (13 waves, 832 threads) at two register budgets, and 10 waves
+  if (nt == 13 && g_attn_variant == 5) return launch_tr<PREC, 13, 13, 7>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 6) return launch_tr<PREC, 13, 13, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 7) return launch_tr<PREC, 13, 10, 5>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
 #endif
 #define MCM_TR(N, W, O) \
   if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
