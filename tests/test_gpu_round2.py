@@ -249,3 +249,34 @@ def test_image_folder_loader_equals_pillow_transform(tmp_path):
         assert s.shape == (4,) and np.array_equal(s, direct)
     finally:
         net.close()
+
+
+def test_hot_loop_call_is_hip_graph_capturable():
+    """include/mcm.h: "no device allocation happens after mcm_create … so calls are hipGraph-capturable".  One
+    iteration of the loop body (mcm_score: vision tower + scoring tail, ~110 kernel launches on the caller's stream) is
+    captured into a graph, replayed on new pixels, and gives the bits of the eager call."""
+    net = _net("B16-2L", "fp16", max_batch=16, max_prompt_tokens=1024)
+    try:
+        ids, _ = make_token_ids(11, seed=4)
+        txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+        g_ = torch.Generator(device="cuda").manual_seed(8)
+        px = torch.randn((16, 3, 224, 224), generator=g_, device="cuda")
+        out = torch.empty(16, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):       # warm-up on the capture stream (first launches set kernel attributes)
+            net.score_images(px, txt, 1.0, "MCM", out=out)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            net.score_images(px, txt, 1.0, "MCM", out=out)
+        want = net.score_images(px, txt, 1.0, "MCM").clone()
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        px.copy_(torch.randn((16, 3, 224, 224), generator=g_, device="cuda"))   # same buffers, new pixels
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, net.score_images(px, txt, 1.0, "MCM"))
+    finally:
+        net.close()
