@@ -1,7 +1,12 @@
 #!/bin/bash
-# scratch driver (round 3, call 18): the whole GPU suite on the final tree (timing) + smoke
-mkdir -p gpurun_out/r3c18
-O=$PWD/gpurun_out/r3c18
-( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=12 ) > $O/pytest.txt 2>&1
-grep -E "passed|failed|^E |^real" $O/pytest.txt | head; grep -A13 "slowest" $O/pytest.txt | cut -c1-150
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+# scratch driver (round 3, call 19): the default bench line of the final tree + a 60-second soak
+mkdir -p gpurun_out/r3c19
+O=$PWD/gpurun_out/r3c19
+( time timeout 1500 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+( time timeout 600 python bench.py --steps 300 --warmup 5 --sustain-seconds 60 --no-drift --cpu-seconds 0 ) > $O/soak.json 2> $O/soak.err; tail -3 $O/soak.err
+python - <<PY
+import json
+for f in ("bench","soak"):
+    d=json.load(open("$O/%s.json"%f))
+    print(f, round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["sustained"], d["roofline"]["frac"], d["kernel_ms_per_step"])
+PY
