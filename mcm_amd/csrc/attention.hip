@@ -331,6 +331,74 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
     const uint4 q0 = qf[i][0], q1 = qf[i][1];
+    const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t lacc = zero;
+    f32x4_t o[4] = {zero, zero, zero, zero};
+    constexpr int NS = (NT + 1) / 2;
+    // mask of key tile t for this lane's query (only tiles that can hold an invalid key are touched)
+    auto mask_tile = [&](f32x4_t& st, int t) {
+      const bool full = (t * 16 + 15 < L) && (!CAUSAL || t * 16 + 15 <= qb * 16);
+      if (!full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 16 + g * 4 + r;
+          const bool ok = key < L && (!CAUSAL || key <= q);
+          st[r] = ok ? st[r] : -INFINITY;
+        }
+      }
+    };
+    if constexpr (PRIO == 4) {
+      // TWO-PASS form (harness A/B): pass 1 computes S = K Q^T only for the row max and throws it away; pass 2
+      // recomputes it key step by key step, exponentiates and feeds P straight into the row-sum and P V MFMAs.  The
+      // 13-tile score array (52 registers) never exists, so the kernel fits 80 registers and three 8-wave workgroups
+      // share a CU (one of them always loading); the exponentials of step u+1 overlap the MFMAs of step u.  Same
+      // arithmetic in the same order as the one-pass form: bit-identical results; 26 more MFMAs and K-fragment reads
+      // per q-block on pipes that are 24 % busy.
+      float m = -INFINITY;
+      {
+        uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const uint4 k0 = kn0, k1 = kn1;
+          if (t + 1 < NT) {
+            kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
+            kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
+          }
+          f32x4_t st = mfma_keep<PREC>(k0, q0, zero);
+          st = mfma_keep<PREC>(k1, q1, st);
+          mask_tile(st, t);
+          m = fmaxf(fmaxf(fmaxf(fmaxf(m, st[0]), st[1]), st[2]), st[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float msc = m * SC;
+      auto ptile = [&](int t) {  // P of key tile t in MFMA operand order
+        f32x4_t st = mfma_keep<PREC>(*(const uint4*)(Ks + t * 2048 + koff[0]), q0, zero);
+        st = mfma_keep<PREC>(*(const uint4*)(Ks + t * 2048 + koff[1]), q1, st);
+        mask_tile(st, t);
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(st[r], SC, -msc));
+        return make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
+      };
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const uint2 p0 = ptile(2 * u);
+        const uint2 p1 = (2 * u + 1 < NT) ? ptile((2 * u + 1 < NT) ? 2 * u + 1 : 0) : make_uint2(0u, 0u);
+        const uint4 pu = make_uint4(p0.x, p0.y, p1.x, p1.y);
+        lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), pu, lacc);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const char* vp = vlane[dt];
+          const uint2 lo = tr_read16(vp + (2 * u) * 2048);
+          const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
+          o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pu, o[dt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     f32x4_t s[NT];
     uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
@@ -350,15 +418,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const bool full = (t * 16 + 15 < L) && (!CAUSAL || t * 16 + 15 <= qb * 16);
-      if (!full) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t * 16 + g * 4 + r;
-          const bool ok = key < L && (!CAUSAL || key <= q);
-          s[t][r] = ok ? s[t][r] : -INFINITY;
-        }
-      }
+      mask_tile(s[t], t);
       m = fmaxf(fmaxf(fmaxf(fmaxf(m, s[t][0]), s[t][1]), s[t][2]), s[t][3]);
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -379,15 +439,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   ((2 * (u) + 1 < NT) ? make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
                                    pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
                       : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
-    constexpr int NS = (NT + 1) / 2;
     if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // O^T = V^T · P^T for the four 16-dim blocks and the row sum (all-ones A operand), key step by key step: five
     // independent accumulator chains in flight, so no MFMA waits for the one just issued (dim-block-outer order
     // made each of the 7 steps of a chain wait out the previous step's latency)
-    f32x4_t lacc = zero;
-    f32x4_t o[4] = {zero, zero, zero, zero};
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const uint4 pu = MCM_PSTEP(u);
@@ -402,6 +458,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     }
 #undef MCM_PSTEP
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    }
     const float rl = 1.0f / lacc[0];
     // A lane holds 4 dims (8 B) of each of the four 16-dim blocks.  Lanes g and g^1 (16 lanes apart) trade one
     // block of each pair by v_permlane16_swap, after which a lane owns 8 consecutive dims (16 B) of ONE block:
@@ -554,6 +611,9 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   if (nt == 13 && g_attn_variant == 5) return launch_tr<PREC, 13, 13, 7>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
   if (nt == 13 && g_attn_variant == 6) return launch_tr<PREC, 13, 13, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
   if (nt == 13 && g_attn_variant == 7) return launch_tr<PREC, 13, 10, 5>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  // two-pass form at 80 registers (three workgroups per CU) and at the default budget
+  if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
 #endif
 #define MCM_TR(N, W, O) \
   if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
