@@ -31,4 +31,6 @@ esac
 [ -n "$sq" ] && python tools/pmc_summary.py $sq > profiles/${tag}_pmc_sq.txt
 [ -n "$fe" ] && [ -n "$wr" ] && python tools/pmc_summary.py $fe $wr > profiles/${tag}_pmc_traffic.txt
 [ -n "$fe" ] && [ -n "$wr" ] && python tools/traffic_json.py $fe $wr profiles/${tag}_traffic.json > /dev/null
+# profiles/ on the GPU box does not travel back (only gpurun_out/ is merged): keep a copy of the summaries next to the raw data
+mkdir -p $out/summaries && cp profiles/${tag}_* $out/summaries/ 2>/dev/null
 ls -la profiles/${tag}_* ; tail -3 $out/trace.log
