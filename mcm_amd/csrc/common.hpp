@@ -174,6 +174,11 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
                             size_t x_stride = 0, size_t y_stride = 0, bool reverse = false,
                             unsigned int* sat = nullptr);
 
+// pre_layrnorm (in place, fp32) + layer 0's layer_norm1 (operand dtype of `prec`, to y) in one pass
+hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
+                                const float* b1, void* y, int M, int D, float eps, hipStream_t s,
+                                bool reverse = false, unsigned int* sat = nullptr);
+
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
                             bool causal, int qrows, hipStream_t s, bool reverse = false);

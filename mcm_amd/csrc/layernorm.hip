@@ -78,7 +78,94 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
   sat_report<OUT>(amax, sat);
 }
 
+// pre_layrnorm followed by layer 0's layer_norm1 in one pass (HF modeling_clip.py:642 then :370): the fp32 result of
+// the first LayerNorm is written back in place (it is the residual stream) AND, still in registers, normalised again
+// into the first QKV GEMM's operand.  Same arithmetic as the two launches (the second LayerNorm sees exactly the fp32
+// values the first one stores), one 310-MB read of x less.
+template <int OUT>
+__global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const float* __restrict__ g0,
+                                                            const float* __restrict__ b0,
+                                                            const float* __restrict__ g1,
+                                                            const float* __restrict__ b1, void* y, int M, int D,
+                                                            float eps, int rev, unsigned int* sat) {
+  enter_precision_mode<OUT>();
+  const int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  if (rev) row = M - 1 - row;
+  float* xr = x + (size_t)row * D;
+  float4 v[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* g = pass ? g1 : g0;
+    const float* b = pass ? b1 : b0;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int d = (i * 64 + lane) * 4;
+      if (d < D) {
+        if (pass == 0) v[i] = *(const float4*)(xr + d);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int d = (i * 64 + lane) * 4;
+      if (d < D) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int d = (i * 64 + lane) * 4;
+      if (d < D) {
+        const float4 gv = *(const float4*)(g + d);
+        const float4 bv = *(const float4*)(b + d);
+        float4 o;
+        o.x = v[i].x * rstd * gv.x + bv.x;
+        o.y = v[i].y * rstd * gv.y + bv.y;
+        o.z = v[i].z * rstd * gv.z + bv.z;
+        o.w = v[i].w * rstd * gv.w + bv.w;
+        if (pass == 0) {
+          *(float4*)(xr + d) = o;
+          v[i] = o;
+        } else if constexpr (OUT != MCM_PREC_F32) {
+          uint2 pk;
+          pk.x = pack2<OUT>(o.x, o.y);
+          pk.y = pack2<OUT>(o.z, o.w);
+          sat_track<OUT>(amax, o.x, o.y);
+          sat_track<OUT>(amax, o.z, o.w);
+          *(uint2*)((uint16_t*)y + (size_t)row * D + d) = pk;
+        } else {
+          *(float4*)((float*)y + (size_t)row * D + d) = o;
+        }
+      }
+    }
+  }
+  sat_report<OUT>(amax, sat);
+}
+
 }  // namespace
+
+hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
+                                const float* b1, void* y, int M, int D, float eps, hipStream_t s,
+                                bool reverse, unsigned int* sat) {
+  if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int rev = reverse ? 1 : 0;
+  if (prec == MCM_PREC_BF16)
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+  else if (prec == MCM_PREC_F16)
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+  else
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+  return hipGetLastError();
+}
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,

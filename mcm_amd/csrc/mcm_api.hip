@@ -200,14 +200,16 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
 // modeling_clip.py:649-651).  The last layer then computes K/V for all tokens but Q, the
 // attention output, out_proj, LN2 and the MLP for row 0 only — identical results for the
 // consumed rows (every op after attention is row-wise), 1/12 less work for a 12-layer tower.
+// ln1_of_layer0_done: the caller has already produced layer 0's layer_norm1 output in h->ln (the vision tower fuses it
+// with pre_layrnorm, launch_layernorm_pre)
 int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal,
-               bool pooled_row0) {
+               bool pooled_row0, bool ln1_of_layer0_done = false) {
   const int M = nseq * L, D = t.D, P = t.prec;
   const int es = prec_esize(P);
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
-    HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    if (!(l == 0 && ln1_of_layer0_done)) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
     if (!cls) {
       const int nch = (g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
       for (int c = 0; c < nch; ++c) {
@@ -483,9 +485,15 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
     HIP_TRY(h, launch_cls_rows(h->x, W(h, "vision_model.embeddings.class_embedding"), a.pos, B,
                                h->ntok, D, s));
   }
-  HIP_TRY(h, lnorm(h, s, c.precision, h->x, W(h, "vision_model.pre_layrnorm.weight"),
-                   W(h, "vision_model.pre_layrnorm.bias"), h->x, B * h->ntok, D, true));
-  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true))) return rc;
+  {  // pre_layrnorm (fp32, in place) and layer 0's layer_norm1 in one pass over x; a 1-layer tower whose only
+     // layer is the CLS-only one still works: its layer_norm1 is over all rows either way
+    Scope sc(h, s, MCM_KC_LAYERNORM, 16.0 * B * h->ntok * D);
+    HIP_TRY(h, launch_layernorm_pre(c.precision, h->x, W(h, "vision_model.pre_layrnorm.weight"),
+                                    W(h, "vision_model.pre_layrnorm.bias"), h->vis.L[0].ln1w, h->vis.L[0].ln1b,
+                                    h->ln, B * h->ntok, D, c.ln_eps, s, next_dir(h),
+                                    h->sat_on ? h->sat_dev : nullptr));
+  }
+  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true))) return rc;
   {
     Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * B * D * c.proj_dim);
     HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,

@@ -1,14 +1,14 @@
 #!/bin/bash
-# scratch driver (round 3, call 21): HF-on-device parity for the other two checkpoints / regimes
-mkdir -p gpurun_out/r3c21
-O=$PWD/gpurun_out/r3c21
-for cfg in "ViT-B/32 50000 10000 512 fp16-exact B32_fp16exact" "ViT-B/32 50000 10000 512 fp32 B32_fp32w" "ViT-L/14 50000 10000 256 fp32 L14_fp32w"; do set -- $cfg
-  timeout 1500 python tests/probes/hf_gpu_probe.py $1 $2 $3 $4 $5 fp16,bf16 > $O/$6.json 2> $O/$6.err
+# scratch driver (round 3, call 22): pre_layrnorm + layer_norm1 fused — model tests, smoke, bench A/B vs previous numbers
+mkdir -p gpurun_out/r3c22
+O=$PWD/gpurun_out/r3c22
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
+timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_round2.py "tests/test_gpu_configs.py::test_config1_imagenet10_vs_imagenet20_b16_batch64" -m gpu -x -q 2>&1 | tail -3
+for i in 1 2 3; do
+  timeout 300 python bench.py --no-drift --cpu-seconds 0 --sustain-seconds 3 > $O/b.$i.json 2> $O/b.err
   python - <<PY
 import json
-d=json.load(open("$O/$6.json"))
-f=lambda x:{k:float("%.3g"%v) for k,v in x.items()}
-print("$6", round(d["seconds"]), "s | fp32 arm vs hf", f(d["reference"]["vs_external"]["hf"]))
-for a in d["arms"]: print("    ", a, "vs hf", f(d["arms"][a]["vs_external"]["hf"]))
+d=json.load(open("$O/b.$i.json"))
+print(round(d["value"]), "img/s", round(d["sustained_images_per_sec"]), "sustained", d["kernel_ms_per_step"])
 PY
-done 2>&1 | tee $O/summary.txt
+done 2>&1 | tee $O/bench.txt
