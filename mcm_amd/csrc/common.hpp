@@ -174,10 +174,12 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
                             size_t x_stride = 0, size_t y_stride = 0, bool reverse = false,
                             unsigned int* sat = nullptr);
 
-// pre_layrnorm (in place, fp32) + layer 0's layer_norm1 (operand dtype of `prec`, to y) in one pass
+// pre_layrnorm (in place, fp32) + layer 0's layer_norm1 (operand dtype of `prec`, to y) in one pass; with cls != null
+// row 0 of every ntok-row image is taken as cls + pos0 (class_embedding + position_embedding[0]) instead of read
 hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
                                 const float* b1, void* y, int M, int D, float eps, hipStream_t s,
-                                bool reverse = false, unsigned int* sat = nullptr);
+                                bool reverse = false, unsigned int* sat = nullptr, const float* cls = nullptr,
+                                const float* pos0 = nullptr, int ntok = 0);
 
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
@@ -189,8 +191,6 @@ hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, in
                               int patch, int kpad, const float* mean, const float* stdv,
                               hipStream_t s);
 hipError_t launch_bank_reduce(const float* feats, int K, int T, int P, float* bank, hipStream_t s);
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D,
-                           hipStream_t s);
 hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* pos, float* x,
                              int K, int S, int D, hipStream_t s);
 hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, int cols,

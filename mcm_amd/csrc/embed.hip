@@ -4,7 +4,8 @@
 //                 (HF modeling_clip.py:148-154,209-210): NCHW fp32 pixels → patch matrix
 //                 [B*np, Kpad], k = (c,py,px) = the [D,3,P,P] weight flattening, in the GEMM
 //                 operand dtype, zero-padded to Kpad (L/14: 588 → 640).
-//   cls_rows      row 0 of every image: class_embedding + position_embedding[0] (:212-217)
+//   (row 0 of every image — class_embedding + position_embedding[0], :212-217 — is produced by
+//   layernorm.hip's layernorm_pre_kernel, inside the pre_layrnorm pass)
 //   text_embed    token_embedding[id] + position_embedding[s]                  (:251-254)
 //   cvt_weight    fp32 [rows, cols] → operand dtype [rows, cols_pad], zero padded
 //   pool_project  pooled row → LayerNorm → projection (no bias) → L2 normalise, all fp32:
@@ -110,15 +111,6 @@ __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* __restric
   }
   const float rn = 1.0f / sqrtf(wave_sum(sq));
   for (int d = lane; d < P; d += 64) bank[(size_t)k * P + d] *= rn;
-}
-
-__global__ __launch_bounds__(256) void cls_rows_kernel(float* x, const float* __restrict__ cls,
-                                                       const float* __restrict__ pos, int B,
-                                                       int ntok, int D) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * D) return;
-  const int b = i / D, d = i - b * D;
-  x[(size_t)b * ntok * D + d] = cls[d] + pos[d];
 }
 
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids,
@@ -253,13 +245,6 @@ hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, in
 hipError_t launch_bank_reduce(const float* feats, int K, int T, int P, float* bank, hipStream_t s) {
   if (K <= 0 || T <= 0 || P <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bank_reduce_kernel, dim3((K + 3) / 4), dim3(256), 0, s, feats, K, T, P, bank);
-  return hipGetLastError();
-}
-
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D,
-                           hipStream_t s) {
-  hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, cls, pos, B,
-                     ntok, D);
   return hipGetLastError();
 }
 

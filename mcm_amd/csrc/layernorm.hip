@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
   sat_report<OUT>(amax, sat);
 }
 
-// pre_layrnorm followed by layer 0's layer_norm1 in one pass (HF modeling_clip.py:642 then :370): the fp32 result of
+// (optionally the CLS row of every image =) pre_layrnorm followed by layer 0's layer_norm1 in one pass (HF modeling_clip.py:642 then :370): the fp32 result of
 // the first LayerNorm is written back in place (it is the residual stream) AND, still in registers, normalised again
 // into the first QKV GEMM's operand.  Same arithmetic as the two launches (the second LayerNorm sees exactly the fp32
 // values the first one stores), one 310-MB read of x less.
@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
                                                             const float* __restrict__ b0,
                                                             const float* __restrict__ g1,
                                                             const float* __restrict__ b1, void* y, int M, int D,
-                                                            float eps, int rev, unsigned int* sat) {
+                                                            float eps, int rev, unsigned int* sat,
+                                                            const float* __restrict__ cls,
+                                                            const float* __restrict__ pos0, int ntok) {
   enter_precision_mode<OUT>();
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -105,7 +107,14 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
     for (int i = 0; i < MAXV; ++i) {
       const int d = (i * 64 + lane) * 4;
       if (d < D) {
-        if (pass == 0) v[i] = *(const float4*)(xr + d);
+        if (pass == 0) {
+          if (cls != nullptr && row % ntok == 0) {  // CLS row: class_embedding + position_embedding[0] (HF :212-217)
+            const float4 c = *(const float4*)(cls + d), p = *(const float4*)(pos0 + d);
+            v[i] = make_float4(c.x + p.x, c.y + p.y, c.z + p.z, c.w + p.w);
+          } else {
+            v[i] = *(const float4*)(xr + d);
+          }
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       }
     }
@@ -154,16 +163,16 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
 
 hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
                                 const float* b1, void* y, int M, int D, float eps, hipStream_t s,
-                                bool reverse, unsigned int* sat) {
+                                bool reverse, unsigned int* sat, const float* cls, const float* pos0, int ntok) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
   const int rev = reverse ? 1 : 0;
   if (prec == MCM_PREC_BF16)
-    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat, cls, pos0, ntok > 0 ? ntok : 1);
   else if (prec == MCM_PREC_F16)
-    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat, cls, pos0, ntok > 0 ? ntok : 1);
   else
-    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat);
+    hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat, cls, pos0, ntok > 0 ? ntok : 1);
   return hipGetLastError();
 }
 

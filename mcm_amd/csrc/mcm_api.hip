@@ -480,18 +480,16 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
   a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
   a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np;
   HIP_TRY(h, gemm(h, s, c.precision, EPI_PATCH, a));
-  {
-    Scope sc(h, s, MCM_KC_EMBED, 0.0);
-    HIP_TRY(h, launch_cls_rows(h->x, W(h, "vision_model.embeddings.class_embedding"), a.pos, B,
-                               h->ntok, D, s));
-  }
+  // the CLS row of every image (class_embedding + position_embedding[0], HF :212-217) is produced inside the
+  // LayerNorm pass below instead of by a launch of its own
   {  // pre_layrnorm (fp32, in place) and layer 0's layer_norm1 in one pass over x; a 1-layer tower whose only
      // layer is the CLS-only one still works: its layer_norm1 is over all rows either way
     Scope sc(h, s, MCM_KC_LAYERNORM, 16.0 * B * h->ntok * D);
     HIP_TRY(h, launch_layernorm_pre(c.precision, h->x, W(h, "vision_model.pre_layrnorm.weight"),
                                     W(h, "vision_model.pre_layrnorm.bias"), h->vis.L[0].ln1w, h->vis.L[0].ln1b,
                                     h->ln, B * h->ntok, D, c.ln_eps, s, next_dir(h),
-                                    h->sat_on ? h->sat_dev : nullptr));
+                                    h->sat_on ? h->sat_dev : nullptr,
+                                    W(h, "vision_model.embeddings.class_embedding"), a.pos, h->ntok));
   }
   if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true))) return rc;
   {
