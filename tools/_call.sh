@@ -1,14 +1,13 @@
 #!/bin/bash
-# scratch driver (round 3, call 22): pre_layrnorm + layer_norm1 fused — model tests, smoke, bench A/B vs previous numbers
-mkdir -p gpurun_out/r3c22
-O=$PWD/gpurun_out/r3c22
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
-timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_round2.py "tests/test_gpu_configs.py::test_config1_imagenet10_vs_imagenet20_b16_batch64" -m gpu -x -q 2>&1 | tail -3
-for i in 1 2 3; do
-  timeout 300 python bench.py --no-drift --cpu-seconds 0 --sustain-seconds 3 > $O/b.$i.json 2> $O/b.err
-  python - <<PY
+# scratch driver (round 3, call 24): final tree — whole GPU suite, default bench, rocprofv3 passes
+mkdir -p gpurun_out/r3c24
+O=$PWD/gpurun_out/r3c24
+( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=6 ) > $O/pytest.txt 2>&1
+grep -E "passed|failed|^E |^real" $O/pytest.txt | head -5
+( time timeout 1500 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<PY
 import json
-d=json.load(open("$O/b.$i.json"))
-print(round(d["value"]), "img/s", round(d["sustained_images_per_sec"]), "sustained", d["kernel_ms_per_step"])
+d=json.load(open("$O/bench.json"))
+print(round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["sustained"], d["roofline"]["frac"], d["kernel_ms_per_step"], d["cpu_baseline"]["value"], d["cpu_baseline"]["value_hoisted"], d["parity"]["meets_1e-4"])
 PY
-done 2>&1 | tee $O/bench.txt
+bash tools/profile.sh r03_i > $O/profile.log 2>&1; tail -3 $O/profile.log
