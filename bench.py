@@ -423,6 +423,22 @@ def main():
                 line["roofline"]["sustained_power_w"] = sustained["power_w_mean"]
                 line["roofline"]["frac_of_peak_at_sustained_clock"] = \
                     (ach / (peak * sustained["sclk_mhz_mean"] / 2400.0)) if ach else None
+            # the two HBM-bound kernel families of the step against the HBM roof (north_star: "rocprof HBM GB/s ...
+            # against peak"): ALGORITHMIC bytes of one step / HIP-event time of that family in one step
+            M, D, L, es = B * geo.v_tokens, geo.v_width, geo.v_layers, 2 if args.precision != "fp32" else 4
+            ln_bytes = ((2 * (L - 1) + 1) * M * D * (4 + es)      # layer_norm1/2 of the full layers + the last layer_norm1
+                        + B * D * (4 + es)                          # the last layer's layer_norm2: CLS rows only
+                        + M * D * 4)                                # the fused pre_layrnorm pass also rewrites x in fp32
+            at_bytes = (L - 1) * M * 4 * D * es + (M * 2 * D * es + 2 * B * D * es)   # qkv in + out; last layer: K, V + CLS
+            hbm = {}
+            for name, nbytes in (("layernorm", ln_bytes), ("attention", at_bytes)):
+                ms = prof[name]["ms"] / n_prof
+                if ms > 0:
+                    gbs = nbytes / (ms * 1e-3) / 1e9
+                    hbm[name] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                 "frac_of_measured_copy_rate": gbs / 6290.0, "algorithmic_bytes_per_step": nbytes,
+                                 "ms_per_step": ms}
+            line["roofline_hbm_kernels"] = hbm
             tot = sum(v["ms"] for v in prof.values())
             executed = sum(v["flops"] for v in prof.values()) / n_prof / B / 1e9
             line["kernel_ms_per_step"] = {k: round(v["ms"] / n_prof, 4) for k, v in prof.items()}
