@@ -166,6 +166,16 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
   a.rev = next_dir(h) ? 1 : 0;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
   Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);
+  // Row padding into the workspace: the ping-pong kernel takes problems made of whole 256-row tiles only, so a
+  // dense activation GEMM whose M is not a multiple of 256 is run on M rounded up.  The extra rows exist (every
+  // activation buffer is allocated in whole 256-row tiles and zeroed once), every output row depends on its own
+  // input row only, and the pad rows' results are never read: same bits for the real rows, and batches that are not
+  // multiples of 256 images (any batch at ViT-L/14's 257 tokens but 256 k; ragged last batches) get the fast kernel.
+  const bool from_row0 = a.x == h->ln || a.x == h->att || a.x == h->hbuf;  // not a chunk that starts mid-buffer
+  if (epi != EPI_PATCH && from_row0 && a.M % 256 != 0 && a.N % 256 == 0 && a.ldx == a.K && a.ldo == a.N) {
+    const int64_t mp = ((int64_t)a.M + 255) / 256 * 256;
+    if (mp <= h->max_rows) a.M = (int)mp;
+  }
   return launch_gemm(prec, epi, a, s);
 }
 hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b,
@@ -363,7 +373,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
     if ((rc = dev_alloc(h, (void**)&kv.second.dev, (size_t)kv.second.numel * sizeof(float)))) break;
   }
   // activation workspace
-  const int64_t mv = (int64_t)c.max_batch * h->ntok, mt = c.max_prompt_tokens;
+  // activation rows: whole 256-row GEMM tiles (see gemm(): problems are padded up into these rows)
+  const int64_t mv = ((int64_t)c.max_batch * h->ntok + 255) / 256 * 256, mt = ((int64_t)c.max_prompt_tokens + 255) / 256 * 256;
   h->max_rows = mv > mt ? mv : mt;
   // shared by both towers: vision rows in the operand dtype of cfg.precision, text rows in fp32
   auto both = [&](int64_t vcols, int64_t tcols) {
@@ -371,12 +382,19 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
     return a > b ? a : b;
   };
   const int64_t dmax = c.v_width > c.t_width ? c.v_width : c.t_width;
-  if (!rc) rc = dev_alloc(h, (void**)&h->x, (size_t)h->max_rows * dmax * sizeof(float));
-  if (!rc) rc = dev_alloc(h, &h->ln, both(c.v_width, c.t_width));
-  if (!rc) rc = dev_alloc(h, &h->qkv, both(3 * (int64_t)c.v_width, 3 * (int64_t)c.t_width));
-  if (!rc) rc = dev_alloc(h, &h->att, both(c.v_width, c.t_width));
+  const size_t xb = (size_t)h->max_rows * dmax * sizeof(float), lnb = both(c.v_width, c.t_width),
+               qkvb = both(3 * (int64_t)c.v_width, 3 * (int64_t)c.t_width), attb = both(c.v_width, c.t_width);
+  if (!rc) rc = dev_alloc(h, (void**)&h->x, xb);
+  if (!rc) rc = dev_alloc(h, &h->ln, lnb);
+  if (!rc) rc = dev_alloc(h, &h->qkv, qkvb);
+  if (!rc) rc = dev_alloc(h, &h->att, attb);
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
+  // zeroed once: pad rows (gemm()) then only ever hold zeros, bias-only results or a previous batch's valid rows
+  if (!rc && (hipMemset(h->x, 0, xb) != hipSuccess || hipMemset(h->ln, 0, lnb) != hipSuccess ||
+              hipMemset(h->qkv, 0, qkvb) != hipSuccess || hipMemset(h->att, 0, attb) != hipSuccess ||
+              hipMemset(h->hbuf, 0, h->hbuf_bytes) != hipSuccess))
+    rc = fail(h, MCM_EHIP, "hipMemset of the activation workspace");
   if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
