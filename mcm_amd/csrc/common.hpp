@@ -164,7 +164,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip and libmcm_hip_harness.so only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
-void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 6: see gemm.hip
+void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 8: see gemm.hip
 void attention_set_variant(int v);  // 1 = transpose-read kernel (the shipped one), 0 = round-1 kernel
 #endif
 

@@ -931,7 +931,10 @@ __device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uin
 // 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
 // waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
 // was last read (W fragments, by these very waves) a whole step earlier, so no ring of three is needed.
-template <int PREC, int EPI, bool BAL = false>
+// STAG (staggered epilogues): waves 0-3 run the epilogue of a finished tile BEFORE the barrier that ends the phase
+// in which waves 4-7 still compute that tile's last K-step, waves 4-7 theirs one phase later, under the first compute
+// phase of waves 0-3 on the next tile: each group's stores and conversions run beside the other group's MFMAs.
+template <int PREC, int EPI, bool BAL = false, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   using namespace p256;
   enter_precision_mode<PREC>();
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NP0; ++i) piece(lk, si, i);
         issue_done();
-        phase_barrier();
+        if constexpr (!STAG) phase_barrier();
       }
       epilogue();
       if (!grp) {
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       if (grp) wait_vmcnt<4>();  // everything older than this phase's 4 X pieces: the W pieces waves 0-3 read next
     }
     PPT(0);
-    if (!split) phase_barrier();
+    if (!split || STAG) phase_barrier();
     PPT(1);
     // ---- compute phase of step s
     if (ktc == nk - 1 && a.bias) {
@@ -1644,7 +1647,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
 
 #ifdef MCM_HARNESS
 int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores),
-                     // 5 ping-pong 256x256 (interior tiles only, else 3), 6 ping-pong on 32x32x16 MFMAs (else 5)
+                     // 5 ping-pong 256x256 (interior tiles only, else 3), 6 ping-pong on 32x32x16 MFMAs (else 5),
+                     // 7 ping-pong with balanced DMA, 8 ping-pong with staggered epilogues (else 5)
 int variant() { return g_variant; }
 #else
 constexpr int variant() { return -1; }  // the shipped library has the size policy of launch_one only
@@ -1707,16 +1711,16 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool BAL = false>
+template <int PREC, int EPI, bool BAL = false, bool STAG = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1755,6 +1759,12 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   if (v == 7) {  // ping-pong with balanced DMA (8 + 8 pieces); else as 5
     if constexpr (EPI != EPI_PATCH) {
       if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI, true>(a, s);
+    }
+    v = 5;
+  }
+  if (v == 8) {  // ping-pong with staggered epilogues; else as 5
+    if constexpr (EPI != EPI_PATCH) {
+      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI, false, true>(a, s);
     }
     v = 5;
   }

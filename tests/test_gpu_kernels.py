@@ -108,8 +108,9 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[-1, 0, 2, 4, 5, 6, 7], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
-                                                "pingpong256x256", "pingpong256x256-mfma32", "pingpong256x256-balanced"])
+@pytest.fixture(params=[-1, 0, 2, 4, 5, 6, 7, 8], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
+                                                   "pingpong256x256", "pingpong256x256-mfma32", "pingpong256x256-balanced",
+                                                   "pingpong256x256-staggered"])
 def gemm_net(request, tiny_net, harness_net):
     """Every GEMM kernel variant must pass the same parity cases (the shipped policy picks by problem size, so
     small test shapes would otherwise only exercise the tile kernel).  -1 = the shipped library as is; the
@@ -162,7 +163,7 @@ def test_linear(gemm_net, M, N, K, prec, epi):
                                    (300, 256, 128), (1, 512, 256), (700, 768, 768), (129, 256, 3072)])
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("pp_variant", [5, 6, 7], ids=["mfma16", "mfma32", "balanced-dma"])
+@pytest.mark.parametrize("pp_variant", [5, 6, 7, 8], ids=["mfma16", "mfma32", "balanced-dma", "staggered-epilogues"])
 def test_linear_pingpong_interior_shapes_vs_oracle(harness_net, M, N, K, prec, epi, pp_variant):
     tiny_net = harness_net
     """The ping-pong 256x256 kernel only takes problems made of whole tiles, so it gets its own oracle cases:
@@ -237,7 +238,7 @@ def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, pre
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (-1, 3, 4, 5, 6, 7):
+        for variant in (-1, 3, 4, 5, 6, 7, 8):
             for _ in range(3):
                 got = run(variant)
                 assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
@@ -274,7 +275,7 @@ def test_linear_l14_shapes_pingpong_bitwise(tiny_net, harness_net, N, K, epi):
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (-1, 5, 6, 7):
+        for variant in (-1, 5, 6, 7, 8):
             for _ in range(2):  # mcm_op_linear alternates the walk direction per launch: both get exercised
                 got = run(variant)
                 view = torch.int32 if epi == 2 else torch.int16
@@ -474,7 +475,7 @@ def test_fp16_saturation_counter_in_the_persistent_gemm_kernels(tiny_net, harnes
     ws = w.clone()
     ws[300, :] = 250.0     # 250 * 250 * 128 = 8e6
     try:
-        for variant in (-1, 0, 3, 5, 6, 7):
+        for variant in (-1, 0, 3, 5, 6, 7, 8):
             net = tiny_net if variant < 0 else harness_net
             if variant >= 0:
                 assert net._lib.mcm_debug_gemm_variant(variant) == 0

@@ -31,7 +31,7 @@ def gemm_isa(tmp_path_factory):
 
 
 def _kernel(isa, prec, epi):
-    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi), isa, re.S | re.M)
+    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dELb0ELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi), isa, re.S | re.M)
     assert m, "gemm_pp_kernel<%d,%d> not found" % (prec, epi)
     return m.group(0)
 

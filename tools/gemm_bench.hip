@@ -71,8 +71,8 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int nvar = 8;
-  const unsigned vmask = argc > 9 ? (unsigned)strtoul(argv[9], 0, 0) : 0xffu;  // variants to time
+  const int nvar = 9;
+  const unsigned vmask = argc > 9 ? (unsigned)strtoul(argv[9], 0, 0) : 0x1ffu;  // variants to time
   double best[nvar] = {0};
   for (int round = 0; round < 3; ++round)
     for (int v = 0; v < nvar; ++v) {
