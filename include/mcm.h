@@ -296,7 +296,8 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
  *     others run as 5).
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
-/* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel. */
+/* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel, 2 ... 9 = priority / wave-count /
+ * two-pass arms of the shipped kernel at the B/16 shape, 10 = XCD-aware deal of the (sequence, head) workgroups. */
 int mcm_debug_attention_variant(int32_t variant);
 /* A/B and ablation bits of the GEMM kernels (gemm.hip, GemmArgs::dbg; 0 = shipped behaviour). */
 int mcm_debug_gemm_dbg(int32_t bits);

@@ -272,8 +272,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-  const int seq = bid / heads, h = bid - seq * heads;
+  const int bid = (rev & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  int seq = bid / heads, h = bid - seq * heads;
+  if (rev & 2) {  // XCD-aware deal (sequences a multiple of 8): workgroup b runs on XCD b % 8, and the `heads`
+                  // workgroups of a sequence are consecutive on ONE XCD — the 128-B q / k / v segments of a qkv row
+                  // are neighbours in memory, so a row is fetched by one L2, at about the same time
+    const int j = bid >> 3, sj = j / heads;
+    seq = sj * 8 + (bid & 7);
+    h = j - sj * heads;
+  }
   const int D = heads * 64;
   const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
   const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
@@ -603,6 +610,9 @@ template <int PREC>
 hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                               hipStream_t s, int rev) {
   const int nt = (L + 15) / 16;
+#ifdef MCM_HARNESS
+  if (g_attn_variant == 10 && nseq % 8 == 0) rev |= 2;  // XCD-aware deal of the (sequence, head) workgroups
+#endif
 #ifdef MCM_HARNESS  // priority A/B arms, B/16 shape only (13 key tiles)
   if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
   if (nt == 13 && g_attn_variant == 3) return launch_tr<PREC, 13, 8, 3, 2>(qkv, out, nseq, L, heads, causal, qrows, s, rev);

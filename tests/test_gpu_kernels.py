@@ -358,7 +358,7 @@ def test_score_kinds(tiny_net, K, T):
 
 
 ATTN_MORE = [(2, 65, 2, False), (2, 80, 2, False), (2, 96, 2, False), (2, 112, 2, False), (3, 40, 2, True),
-             (2, 128, 2, True), (1, 288, 1, False), (2, 1, 2, False)]
+             (2, 128, 2, True), (1, 288, 1, False), (2, 1, 2, False), (8, 65, 2, False), (16, 40, 3, True)]
 
 
 @pytest.mark.parametrize("nseq,L,heads,causal", ATTN_MORE)
@@ -378,8 +378,11 @@ def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causa
     dt = DTYPE[prec]
     qd = _dev(qkv, dt)
     tol = 2e-2 if prec == "bf16" else 3e-3
+    outs = {}
     try:
-        for variant in (-1, 1, 0):  # -1: the shipped library; 1 / 0: both kernels forced in the harness library
+        # -1: the shipped library; 1 / 0: both kernels forced in the harness library; 10: the XCD-aware deal of the
+        # workgroups (sequence counts that are multiples of 8; the plain deal otherwise)
+        for variant in (-1, 1, 0, 10):
             net = tiny_net if variant < 0 else harness_net
             if variant >= 0:
                 assert net._lib.mcm_debug_attention_variant(variant) == 0
@@ -389,6 +392,8 @@ def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causa
             torch.cuda.synchronize()
             np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=tol, atol=tol,
                                        err_msg=f"variant {variant}")
+            outs[variant] = out
+        assert torch.equal(outs[1], outs[10]) and torch.equal(outs[1], outs[-1])
     finally:
         harness_net._lib.mcm_debug_attention_variant(1)
 

@@ -36,7 +36,7 @@ for prec, dt in ((0, torch.bfloat16), (2, torch.float16)):
         qkv[:, :2 * D] *= 1.5
         qkv = qkv.to(dt)
         outs = []
-        for variant in ((0, 1, 3, 8, 9) if L == 197 else (0, 1)):
+        for variant in ((0, 1, 10, 1, 10) if L in (197, 257) else (0, 1, 10)):
             assert lib.mcm_debug_attention_variant(variant) == 0
             out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
 
