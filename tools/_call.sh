@@ -1,15 +1,13 @@
 #!/bin/bash
-# scratch driver (round 3, call 30): XCD-aware deal of the attention workgroups (harness arm 10) vs shipped (1)
-mkdir -p gpurun_out/r3c30
-O=$PWD/gpurun_out/r3c30
-timeout 600 python tools/attn_probe.py 50 > $O/probe.txt 2>&1; grep -E "L=197|L=257|L=50|bit-equal" $O/probe.txt | cut -c1-200
-B="timeout 600 python bench.py --no-drift --cpu-seconds 0 --steps 40"
-one() {
-  $B --attn-variant $2 > $O/b_$1.json 2> $O/b_$1.err || tail -3 $O/b_$1.err
-  python - <<PY
+# scratch driver (round 3, call 31): final tree — whole GPU suite, smoke, default bench
+mkdir -p gpurun_out/r3c31
+O=$PWD/gpurun_out/r3c31
+( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=6 ) > $O/pytest.txt 2>&1
+grep -E "passed|failed|^E |^real" $O/pytest.txt | head -5
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+( time timeout 1500 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<PY
 import json
-d=json.load(open("$O/b_$1.json"))
-print("$1", round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["kernel_ms_per_step"])
+d=json.load(open("$O/bench.json"))
+print(round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["sustained"], d["roofline"]["frac"], d["kernel_ms_per_step"], d["cpu_baseline"]["value"], d["cpu_baseline"]["value_hoisted"], d["parity"]["meets_1e-4"], d["parity"]["d_auroc"], d["parity"]["d_fpr95"])
 PY
-}
-for rep in 1 2; do one a1_$rep 1; one a10_$rep 10; done 2>&1 | tee $O/bench.txt
