@@ -303,6 +303,10 @@ int mcm_debug_attention_variant(int32_t variant);
 int mcm_debug_gemm_dbg(int32_t bits);
 /* A/B: run the QKV projection + attention of every layer per chunk of the batch (n chunks; 1 = shipped). */
 int mcm_debug_qkv_chunks(int32_t n);
+/* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
+ * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
+ * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */
+int mcm_debug_ln_fold(int32_t on);
 #endif
 
 #ifdef __cplusplus

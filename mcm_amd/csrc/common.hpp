@@ -132,6 +132,40 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- LayerNorm fold: moments of a 64-column segment held by the 16 lanes of a DPP row (4 columns per lane) ----------
+// Used by the residual epilogue of the ping-pong GEMM and by fold_rows_kernel (layernorm.hip), which must produce the
+// SAME bits for the same row (a score must not depend on which kernel the batch size selected): every operation is an
+// explicitly rounded one, in a fixed order, so contraction cannot differ between the two call sites.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {  // x of the lane the DPP control selects (within a row of 16)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane
+#pragma clang fp contract(off)
+  v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = v + dpp_move<0x141>(v);  // row_half_mirror
+  v = v + dpp_move<0x140>(v);  // row_mirror
+  return v;
+}
+// sum of the segment and its sum of squares about the segment's own mean (every lane of the row gets both)
+__device__ __forceinline__ void slot_moments(const f32x4_t& v, float& sum, float& m2) {
+#pragma clang fp contract(off)  // (hipcc's default would fuse differently at different call sites)
+  sum = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+  const float mean = sum * (1.0f / 64.0f);
+  const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+  m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+}
+// z = gamma o x, the fold's A operand, before it is packed to the operand dtype
+__device__ __forceinline__ f32x4_t fold_scale(const f32x4_t& v, const f32x4_t& gamma) {
+#pragma clang fp contract(off)
+  return v * gamma;
+}
+// consumer side of the fold: (acc - mean c) rstd + b' as two fused multiply-adds, the same in every GEMM kernel
+__device__ __forceinline__ float fold_apply(float acc, float rstd, float mrstd, float c, float b) {
+  return __builtin_fmaf(acc, rstd, __builtin_fmaf(-mrstd, c, b));
+}
+
 // element size in bytes of the MFMA operand dtype of a precision mode
 __host__ __device__ constexpr int prec_esize(int prec) { return prec == MCM_PREC_F32 ? 4 : 2; }
 
@@ -159,8 +193,27 @@ struct GemmArgs {
   int rev;            // persistent kernel: walk the M tiles from the last to the first
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
   unsigned int* sat;  // fp16 saturation counter of the handle (nullptr: not reported), see sat_report
+  // LayerNorm fold (16-bit modes, ping-pong kernel, gemm.hip "LayerNorm fold"): the LayerNorm between a residual GEMM
+  // and the GEMM that consumes its output is not launched; both sides are set or null together per GEMM.
+  void* fold_z;           // EPI_RESID (producer): [M, N] operand dtype, z = gamma o (new residual row)
+  const float* fold_g;    //   gamma [N] of the LayerNorm that follows
+  float2* fold_part;      //   per-row partial moments [N / 64][M]: (sum, sum of squares about the 64-column mean)
+  const float2* fold_rs;  // EPI_STORE / EPI_GELU (consumer): per-row (rstd, mean * rstd) [M]
+  const float* fold_c;    //   c [N] = W gamma; `bias` then holds b + W beta
 };
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
+// which LayerNorm-fold form launch_gemm has for this problem: 1 = ping-pong kernel (producer and consumer epilogues),
+// 2 = tile kernel (consumer epilogue only; its producer is launch_fold_rows after the plain residual GEMM), 0 = none
+int gemm_fold_kind(int epi, int M, int N);
+// LayerNorm fold, weight side: c[n] = sum_k gamma[k] W[n,k], bfold[n] = bias[n] + sum_k beta[k] W[n,k]  (W: operand dtype)
+hipError_t launch_fold_prep(int prec, const void* w, const float* gamma, const float* beta, const float* bias,
+                            float* c, float* bfold, int N, int K, hipStream_t s);
+// LayerNorm fold, producer side without a fused epilogue (problems the tile kernel takes): z = gamma o x in the operand
+// dtype and the row moments, bit-identical to what the ping-pong kernel's residual epilogue writes
+hipError_t launch_fold_rows(int prec, const float* x, const float* gamma, void* z, float2* part, int M, int D,
+                            hipStream_t s, unsigned int* sat = nullptr);
+// LayerNorm fold, row side: partial moments [slots][M] -> (rstd, mean * rstd) [M]
+hipError_t launch_fold_stats(const float2* part, int slots, int M, int D, float eps, float2* rs, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip and libmcm_hip_harness.so only
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);

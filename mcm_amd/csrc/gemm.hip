@@ -114,19 +114,33 @@ __device__ __forceinline__ int perm_n(int lr) {
 }
 
 // epilogue of a (MF*16)x64 wave tile at (mw, nw)
-template <int PREC, int EPI, int MF>
+// FOLD: consumer side of the LayerNorm fold (see wave_epilogue_lds); bv then holds b', c and the row statistics are
+// read here.  Same arithmetic (fold_apply) as the ping-pong kernel's form: a score does not depend on the kernel.
+template <int PREC, int EPI, int MF, bool FOLD = false>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                               const f32x4_t (&bv)[4], int mw, int nw, int fr, int g, float& amax) {
   const int n = nw + g * 16;
   if (n >= a.N) return;
+  f32x4_t cv[4];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) cv[fj] = *(const f32x4_t*)(a.fold_c + min(n, a.N - 16) + fj * 4);
+  }
 #pragma unroll
   for (int fi = 0; fi < MF; ++fi) {
     const int m = mw + fi * 16 + fr;
     if (m >= a.M) continue;
     f32x4_t v[4];
+    float2 rs = make_float2(1.f, 0.f);
+    if constexpr (FOLD) rs = a.fold_rs[m];
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
-      v[fj] = acc[fj][fi] + bv[fj];
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[fj][t] = fold_apply(acc[fj][fi][t], rs.x, rs.y, cv[fj][t], bv[fj][t]);
+      } else {
+        v[fj] = acc[fj][fi] + bv[fj];
+      }
       if constexpr (EPI == EPI_GELU) {  // same form in every kernel variant: results must not
 #pragma unroll                          // depend on which variant the size heuristic picks
         for (int t = 0; t < 4; ++t)
@@ -187,10 +201,19 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
 
 // INTERIOR (16-bit outputs only; the ping-pong kernel): the caller guarantees a full tile and uniform mw / nw;
 // rows are then addressed as a uniform base plus one 32-bit lane offset, without bounds checks.
-template <int PREC, int EPI, int MF, bool INTERIOR = false>
+// LayerNorm fold, consumer side (FOLD; ping-pong kernel, 16-bit outputs): the A operand was z = gamma o x instead of
+// LayerNorm(x), so the row's normalisation is applied here: out = (acc - mean c_n) rstd + b'_n with c = W gamma and
+// b' = b + W beta (both prepared once per weight, launch_fold_prep) and (rstd, mean rstd) per row from the producer's
+// moments (launch_fold_stats).  `bv` holds b' and fo.cv holds c for the lane's 16 columns; a lane of the wave keeps
+// (rstd, mean rstd) of rows lane and 64 + lane of the wave's 128 and the unit's row is fetched by ds_bpermute.
+struct FoldRegs {
+  f32x4_t cv[4];
+  float rstd[2], mrstd[2];
+};
+template <int PREC, int EPI, int MF, bool INTERIOR = false, bool FOLD = false>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
-                                                  char* scratch, float& amax) {
+                                                  char* scratch, float& amax, const FoldRegs* fo = nullptr) {
   const int fr = lane & 15, g = lane >> 4;
   if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
@@ -200,9 +223,20 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
     const int n = nw + c8 * 8;
     auto write_unit = [&](int u) {
       f32x4_t v[4];
+      float rstd = 1.f, mr = 0.f;
+      if constexpr (FOLD) {  // row u*16 + fr of the wave's 128: held by lane (u & 3) * 16 + fr, slot u >> 2
+        const int src = (((u & 3) << 4) | fr) << 2;
+        rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fo->rstd[u >> 2])));
+        mr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fo->mrstd[u >> 2])));
+      }
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) {
-        v[fj] = acc[fj][u] + bv[fj];
+        if constexpr (FOLD) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[fj][t] = fold_apply(acc[fj][u][t], rstd, mr, fo->cv[fj][t], bv[fj][t]);
+        } else {
+          v[fj] = acc[fj][u] + bv[fj];
+        }
         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
@@ -359,7 +393,7 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 }  // namespace tile
 
-template <int PREC, int EPI>
+template <int PREC, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   using namespace tile;
   enter_precision_mode<PREC>();
@@ -427,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   f32x4_t bv[4];
   load_bias(a, n0 + wc * 64 + g * 16, bv);
   float amax = 0.f;
-  wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
+  wave_epilogue<PREC, EPI, 4, FOLD>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
   sat_report<PREC>(amax, a.sat);
 }
 
@@ -810,6 +844,14 @@ __device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_
 __device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+#ifdef MCM_HARNESS  // streamed forms (A/B bit 64: the fold producer's residual rows bypass the caches)
+__device__ __forceinline__ void gload16_nt(f32x4_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gstore16_nt(const void* sbase, uint32_t voff, const f32x4_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_pin(f32x4_t (&b)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
@@ -825,7 +867,11 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
   const char* base = (const char*)(EPI == EPI_RESID ? a.resid : (float*)a.out) + ((size_t)mw * a.ldo + nw) * 4;
   auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
   f32x4_t buf[2][4];
+  // EPI_RESID: the bias of the lane's 4 columns AFTER the bounce, loaded here (4 registers, and nothing of this epilogue
+  // is live across the K loop; `bv` is not used) - the same (acc + b) + resid as every other form
+  f32x4_t bia = {0.f, 0.f, 0.f, 0.f};
   if constexpr (EPI == EPI_RESID) {
+    if (a.bias) gload16(bia, a.bias + nw, (uint32_t)c16 * 16u);
 #pragma unroll
     for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
   }
@@ -839,7 +885,8 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
     }
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
-      f32x4_t v = acc[fj][c] + bv[fj];
+      f32x4_t v = acc[fj][c];
+      if constexpr (EPI != EPI_RESID) v += bv[fj];
       if constexpr (EPI == EPI_GELU) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
@@ -855,11 +902,107 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
     if constexpr (EPI == EPI_RESID) {
       if (c == 0 || c + 1 == MF) wait_vmcnt_pin<4>(buf[c & 1]);
       else wait_vmcnt_pin<8>(buf[c & 1]);
+      if (c == 0) asm volatile("" : "+v"(bia));  // older than the loads the wait above covers
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v[t] += buf[c & 1][t];
+      for (int t = 0; t < 4; ++t) v[t] = (v[t] + bia) + buf[c & 1][t];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) gstore16(rowbase(c, t), voff, v[t]);
+  }
+}
+
+// LayerNorm fold, producer side (EPI_RESID in the ping-pong kernel): wave_epilogue_f32_interior<EPI_RESID> plus, for
+// every new residual row segment, (1) z = gamma o x in the operand dtype to fold_z (what the next GEMM multiplies) and
+// (2) the segment's moments — its sum and its sum of squares about its own mean, 64 columns per wave — to
+// fold_part[column / 64][row].  After the LDS bounce the 16 lanes of a DPP row hold the 64 columns of one row, so a
+// moment is 4 DPP adds; the 16 (chunk, row-group) results of 64 rows are parked in the lane whose index equals their
+// number and leave as ONE 512-byte store.  All global accesses from asm, counted like the plain form: at the wait of
+// chunk c the queue holds [loads c] [stores c-1: 4 x + 4 z (+ 1 moments)] [loads c+1].
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gstore8(const void* sbase, uint32_t voff, const u32x2_t& v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int PREC, int MF>
+__device__ __forceinline__ void wave_epilogue_resid_fold(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
+                                                         int mw, int nw, int lane, char* scratch, float& amax) {
+  static_assert(MF == 8, "the wait counts below are written out for 8 chunks");
+  const int fr = lane & 15, g = lane >> 4;
+  const int rrow = lane >> 4, c16 = lane & 15;
+  const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes, fp32 rows
+  const uint32_t zoff = voff >> 1;                                 // bytes, 16-bit rows of the same stride
+  const char* base = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
+  const char* zbase = (const char*)a.fold_z + ((size_t)mw * a.ldo + nw) * 2;
+  auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
+  auto zrowbase = [&](int c, int t) { return zbase + (size_t)(c * 16 + t * 4) * a.ldo * 2; };
+  const char* pbase = (const char*)(a.fold_part + (size_t)(nw >> 6) * a.M + mw);
+  const uint32_t poff = (uint32_t)(((c16 >> 2) * 16 + (c16 & 3) * 4 + rrow) * 8);
+  // gamma and the bias of the lane's 4 columns AFTER the bounce (4 + 4 registers, loaded here: nothing of this
+  // epilogue is live across the K loop); (acc + b) + resid as in every other form
+  auto xload = [&](f32x4_t& dst, const char* rb) {
+#ifdef MCM_HARNESS
+    if (DBG(64)) return gload16_nt(dst, rb, voff);
+#endif
+    gload16(dst, rb, voff);
+  };
+  auto xstore = [&](const char* rb, const f32x4_t& val) {
+#ifdef MCM_HARNESS
+    if (DBG(64)) return gstore16_nt(rb, voff, val);
+#endif
+    gstore16(rb, voff, val);
+  };
+  f32x4_t gam, bia;
+  gload16(gam, a.fold_g + nw, (uint32_t)c16 * 16u);
+  gload16(bia, a.bias + nw, (uint32_t)c16 * 16u);
+  f32x4_t buf[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xload(buf[0][t], rowbase(0, t));
+  float ms = 0.f, mq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MF; ++c) {
+    if (c + 1 < MF) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xload(buf[(c + 1) & 1][t], rowbase(c + 1, t));
+    }
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ fr) << 4)) = acc[fj][c];
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 4 + rrow;
+      v[t] = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
+    }
+    if (c == 0) {
+      wait_vmcnt_pin<4>(buf[0]);
+      asm volatile("" : "+v"(gam), "+v"(bia));
+    } else if (c + 1 == MF) {
+      wait_vmcnt_pin<8>(buf[c & 1]);
+    } else if (c == 4) {
+      wait_vmcnt_pin<13>(buf[c & 1]);  // stores of chunk 3 include the first moments store
+    } else {
+      wait_vmcnt_pin<12>(buf[c & 1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = (v[t] + bia) + buf[c & 1][t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xstore(rowbase(c, t), v[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4_t z = fold_scale(v[t], gam);
+      sat_track<PREC>(amax, z[0], z[1]);
+      sat_track<PREC>(amax, z[2], z[3]);
+      if constexpr (PREC == MCM_PREC_F16) asm volatile("" : "+v"(amax));  // here, not 128 live values later
+      const u32x2_t zz = {pack2<PREC>(z[0], z[1]), pack2<PREC>(z[2], z[3])};
+      gstore8(zrowbase(c, t), zoff, zz);
+      float sm, sq;
+      slot_moments(v[t], sm, sq);
+      const bool mine = c16 == (c & 3) * 4 + t;
+      ms = mine ? sm : ms;
+      mq = mine ? sq : mq;
+    }
+    if ((c & 3) == 3) {
+      const u32x2_t pm = {__builtin_bit_cast(uint32_t, ms), __builtin_bit_cast(uint32_t, mq)};
+      gstore8(pbase + (size_t)(c >> 2) * 64 * 8, poff, pm);
+    }
   }
 }
 
@@ -934,7 +1077,10 @@ __device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uin
 // STAG (staggered epilogues): waves 0-3 run the epilogue of a finished tile BEFORE the barrier that ends the phase
 // in which waves 4-7 still compute that tile's last K-step, waves 4-7 theirs one phase later, under the first compute
 // phase of waves 0-3 on the next tile: each group's stores and conversions run beside the other group's MFMAs.
-template <int PREC, int EPI, bool BAL = false, bool STAG = false>
+// FOLD (LayerNorm fold, 16-bit modes): EPI_RESID runs the producer epilogue (wave_epilogue_resid_fold), EPI_STORE /
+// EPI_GELU the consumer form of wave_epilogue_lds; a wave then carries 6 registers of row / column data across its last
+// compute phase instead of 16 bias registers.
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   using namespace p256;
   enter_precision_mode<PREC>();
@@ -1075,22 +1221,54 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 
   Cursor cc{jx / nbn, jx % nbn};
   int em0 = 0, en0 = 0;  // tile whose epilogue is pending
+  constexpr bool FOLD_OUT = FOLD && EPI <= EPI_GELU;  // consumer side of the LayerNorm fold
+  static_assert(!FOLD || (PREC != MCM_PREC_F32 && EPI != EPI_PATCH), "LayerNorm fold: 16-bit operand modes");
   f32x4_t bv[4];  // bias of the pending tile: asm loads issued at the top of its last compute phase
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // consumer fold: b'[n] and c[n] of column n0 + wc*64 + lane, (rstd, mean rstd) of rows m0 + wr*128 + lane and + 64
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  float fold_b = 0.f, fold_c = 0.f;
+  f32x2_t fold_r0 = {0.f, 0.f}, fold_r1 = {0.f, 0.f};
   auto epilogue = [&]() {
     // every lane-derived address of the epilogue is recomputed from an opaque copy of the lane id: hoisted out
     // of the K loop they would occupy ~20 registers that the loop (128 accumulators + 64 fragments) does not have
     int le = lane;
     asm volatile("" : "+v"(le));
+    if constexpr (FOLD_OUT) {
+      asm volatile("" : "+v"(fold_b), "+v"(fold_c), "+v"(fold_r0), "+v"(fold_r1));
+      if (!DBG(4)) {
+        char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+        FoldRegs fo;
+        f32x4_t bx[4];
+        const int gl = le >> 4;
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-    if (!DBG(4)) {
-      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-      if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
-        wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
-      else
-        wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {  // the lane's 16 columns: gl*16 + fj*4 + t of the wave's 64
+            const int src = (gl * 16 + fj * 4 + t) << 2;
+            bx[fj][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fold_b)));
+            fo.cv[fj][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fold_c)));
+          }
+        fo.rstd[0] = fold_r0[0]; fo.mrstd[0] = fold_r0[1];
+        fo.rstd[1] = fold_r1[0]; fo.mrstd[1] = fold_r1[1];
+        wave_epilogue_lds<PREC, EPI, 8, true, true>(a, acc, bx, em0 + wr * 128, en0 + wc * 64, le, win, amax, &fo);
+      }
+    } else {
+      if constexpr (!FOLD && EPI != EPI_RESID) {  // (the residual forms load their bias inside the epilogue: a pin
+                                                   // would keep 16 zeros live across the K loop)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+      }
+      if (!DBG(4)) {
+        char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+        if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
+          wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
+        else if constexpr (FOLD)
+          wave_epilogue_resid_fold<PREC, 8>(a, acc, em0 + wr * 128, en0 + wc * 64, le, win, amax);
+        else
+          wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
+      }
     }
     zero_acc<8>(acc);
   };
@@ -1197,7 +1375,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     if (!split || STAG) phase_barrier();
     PPT(1);
     // ---- compute phase of step s
-    if (ktc == nk - 1 && a.bias) {
+    if constexpr (FOLD_OUT) {
+      if (ktc == nk - 1) {  // 4 asm loads, covered by the wait that ends this phase
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int pn = cc.nt * BN + wc * 64, pm = (mt_of(cc.mtl) * 8 + xcd) * BM + wr * 128;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(fold_b) : "v"(le * 4), "s"(a.bias + pn) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(fold_c) : "v"(le * 4), "s"(a.fold_c + pn) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fold_r0) : "v"(le * 8), "s"(a.fold_rs + pm) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fold_r1) : "v"(le * 8), "s"(a.fold_rs + pm + 64) : "memory");
+      }
+    } else if (FOLD || EPI == EPI_RESID) {  // residual forms: the bias (and gamma) are loaded inside the epilogue
+    } else if (ktc == nk - 1 && a.bias) {
       int le = lane;
       asm volatile("" : "+v"(le));
       load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
@@ -1223,7 +1412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
-  if constexpr (EPI <= EPI_GELU) sat_report<PREC>(amax, a.sat);
+  if constexpr (EPI <= EPI_GELU || FOLD) sat_report<PREC>(amax, a.sat);
   PPT_DUMP();
 }
 
@@ -1668,17 +1857,17 @@ int persistent_grid() {
   return n;
 }
 
-template <int PREC, int EPI>
+template <int PREC, int EPI, bool FOLD = false>
 hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI, FOLD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, tile::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int nbn = (a.N + tile::BN - 1) / tile::BN, nbm = (a.M + tile::BM - 1) / tile::BM;
-  hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI, FOLD>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1711,16 +1900,16 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool BAL = false, bool STAG = false>
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1740,17 +1929,38 @@ hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
 
 #endif
 
-template <int PREC, int EPI>
-hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+// the kernel family launch_one picks for a problem: 0 tile kernel, 5 ping-pong (whole tiles) or plain persistent
+int size_policy(int M, int N) {
   int v = variant();
   if (v < 0) {  // auto: the persistent 256x256 kernel once its tiles cover most of the CUs, else the
                 // one-workgroup-per-tile kernel (text tower, CLS-only last layer).  Measured with
                 // bench.py --batch 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 %
                 // end to end against the old >= 1024 rule).
-    const long tiles = (long)((a.M + p256::BM - 1) / p256::BM) * ((a.N + p256::BN - 1) / p256::BN);
+    const long tiles = (long)((M + p256::BM - 1) / p256::BM) * ((N + p256::BN - 1) / p256::BN);
     v = tiles >= 192 ? 5 : 0;  // 5 falls back to 3 when the problem has edge tiles
   }
   if (v != 0 && persistent_grid() < 8) v = 0;
+  return v;
+}
+
+template <int PREC, int EPI>
+hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
+  int v = size_policy(a.M, a.N);
+  const bool fold = a.fold_z != nullptr || a.fold_rs != nullptr;
+  if (fold) {  // LayerNorm fold (harness / -DMCM_LN_FOLD builds only: measured slower than the LayerNorm launches)
+#if defined(MCM_HARNESS) || defined(MCM_LN_FOLD)
+    if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
+      const bool sides = EPI == EPI_RESID ? (a.fold_z && a.fold_g && a.fold_part && a.bias && !a.fold_rs)
+                                          : (a.fold_rs && a.fold_c && a.bias && !a.fold_z);
+      if (v == 5 && sides && a.M % p256::BM == 0 && a.N % p256::BN == 0 && a.ldo == a.N)
+        return launch_pp<PREC, EPI, false, false, true>(a, s);
+      if constexpr (EPI <= EPI_GELU) {
+        if (v == 0 && sides) return launch_tile<PREC, EPI, true>(a, s);
+      }
+    }
+#endif
+    return hipErrorInvalidValue;
+  }
   if (v == 0) return launch_tile<PREC, EPI>(a, s);
 #ifdef MCM_HARNESS
   if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
@@ -1805,6 +2015,14 @@ void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
 #else
 constexpr int g_group_n = 0, g_dbg = 0;
 #endif
+
+int gemm_fold_kind(int epi, int M, int N) {
+  if (epi == EPI_PATCH || M <= 0 || N <= 0) return 0;
+  const int v = size_policy(M, N);
+  if (v == 5 && M % p256::BM == 0 && N % p256::BN == 0) return 1;
+  if (v == 0) return 2;
+  return 0;
+}
 
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;

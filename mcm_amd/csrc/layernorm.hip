@@ -159,6 +159,82 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
   sat_report<OUT>(amax, sat);
 }
 
+// ---- LayerNorm fold (gemm.hip): the LayerNorm between a residual GEMM and its consumer, without its own pass -------
+// Weight side, once per weight: with z = gamma o x the consumer computes sum_k z_k W[n,k]; LayerNorm(x) W^T + b =
+// ((z W^T)[n] - mean c[n]) rstd + b'[n] with c[n] = sum_k gamma_k W[n,k], b'[n] = b[n] + sum_k beta_k W[n,k].
+// W is the OPERAND copy (the values the MFMAs multiply), so the mean term cancels exactly what the GEMM summed.
+// One wave per output column n; fp32 sums of K <= 4096 products.
+template <int PREC>
+__global__ __launch_bounds__(256) void fold_prep_kernel(const uint16_t* __restrict__ w, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ bias,
+                                                        float* __restrict__ c, float* __restrict__ bfold, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const uint16_t* wr = w + (size_t)n * K;
+  float sc = 0.f, sb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float wv;
+    if constexpr (PREC == MCM_PREC_F16) wv = (float)__builtin_bit_cast(_Float16, wr[k]);
+    else wv = bf2f(wr[k]);
+    sc = fmaf(gamma[k], wv, sc);
+    sb = fmaf(beta[k], wv, sb);
+  }
+  sc = wave_sum(sc);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    c[n] = sc;
+    bfold[n] = (bias ? bias[n] : 0.f) + sb;
+  }
+}
+
+// Producer side for problems whose residual GEMM has no fused fold epilogue (the tile kernel: small batches): one wave
+// per row, 256 columns per pass — the 16 lanes of a DPP row hold one 64-column slot, 4 columns per lane, exactly the
+// arrangement of the ping-pong epilogue after its LDS bounce, and the same slot_moments / multiply / pack: same bits.
+template <int PREC>
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        uint16_t* __restrict__ z, float2* __restrict__ part, int M,
+                                                        int D, unsigned int* sat) {
+  enter_precision_mode<PREC>();
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float amax = 0.f;
+  for (int c0 = 0; c0 < D; c0 += 256) {  // D is a multiple of 256 (launch_fold_rows)
+    const int col = c0 + lane * 4;
+    const f32x4_t v = *(const f32x4_t*)(x + (size_t)row * D + col);
+    const f32x4_t gm = *(const f32x4_t*)(gamma + col);
+    const f32x4_t zz = fold_scale(v, gm);
+    sat_track<PREC>(amax, zz[0], zz[1]);
+    sat_track<PREC>(amax, zz[2], zz[3]);
+    *(uint2*)(z + (size_t)row * D + col) = make_uint2(pack2<PREC>(zz[0], zz[1]), pack2<PREC>(zz[2], zz[3]));
+    float sm, sq;
+    slot_moments(v, sm, sq);
+    if ((lane & 15) == 0) part[(size_t)(col >> 6) * M + row] = make_float2(sm, sq);
+  }
+  sat_report<PREC>(amax, sat);
+}
+
+// Row side, once per folded LayerNorm: the producer left, per row and 64-column slot, the slot's sum and its sum of
+// squares about the slot's own mean; combined here (Chan et al.) into the row's mean and centred variance - the same
+// two quantities the LayerNorm kernel computes, without E[x^2] - mean^2 cancellation.  part: [slots][M], rs: [M].
+__global__ __launch_bounds__(256) void fold_stats_kernel(const float2* __restrict__ part, int slots, int M, int D,
+                                                         float eps, float2* __restrict__ rs) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  float sum = 0.f;
+  for (int j = 0; j < slots; ++j) sum += part[(size_t)j * M + row].x;
+  const float mean = sum / (float)D;
+  float m2 = 0.f;
+  for (int j = 0; j < slots; ++j) {
+    const float2 p = part[(size_t)j * M + row];
+    const float dm = p.x * (1.0f / 64.0f) - mean;
+    m2 += p.y + 64.0f * dm * dm;
+  }
+  const float rstd = 1.0f / sqrtf(m2 / (float)D + eps);
+  rs[row] = make_float2(rstd, mean * rstd);
+}
+
 }  // namespace
 
 hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
@@ -194,5 +270,33 @@ hipError_t launch_layernorm(int prec, const float* x, const float* g, const floa
     hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F16>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt, sat);
   else
     hipLaunchKernelGGL(layernorm_kernel<MCM_PREC_F32>, grid, block, 0, s, x, g, b, y, M, D, eps, xs, ys, rev, nt, sat);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_prep(int prec, const void* w, const float* gamma, const float* beta, const float* bias,
+                            float* c, float* bfold, int N, int K, hipStream_t s) {
+  if (prec == MCM_PREC_F32 || N <= 0 || K <= 0) return hipErrorInvalidValue;
+  const dim3 grid((N + 3) / 4), block(256);
+  if (prec == MCM_PREC_F16)
+    hipLaunchKernelGGL(fold_prep_kernel<MCM_PREC_F16>, grid, block, 0, s, (const uint16_t*)w, gamma, beta, bias, c, bfold, N, K);
+  else
+    hipLaunchKernelGGL(fold_prep_kernel<MCM_PREC_BF16>, grid, block, 0, s, (const uint16_t*)w, gamma, beta, bias, c, bfold, N, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_stats(const float2* part, int slots, int M, int D, float eps, float2* rs, hipStream_t s) {
+  if (slots <= 0 || M <= 0 || D != slots * 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fold_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, slots, M, D, eps, rs);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_rows(int prec, const float* x, const float* gamma, void* z, float2* part, int M, int D,
+                            hipStream_t s, unsigned int* sat) {
+  if (prec == MCM_PREC_F32 || M <= 0 || D <= 0 || D % 256) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  if (prec == MCM_PREC_F16)
+    hipLaunchKernelGGL(fold_rows_kernel<MCM_PREC_F16>, grid, block, 0, s, x, gamma, (uint16_t*)z, part, M, D, sat);
+  else
+    hipLaunchKernelGGL(fold_rows_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, gamma, (uint16_t*)z, part, M, D, sat);
   return hipGetLastError();
 }

@@ -34,6 +34,8 @@ struct LayerW {
   void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // operand dtype
   float *bqkv = nullptr;                                               // [3D] packed
   const float *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;               // fp32 masters
+  // LayerNorm fold (vision tower, 16-bit modes): c = W gamma and b' = b + W beta of the two GEMMs that follow a LayerNorm
+  float *cqkv = nullptr, *bqkvf = nullptr, *c1 = nullptr, *b1f = nullptr;
 };
 
 struct Tower {
@@ -76,6 +78,7 @@ struct mcm_handle {
   bool flip = false;  // walk direction of the next kernel (next_dir)
   unsigned int* sat_dev = nullptr;  // sticky fp16 saturation counter (common.hpp sat_report)
   bool sat_on = true;
+  float2 *fold_part = nullptr, *fold_rs = nullptr;  // LayerNorm fold: row moments [v_width / 64][rows], (rstd, mean rstd) [rows]
   std::string err;
 };
 
@@ -206,9 +209,24 @@ hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int hea
 }
 #ifdef MCM_HARNESS
 int g_qkv_chunks = 1;  // A/B: QKV projection + attention per chunk of the batch (qkv of a chunk stays in the Infinity Cache)
+int g_ln_fold = 0;     // A/B: 1 = LayerNorm fold (mcm_debug_ln_fold); 0 = every LayerNorm as its own launch (shipped)
 #else
 constexpr int g_qkv_chunks = 1;
+#ifdef MCM_LN_FOLD  // A/B build of the shipped library with the fold on (tools/_call.sh: libmcm_hip_fold.so)
+constexpr int g_ln_fold = 1;
+#else
+constexpr int g_ln_fold = 0;
 #endif
+#endif
+// rows of a dense activation GEMM as gemm() runs it (whole 256-row tiles when the workspace has them)
+int64_t padded_rows(const mcm_handle* h, int M) {
+  const int64_t mp = ((int64_t)M + 255) / 256 * 256;
+  return mp <= h->max_rows ? mp : M;
+}
+hipError_t fold_stats(mcm_handle* h, hipStream_t s, int Mp, int D) {
+  Scope sc(h, s, MCM_KC_LAYERNORM, 4.0 * Mp * (D / 64));
+  return launch_fold_stats(h->fold_part, D / 64, Mp, D, h->cfg.ln_eps, h->fold_rs, s);
+}
 hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g,
                          const float* b, void* y, int M, int D, size_t xs, size_t ys) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
@@ -223,14 +241,38 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
 // consumed rows (every op after attention is row-wise), 1/12 less work for a 12-layer tower.
 // ln1_of_layer0_done: the caller has already produced layer 0's layer_norm1 output in h->ln (the vision tower fuses it
 // with pre_layrnorm, launch_layernorm_pre)
+// fold_ok (vision tower) and the harness switch mcm_debug_ln_fold(1): LayerNorm fold, an A/B arm (measured 1 % slower
+// end to end than the LayerNorm launches; the shipped library never takes it).  The LayerNorm between a
+// residual GEMM and the GEMM behind it is not launched: the residual epilogue also writes z = gamma o x (into h->ln,
+// where the LayerNorm output would have gone) and the row moments, fold_stats turns those into (rstd, mean rstd) per
+// row, and the consumer's epilogue normalises (gemm.hip, "LayerNorm fold").  Not for the layer the caller pools row 0 of
+// (its LayerNorms see other rows / strides) and not for layer 0's layer_norm1 (fused with pre_layrnorm by the caller).
 int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal,
-               bool pooled_row0, bool ln1_of_layer0_done = false) {
+               bool pooled_row0, bool ln1_of_layer0_done = false, bool fold_ok = false) {
   const int M = nseq * L, D = t.D, P = t.prec;
   const int es = prec_esize(P);
+  const int Mp = (int)padded_rows(h, M);
+  // producer form: 1 = fused into the residual GEMM's epilogue (ping-pong kernel), 2 = plain residual GEMM + fold_rows
+  // (tile kernel: small batches) - bit-identical; the consumers need a fold epilogue in whichever kernel they take
+  const int pkind = gemm_fold_kind(EPI_RESID, Mp, D);
+  const bool can_fold = fold_ok && g_ln_fold && g_qkv_chunks == 1 && h->fold_part && P != MCM_PREC_F32 &&
+                        t.L[0].cqkv != nullptr && pkind != 0 && gemm_fold_kind(EPI_STORE, Mp, 3 * D) != 0 &&
+                        gemm_fold_kind(EPI_GELU, Mp, t.ff) != 0;
+  auto produce = [&](GemmArgs& g, const float* gamma) -> hipError_t {  // residual GEMM + z / moments / statistics
+    if (pkind == 1) { g.fold_z = h->ln; g.fold_g = gamma; g.fold_part = h->fold_part; }
+    hipError_t e = gemm(h, s, P, EPI_RESID, g);
+    if (e == hipSuccess && pkind == 2) {
+      Scope sc(h, s, MCM_KC_LAYERNORM, 6.0 * Mp * D);
+      e = launch_fold_rows(P, h->x, gamma, h->ln, h->fold_part, Mp, D, s, h->sat_on ? h->sat_dev : nullptr);
+    }
+    return e == hipSuccess ? fold_stats(h, s, Mp, D) : e;
+  };
+  bool ln1_folded = false;  // h->ln holds gamma1 o x and h->fold_rs the row statistics of this layer's layer_norm1
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
-    if (!(l == 0 && ln1_of_layer0_done)) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    if (!(l == 0 && ln1_of_layer0_done) && !ln1_folded)
+      HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
     if (!cls) {
       const int nch = (g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
       for (int c = 0; c < nch; ++c) {
@@ -239,6 +281,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
         a.x = (const char*)h->ln + (size_t)r0 * D * es; a.w = w.wqkv; a.bias = w.bqkv;
         a.out = (char*)h->qkv + (size_t)r0 * 3 * D * es;
         a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
+        if (ln1_folded) { a.bias = w.bqkvf; a.fold_rs = h->fold_rs; a.fold_c = w.cqkv; }
         HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
         HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq));
       }
@@ -256,20 +299,29 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     }
     const int Mr = cls ? nseq : M;            // rows that continue
     const int rs = cls ? L * D : D;           // their stride in x / att
+    const bool fold2 = can_fold && !cls;      // layer_norm2 folded into out-proj / fc1
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
     o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
-    HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
-    if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
-    else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
+    if (fold2) {
+      HIP_TRY(h, produce(o, w.ln2w));
+    } else {
+      HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
+      if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
+      else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
+    }
     GemmArgs f1{};
     f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
     f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
+    if (fold2) { f1.bias = w.b1f; f1.fold_rs = h->fold_rs; f1.fold_c = w.c1; }
     HIP_TRY(h, gemm(h, s, P, EPI_GELU, f1));
+    // the next layer's layer_norm1 folded into fc2 / the next QKV projection (not into the row-0-only layer)
+    ln1_folded = fold2 && l + 1 < t.layers && !(pooled_row0 && l + 1 == t.layers - 1 && L > 1);
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
     f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
-    HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
+    if (ln1_folded) HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
+    else HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
   }
   return MCM_OK;
 }
@@ -296,6 +348,16 @@ int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s
     HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".self_attn.out_proj.weight"), w.wo, D, D, D, s));
     HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc1.weight"), w.w1, ff, D, D, s));
     HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc2.weight"), w.w2, D, ff, ff, s));
+    if (&t == &h->vis && h->fold_part) {  // LayerNorm fold: the column vectors of the two LayerNorm consumers
+      if ((rc = dev_alloc(h, (void**)&w.cqkv, (size_t)3 * D * sizeof(float)))) return rc;
+      if ((rc = dev_alloc(h, (void**)&w.bqkvf, (size_t)3 * D * sizeof(float)))) return rc;
+      if ((rc = dev_alloc(h, (void**)&w.c1, (size_t)ff * sizeof(float)))) return rc;
+      if ((rc = dev_alloc(h, (void**)&w.b1f, (size_t)ff * sizeof(float)))) return rc;
+      HIP_TRY(h, launch_fold_prep(prec, w.wqkv, W(h, pre + ".layer_norm1.weight"), W(h, pre + ".layer_norm1.bias"),
+                                  w.bqkv, w.cqkv, w.bqkvf, 3 * D, D, s));
+      HIP_TRY(h, launch_fold_prep(prec, w.w1, W(h, pre + ".layer_norm2.weight"), W(h, pre + ".layer_norm2.bias"),
+                                  W(h, pre + ".mlp.fc1.bias"), w.c1, w.b1f, ff, D, s));
+    }
     w.bo = W(h, pre + ".self_attn.out_proj.bias");
     w.b1 = W(h, pre + ".mlp.fc1.bias");
     w.b2 = W(h, pre + ".mlp.fc2.bias");
@@ -416,6 +478,12 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc rowidx");
   if (!rc) rc = dev_alloc(h, (void**)&h->prep_dev, (size_t)c.max_batch * sizeof(PrepImage));
+#if defined(MCM_HARNESS) || defined(MCM_LN_FOLD)  // LayerNorm fold (A/B arm): row moments and row statistics
+  if (!rc && c.precision != MCM_PREC_F32 && c.v_width % 256 == 0 && c.v_mlp % 256 == 0) {
+    rc = dev_alloc(h, (void**)&h->fold_part, (size_t)(c.v_width / 64) * mv * sizeof(float2));
+    if (!rc) rc = dev_alloc(h, (void**)&h->fold_rs, (size_t)mv * sizeof(float2));
+  }
+#endif
   if (!rc) rc = dev_alloc(h, (void**)&h->sat_dev, 16);
   if (!rc && hipMemset(h->sat_dev, 0, 16) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset saturation counter");
   if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)c.max_batch * sizeof(PrepImage)) != hipSuccess)
@@ -520,7 +588,12 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
                                     h->sat_on ? h->sat_dev : nullptr,
                                     W(h, "vision_model.embeddings.class_embedding"), a.pos, h->ntok));
   }
-  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true))) return rc;
+  if (g_ln_fold) {  // pad rows of the residual stream (gemm() runs whole 256-row tiles): the residual epilogues add to
+                    // them on every call; the fold's fp16 z of a pad row must not saturate, so they start from zero
+    const int64_t M = (int64_t)B * h->ntok, mp = padded_rows(h, (int)M);
+    if (mp > M) HIP_TRY(h, hipMemsetAsync(h->x + M * D, 0, (size_t)(mp - M) * D * sizeof(float), s));
+  }
+  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true, true))) return rc;
   {
     Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * B * D * c.proj_dim);
     HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,
@@ -838,6 +911,11 @@ int mcm_debug_attention_variant(int32_t variant) {
 
 int mcm_debug_gemm_dbg(int32_t bits) {  // ablation / A-B bits of gemm.hip (GemmArgs::dbg)
   gemm_set_dbg(bits);
+  return MCM_OK;
+}
+
+int mcm_debug_ln_fold(int32_t on) {  // 0 (shipped behaviour): every LayerNorm as its own launch; 1: folded where the GEMMs qualify
+  g_ln_fold = on ? 1 : 0;
   return MCM_OK;
 }
 
