@@ -1,17 +1,13 @@
 #!/bin/bash
-# scratch driver (round 3, call 37): residual rows requested two chunks ahead (three buffers; spills 4 again) vs one ahead
-mkdir -p gpurun_out/r3c37
-O=$PWD/gpurun_out/r3c37
-for rep in 1 2; do for b in gemm_bench_old gemm_bench; do for shp in "768 3072 2" "768 768 2"; do
-  echo -n "$b " >> $O/gemm.txt; timeout 300 tools/$b 100864 $shp 1500 0 0 3 0x20 2>&1 | grep -E "BEST" >> $O/gemm.txt
-done; done; done
-cat $O/gemm.txt | cut -c1-120
-one() {
-  timeout 600 python tools/bench_with_lib.py mcm_amd/$2 --no-drift --cpu-seconds 0 --steps 40 > $O/b_$1.json 2> $O/b_$1.err || tail -3 $O/b_$1.err
-  python - <<PY
+# scratch driver (round 3, call 38): final tree — whole GPU suite, smoke, default bench
+mkdir -p gpurun_out/r3c38
+O=$PWD/gpurun_out/r3c38
+( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=6 ) > $O/pytest.txt 2>&1
+grep -E "passed|failed|^E |^real" $O/pytest.txt | head -5
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+( time timeout 1500 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<PY
 import json
-d=json.load(open("$O/b_$1.json"))
-print("$1", round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["kernel_ms_per_step"]["gemm"], d["sustained"].get("sclk_mhz_mean"))
+d=json.load(open("$O/bench.json"))
+print(round(d["value"]), d["ms_per_step"], round(d["sustained_images_per_sec"]), d["sustained"], d["roofline"]["frac"], d["kernel_ms_per_step"], d["cpu_baseline"]["value"], d["cpu_baseline"]["value_hoisted"], d["parity"]["meets_1e-4"], d["parity"]["d_auroc"], d["parity"]["d_fpr95"])
 PY
-}
-for rep in 1 2 3; do one old_$rep libmcm_hip_old.so; one new_$rep libmcm_hip.so; done 2>&1 | tee $O/bench.txt
