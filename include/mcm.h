@@ -307,6 +307,9 @@ int mcm_debug_qkv_chunks(int32_t n);
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */
 int mcm_debug_ln_fold(int32_t on);
+/* A/B: 1 = the 16-bit towers hand q / k / v from the QKV projection to attention head-major ([3 heads][rows][64]: an
+ * attention workgroup's rows are consecutive bytes); 0 (default, shipped) = [rows][3 D].  Bit-identical; no net gain. */
+int mcm_debug_qkv_head_major(int32_t on);
 #endif
 
 #ifdef __cplusplus

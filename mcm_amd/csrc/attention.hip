@@ -261,7 +261,7 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
 template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
                                                                          uint16_t* __restrict__ out, int L,
-                                                                         int heads, int qrows, int rev) {
+                                                                         int heads, int qrows, int rev, int hm) {
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP = NT * 16;           // padded keys
@@ -282,8 +282,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     h = j - sj * heads;
   }
   const int D = heads * 64;
-  const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
-  const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+  // qkv layout.  Row-major (hm = 0): [rows][3 D], a head's q / k / v are 128-B segments of 4.6-KB rows.  Head-major
+  // (hm = rows of the array, what the QKV projection writes in the model): [3 heads][hm][64] — this workgroup's Q, K
+  // and V are three runs of L x 128 consecutive bytes.  rs: row stride, KO / VO: from a q row to the k / v row (elements)
+  const size_t rs = hm ? (size_t)64 : (size_t)3 * D;
+  const size_t KO = hm ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
+  const uint16_t* base = hm ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
 
   // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
@@ -302,13 +306,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
       const int p = blk * 4 + (lane >> 4), s = lane & 15;
       const int row = min(2 * p + (s >> 3), L - 1);
       const int chunk = (s & 7) ^ (p & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + D + chunk * 8),
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + KO + chunk * 8),
                                        (lptr_t)(Ks + blk * 1024), 16, 0, 0);
     }
     {
       const int row = blk * 8 + (lane >> 3), pc = lane & 7;
       const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);  // logical 16-B chunk of this slot
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)min(row, L - 1) * rs + 2 * D + lc * 8),
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)min(row, L - 1) * rs + VO + lc * 8),
                                        (lptr_t)(Vs + blk * 1024), 16, 0, 0);
     }
   }
@@ -577,7 +581,7 @@ int g_attn_variant = 1;  // 1 = attn_tr_kernel (shipped), 0 = attn_bf16_kernel (
 
 template <int PREC, int NT, int NW, int OCC, int PRIO = 0>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
-                     hipStream_t s, int rev) {
+                     hipStream_t s, int rev, int hm) {
   constexpr int lds = NT * 16 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -591,10 +595,10 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
   }
   if (causal)
     hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   else
     hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
-                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev);
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   return hipGetLastError();
 }
 
@@ -608,25 +612,25 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
 // for every wave count (a q-block's arithmetic does not depend on which wave runs it).
 template <int PREC>
 hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
-                              hipStream_t s, int rev) {
+                              hipStream_t s, int rev, int hm) {
   const int nt = (L + 15) / 16;
 #ifdef MCM_HARNESS
   if (g_attn_variant == 10 && nseq % 8 == 0) rev |= 2;  // XCD-aware deal of the (sequence, head) workgroups
 #endif
 #ifdef MCM_HARNESS  // priority A/B arms, B/16 shape only (13 key tiles)
-  if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 3) return launch_tr<PREC, 13, 8, 3, 2>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 4) return launch_tr<PREC, 13, 8, 3, 3>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 3) return launch_tr<PREC, 13, 8, 3, 2>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 4) return launch_tr<PREC, 13, 8, 3, 3>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
   // wave-count arms: one q-block per wave (13 waves, 832 threads) at two register budgets, and 10 waves
-  if (nt == 13 && g_attn_variant == 5) return launch_tr<PREC, 13, 13, 7>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 6) return launch_tr<PREC, 13, 13, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 7) return launch_tr<PREC, 13, 10, 5>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 5) return launch_tr<PREC, 13, 13, 7>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 6) return launch_tr<PREC, 13, 13, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 7) return launch_tr<PREC, 13, 10, 5>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
   // two-pass form at 80 registers (three workgroups per CU) and at the default budget
-  if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
 #endif
 #define MCM_TR(N, W, O) \
-  if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev)
+  if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm)
   MCM_TR(1, 4, 3); MCM_TR(2, 4, 3); MCM_TR(3, 4, 3); MCM_TR(4, 4, 3); MCM_TR(5, 4, 3); MCM_TR(6, 4, 3);
   MCM_TR(8, 4, 3); MCM_TR(10, 8, 3); MCM_TR(13, 8, 3); MCM_TR(17, 8, 3); MCM_TR(18, 8, 3);
 #undef MCM_TR
@@ -641,9 +645,13 @@ void attention_set_variant(int v) { g_attn_variant = v; }
 #endif
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse) {
+                            bool causal, int qrows, hipStream_t s, bool reverse, int hm) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
+  if (hm && (prec == MCM_PREC_F32 || (int64_t)hm < (int64_t)nseq * L)) return hipErrorInvalidValue;
+#ifdef MCM_HARNESS
+  if (hm && g_attn_variant == 0) return hipErrorInvalidValue;  // the round-1 kernel reads row-major qkv only
+#endif
 #ifdef MCM_HARNESS
   if (prec != MCM_PREC_F32 && g_attn_variant == 0) {
 #define MCM_ATTN_BY_LP(P)                                                                      \
@@ -662,9 +670,9 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   }
 #endif
   if (prec == MCM_PREC_F16)
-    return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
+    return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
   if (prec == MCM_PREC_BF16)
-    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0);
+    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;

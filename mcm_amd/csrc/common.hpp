@@ -200,7 +200,16 @@ struct GemmArgs {
   float2* fold_part;      //   per-row partial moments [N / 64][M]: (sum, sum of squares about the 64-column mean)
   const float2* fold_rs;  // EPI_STORE / EPI_GELU (consumer): per-row (rstd, mean * rstd) [M]
   const float* fold_c;    //   c [N] = W gamma; `bias` then holds b + W beta
+  // 16-bit outputs, head-major (0 = row-major with stride ldo): column block n >> 6 — the 64 dims of one head of q, k
+  // or v — is a contiguous [hm rows][64] array, element (m, n) at ((n >> 6) * hm + m) * 64 + (n & 63).  The QKV
+  // projection writes this form so that an attention workgroup's K / V / Q rows are 25 KiB of consecutive bytes
+  // instead of 197 segments of 128 B at a 4.6-KB stride.  An A/B arm: the shipped library passes 0.
+  int hm;
 };
+// element offset of (m, n) in a 16-bit GEMM output
+__device__ __forceinline__ size_t out16_off(const GemmArgs& a, int m, int n) {
+  return a.hm ? ((size_t)(n >> 6) * a.hm + m) * 64 + (n & 63) : (size_t)m * a.ldo + n;
+}
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 // which LayerNorm-fold form launch_gemm has for this problem: 1 = ping-pong kernel (producer and consumer epilogues),
 // 2 = tile kernel (consumer epilogue only; its producer is launch_fold_rows after the plain residual GEMM), 0 = none
@@ -235,8 +244,10 @@ hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float
                                 const float* pos0 = nullptr, int ntok = 0);
 
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
+// hm: 0 = qkv is [rows][3 D] row-major; > 0 = head-major as GemmArgs::hm writes it ([3 heads][hm rows][64], 16-bit
+// modes only; `qkv` is then the base of the whole array and the launch covers sequences from row 0)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse = false);
+                            bool causal, int qrows, hipStream_t s, bool reverse = false, int hm = 0);
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
                            int patch, int kpad, hipStream_t s);

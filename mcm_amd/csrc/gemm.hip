@@ -166,7 +166,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
         sat_track<PREC>(amax, v[fj][0], v[fj][1]);
         sat_track<PREC>(amax, v[fj][2], v[fj][3]);
       }
-      uint4* dst = (uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + n);
+      uint4* dst = (uint4*)((uint16_t*)a.out + out16_off(a, m, n));
       dst[0] = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
                           pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
       dst[1] = make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
@@ -197,6 +197,15 @@ __device__ __forceinline__ void store16_stream(void* p, const V& v) {
   // registers on gfx940+; hipcc pads its own stores but cannot see inside this asm (without the
   // pad, rows of garbage appeared whenever the TA was slow to pick the data up)
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(vv) : "memory");
+}
+
+// the same with a scalar base and a 32-bit lane offset (bytes)
+template <typename V>
+__device__ __forceinline__ void store16_stream_s(const void* sbase, uint32_t voff, const V& v) {
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte payload");
+  const u32x4_t vv = __builtin_bit_cast(u32x4_t, v);
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(vv), "s"(sbase) : "memory");
 }
 
 // INTERIOR (16-bit outputs only; the ping-pong kernel): the caller guarantees a full tile and uniform mw / nw;
@@ -260,16 +269,22 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
         r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 128 + ((c8 ^ (row & 7)) << 4));
       }
     };
-    const int lane_off = rrow * a.ldo + c8 * 8;  // elements
+    // head-major outputs (a.hm): the wave's 64 columns are one head's block, whose rows are 128 B apart
+    const int ldo_e = a.hm ? 64 : a.ldo;
+    const int lane_off = rrow * ldo_e + c8 * 8;  // elements
+    // INTERIOR: scalar base + one 32-bit lane offset; the base walks down the tile 8 rows per store (two scalar adds
+    // per store instead of a 64-bit multiply-add chain and a vector 64-bit add)
+    const char* sp = (const char*)a.out + out16_off(a, mw, nw) * 2;
+    const size_t sp_step = (size_t)ldo_e * 16;  // bytes per 8 rows
     auto store_unit = [&](int u, const uint4 (&r)[2]) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if constexpr (INTERIOR) {
-          uint16_t* rowbase = (uint16_t*)a.out + (size_t)(mw + u * 16 + t * 8) * a.ldo + nw;
-          if (!DBG(16)) store16_stream(rowbase + lane_off, r[t]);
+          if (!DBG(16)) store16_stream_s(sp, (uint32_t)lane_off * 2u, r[t]);
+          sp += sp_step;
         } else {
           const int m = mw + u * 16 + t * 8 + rrow;
-          if (m < a.M && n < a.N && !DBG(16)) store16_stream((uint16_t*)a.out + (size_t)m * a.ldo + n, r[t]);
+          if (m < a.M && n < a.N && !DBG(16)) store16_stream((uint16_t*)a.out + out16_off(a, m, n), r[t]);
         }
       }
     };
@@ -865,7 +880,11 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
   const int rrow = lane >> 4, c16 = lane & 15;
   const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes
   const char* base = (const char*)(EPI == EPI_RESID ? a.resid : (float*)a.out) + ((size_t)mw * a.ldo + nw) * 4;
-  auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
+  // rows are visited in order, 4 at a time: a load pointer and a store pointer walk down the tile by one scalar add
+  // each (per-row-group offsets computed up front cost 64 scalar registers and pushed loop state into VGPR lanes)
+  const size_t step = (size_t)a.ldo * 16;  // bytes per 4 rows
+  const char* lp = base;
+  const char* sp = base;
   f32x4_t buf[2][4];
   // EPI_RESID: the bias of the lane's 4 columns AFTER the bounce, loaded here (4 registers, and nothing of this epilogue
   // is live across the K loop; `bv` is not used) - the same (acc + b) + resid as every other form
@@ -873,14 +892,20 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
   if constexpr (EPI == EPI_RESID) {
     if (a.bias) gload16(bia, a.bias + nw, (uint32_t)c16 * 16u);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
+    for (int t = 0; t < 4; ++t) {
+      gload16(buf[0][t], lp, voff);
+      lp += step;
+    }
   }
 #pragma unroll
   for (int c = 0; c < MF; ++c) {
     if constexpr (EPI == EPI_RESID) {
       if (c + 1 < MF) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) gload16(buf[(c + 1) & 1][t], rowbase(c + 1, t), voff);
+        for (int t = 0; t < 4; ++t) {
+          gload16(buf[(c + 1) & 1][t], lp, voff);
+          lp += step;
+        }
       }
     }
 #pragma unroll
@@ -907,7 +932,10 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
       for (int t = 0; t < 4; ++t) v[t] = (v[t] + bia) + buf[c & 1][t];
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) gstore16(rowbase(c, t), voff, v[t]);
+    for (int t = 0; t < 4; ++t) {
+      gstore16(sp, voff, v[t]);
+      sp += step;
+    }
   }
 }
 
@@ -1980,7 +2008,7 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   }
   if (v == 6) {  // ping-pong on 32x32x16 MFMAs: 16-bit operand modes, whole tiles; else as 5
     if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
-      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp32<PREC, EPI>(a, s);
+      if (a.M % p256::BM == 0 && a.N % p256::BN == 0 && !a.hm) return launch_pp32<PREC, EPI>(a, s);
     }
     v = 5;
   }
@@ -2039,6 +2067,8 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)
     return hipErrorInvalidValue;
+  // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
+  if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
   switch (prec) {
     case MCM_PREC_BF16: return launch_prec<MCM_PREC_BF16>(epi, a, s);
     case MCM_PREC_F16: return launch_prec<MCM_PREC_F16>(epi, a, s);

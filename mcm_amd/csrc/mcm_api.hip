@@ -200,13 +200,21 @@ hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const f
 }
 // seq0: first sequence of the launch (a chunk of the batch starts there)
 hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int heads, bool causal,
-                int qrows = 0, int seq0 = 0) {
+                int qrows = 0, int seq0 = 0, int hm = 0) {
   const int q = qrows > 0 ? qrows : L;
   Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)q * L * 64 * (causal ? 0.5 : 1.0));
   const size_t es = prec_esize(prec), D = (size_t)heads * 64, row0 = (size_t)seq0 * L;
   return launch_attention(prec, (const char*)h->qkv + row0 * 3 * D * es, (char*)h->att + row0 * D * es, nseq, L,
-                          heads, causal, qrows, s, next_dir(h));
+                          heads, causal, qrows, s, next_dir(h), hm);
 }
+// A/B arm (harness: mcm_debug_qkv_head_major): qkv of the 16-bit towers head-major ([3 heads][rows][64],
+// GemmArgs::hm) between the QKV projection and attention.  Bit-identical; attention 1.63 -> 1.56 ms per step, the QKV
+// projection's stores +0.04 ... 0.08 ms: no net gain, the shipped library keeps [rows][3 D].
+#ifdef MCM_HARNESS
+int g_qkv_head_major = 0;
+#else
+constexpr int g_qkv_head_major = 0;
+#endif
 #ifdef MCM_HARNESS
 int g_qkv_chunks = 1;  // A/B: QKV projection + attention per chunk of the batch (qkv of a chunk stays in the Infinity Cache)
 int g_ln_fold = 0;     // A/B: 1 = LayerNorm fold (mcm_debug_ln_fold); 0 = every LayerNorm as its own launch (shipped)
@@ -282,8 +290,12 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
         a.out = (char*)h->qkv + (size_t)r0 * 3 * D * es;
         a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
         if (ln1_folded) { a.bias = w.bqkvf; a.fold_rs = h->fold_rs; a.fold_c = w.cqkv; }
+        // whole-batch launches of a 16-bit tower hand q / k / v over head-major (same bytes in h->qkv, other order;
+        // the row-0-only layer below and the fp32 towers keep [rows][3 D])
+        const int hm = (g_qkv_head_major && nch == 1 && P != MCM_PREC_F32 && t.heads * 64 == D) ? Mp : 0;
+        a.hm = hm;
         HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
-        HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq));
+        HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq, hm));
       }
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
@@ -919,6 +931,10 @@ int mcm_debug_ln_fold(int32_t on) {  // 0 (shipped behaviour): every LayerNorm a
   return MCM_OK;
 }
 
+int mcm_debug_qkv_head_major(int32_t on) {
+  g_qkv_head_major = on ? 1 : 0;
+  return MCM_OK;
+}
 int mcm_debug_qkv_chunks(int32_t n) {
   if (n < 1 || n > 16) return MCM_EINVAL;
   g_qkv_chunks = n;
