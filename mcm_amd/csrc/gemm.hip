@@ -2052,6 +2052,15 @@ int gemm_fold_kind(int epi, int M, int N) {
   return 0;
 }
 
+static hipError_t launch_gemm_one(int prec, int epi, const GemmArgs& a, hipStream_t s) {
+  switch (prec) {
+    case MCM_PREC_BF16: return launch_prec<MCM_PREC_BF16>(epi, a, s);
+    case MCM_PREC_F16: return launch_prec<MCM_PREC_F16>(epi, a, s);
+    case MCM_PREC_F32: return launch_prec<MCM_PREC_F32>(epi, a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   const int es = prec_esize(prec);
@@ -2069,10 +2078,39 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
     return hipErrorInvalidValue;
   // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
   if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
-  switch (prec) {
-    case MCM_PREC_BF16: return launch_prec<MCM_PREC_BF16>(epi, a, s);
-    case MCM_PREC_F16: return launch_prec<MCM_PREC_F16>(epi, a, s);
-    case MCM_PREC_F32: return launch_prec<MCM_PREC_F32>(epi, a, s);
+#ifndef MCM_NO_SLIVER_SPLIT
+  // Sliver round.  The persistent kernel walks T = row tiles x N tiles on G workgroups; when T is a little more than
+  // a whole number of rounds, the last round keeps a few CUs busy for a full tile time while the rest of the chip
+  // idles — ViT-B/32 at batch 512: 100 row tiles x 3 = 300 tiles on 256 workgroups, 1 round + 44 tiles, paid as 2.
+  // Such a problem is cut at a row-tile boundary: the rows that fill whole rounds on every XCD (row tiles are dealt to
+  // the XCDs modulo 8, 1/8 of the workgroups each) go to the ping-pong kernel, the row tiles left over to the 128x128
+  // tile kernel, whose many small workgroups spread over the whole chip.  The kernels are bit-identical
+  // (tests/test_gpu_kernels.py::test_linear_sliver_split_bitwise), so the result does not depend on the cut.
+  {
+    const int G = persistent_grid();
+    const bool fold = a.fold_z != nullptr || a.fold_rs != nullptr;
+    if (epi != EPI_PATCH && !fold && variant() < 0 && G >= 8 && a.M % p256::BM == 0 && a.N % p256::BN == 0 &&
+        size_policy(a.M, a.N) == 5) {
+      const long nbn = a.N / p256::BN, rt = a.M / p256::BM, T = rt * nbn, R = T / G, left = T - R * G;
+      const long rt1 = 8 * ((R * (G / 8)) / nbn);  // row tiles of R whole rounds on each XCD
+      // ... worth it only when the rows left over make enough 128x128 workgroups to occupy the chip: a handful of
+      // them, one per CU with nobody to overlap with, take as long over a deep K as the round they replace (measured
+      // at ViT-L/14, where one row tile is left: 5 918 vs 5 921 img/s; ViT-B/32, 20 row tiles: +2.9 %)
+      const long rest_wgs = (rt - rt1) * 2 * (a.N / 128);
+      if (R >= 1 && left > 0 && left * 4 <= G && rt1 >= 1 && rt1 < rt && rest_wgs * 2 >= G &&
+          size_policy((int)(rt1 * p256::BM), a.N) == 5) {
+        GemmArgs m = a, r = a;
+        const size_t row0 = (size_t)rt1 * p256::BM;
+        m.M = (int)row0;
+        r.M = a.M - (int)row0;
+        r.x = (const char*)a.x + row0 * a.ldx * es;
+        if (a.out) r.out = (char*)a.out + (a.hm ? row0 * 64 : row0 * a.ldo) * es;
+        if (a.resid) r.resid = a.resid + row0 * a.ldo;
+        hipError_t e = launch_gemm_one(prec, epi, m, s);
+        return e != hipSuccess ? e : launch_gemm_one(prec, epi, r, s);
+      }
+    }
   }
-  return hipErrorInvalidValue;
+#endif
+  return launch_gemm_one(prec, epi, a, s);
 }

@@ -247,6 +247,44 @@ def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, pre
         harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,epi", [(25600, 768, 768, 2), (25600, 768, 3072, 2), (25600, 768, 768, 0),
+                                       (512 * 257, 1024, 1024, 2)])
+def test_linear_sliver_split_bitwise(tiny_net, harness_net, M, N, K, epi, prec):
+    """Sliver-round split of launch_gemm (gemm.hip): problems whose tile count is a little more than whole rounds of the
+    persistent grid — ViT-B/32 at batch 512 (100 row tiles x 3 = 300 tiles on 256 workgroups) — are cut at a row-tile
+    boundary into a ping-pong launch and a tile-kernel launch (not ViT-L/14's: its single left-over row tile makes too
+    few workgroups to pay, the last case checks that it still comes out the same).  The shipped library's own choice (split) against
+    the forced unsplit ping-pong kernel and the tile kernel of the harness library, bit for bit, incl. the last rows."""
+    dt = DTYPE[prec]
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
+    x = torch.randn((M, K), generator=g, device="cuda").to(dt)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dt)
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
+
+    def run(variant):
+        net = tiny_net if variant < 0 else harness_net
+        if variant >= 0:
+            assert net._lib.mcm_debug_gemm_variant(variant) == 0
+        y = torch.zeros((M, N), device="cuda", dtype=dt)
+        rd = resid0.clone() if epi == 2 else y
+        rc = net._lib.mcm_op_linear(net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, net._lib.mcm_last_error(net._h)
+        torch.cuda.synchronize()
+        return rd if epi == 2 else y
+
+    try:
+        split = run(-1)
+        assert torch.isfinite(split.float()).all() and bool((split[-256:].float() != 0).any())
+        for variant in (0, 5):
+            got = run(variant)
+            assert torch.equal(got.view(torch.int32 if epi == 2 else torch.int16),
+                               split.view(torch.int32 if epi == 2 else torch.int16)), f"variant {variant}"
+    finally:
+        harness_net._lib.mcm_debug_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2)])
 def test_linear_l14_shapes_pingpong_bitwise(tiny_net, harness_net, N, K, epi):
     """BASELINE config 4 (ViT-L/14, batch 256: M = 256 * 257 rows, K = 1024 / 4096): the ping-pong kernel against
