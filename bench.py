@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--gemm-dbg", type=int, default=0, help="A/B hook (harness library): GEMM ablation / A-B bits")
     ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
     ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
+    ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
@@ -297,13 +298,15 @@ def main():
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
         raise SystemExit(f"unknown --attn-variant {args.attn_variant}")
     if args.ln_fold >= 0:
         net._lib.mcm_debug_ln_fold(args.ln_fold)
+    if args.ln_tail >= 0:
+        net._lib.mcm_debug_ln_tail(args.ln_tail)
     txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
                                 normalize=True)
     if args.qkv_chunks > 1 and net._lib.mcm_debug_qkv_chunks(args.qkv_chunks) != 0:
@@ -401,6 +404,8 @@ def main():
             line["harness_attn_variant"] = args.attn_variant
         if args.ln_fold >= 0:
             line["harness_ln_fold"] = args.ln_fold
+        if args.ln_tail >= 0:
+            line["harness_ln_tail"] = args.ln_tail
         if args.gemm_variant >= 0:
             line["harness"] = f"libmcm_hip_harness.so, GEMM variant {args.gemm_variant} forced (A/B run, not the shipped policy)"
         if ws > 1:

@@ -310,6 +310,13 @@ int mcm_debug_ln_fold(int32_t on);
 /* A/B: 1 = the 16-bit towers hand q / k / v from the QKV projection to attention head-major ([3 heads][rows][64]: an
  * attention workgroup's rows are consecutive bytes); 0 (default, shipped) = [rows][3 D].  Bit-identical; no net gain. */
 int mcm_debug_qkv_head_major(int32_t on);
+/* A/B: 1 = the LayerNorm behind a whole-batch out-proj / fc2 of a 16-bit vision tower is computed in the tail of that
+ * GEMM's kernel by the waves that have run out of tiles (same bits as the LayerNorm launch); 0 (default, shipped) =
+ * every LayerNorm is its own launch.  Measured equal at ViT-B/16 batch 512, slower on smaller problems, DESIGN.md 5.5. */
+int mcm_debug_ln_tail(int32_t on);
+/* Tickets of the LayerNorm tail that gave up waiting for their rows (a bounded spin: wrong rows rather than a hung
+ * device); 0 in a correct run.  Synchronises the device. */
+int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host);
 #endif
 
 #ifdef __cplusplus

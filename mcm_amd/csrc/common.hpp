@@ -205,6 +205,14 @@ struct GemmArgs {
   // projection writes this form so that an attention workgroup's K / V / Q rows are 25 KiB of consecutive bytes
   // instead of 197 segments of 128 B at a 4.6-KB stride.  An A/B arm: the shipped library passes 0.
   int hm;
+  // LayerNorm in the tail (EPI_RESID, ping-pong kernel, 16-bit modes; gemm.hip "LayerNorm in the tail"): the LayerNorm
+  // that follows this residual GEMM is computed by the GEMM kernel's own waves once they run out of tiles
+  const float* ln_g;       // gamma [N]; ln_y == nullptr: not fused, the caller launches the LayerNorm
+  const float* ln_b;       // beta [N]
+  void* ln_y;              // LayerNorm output [M, N] in the operand dtype, row stride N
+  float ln_eps;
+  unsigned int* ln_state;  // 8 regions (one per XCD) of ln_rs words: [ln_cap8] row-tile counters, tickets, finished
+  int ln_rs, ln_cap8;      //   workgroups, timeouts; all zero between launches (the kernel leaves it so)
 };
 // element offset of (m, n) in a 16-bit GEMM output
 __device__ __forceinline__ size_t out16_off(const GemmArgs& a, int m, int n) {
@@ -214,6 +222,8 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 // which LayerNorm-fold form launch_gemm has for this problem: 1 = ping-pong kernel (producer and consumer epilogues),
 // 2 = tile kernel (consumer epilogue only; its producer is launch_fold_rows after the plain residual GEMM), 0 = none
 int gemm_fold_kind(int epi, int M, int N);
+bool gemm_ln_tail_ok(int prec, int M, int N);
+int gemm_persistent_grid();
 // LayerNorm fold, weight side: c[n] = sum_k gamma[k] W[n,k], bfold[n] = bias[n] + sum_k beta[k] W[n,k]  (W: operand dtype)
 hipError_t launch_fold_prep(int prec, const void* w, const float* gamma, const float* beta, const float* bias,
                             float* c, float* bfold, int N, int K, hipStream_t s);

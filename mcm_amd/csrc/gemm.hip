@@ -42,6 +42,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "ln_row.hpp"
 
 namespace {
 
@@ -1098,6 +1099,114 @@ __device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uin
 #define PPT_DUMP()
 #endif
 
+// =========================================================================================
+// LayerNorm in the tail (LNT; EPI_RESID, 16-bit operand modes).  A residual GEMM (out-proj, fc2) is always followed by
+// the LayerNorm of the rows it has just updated, and its persistent grid always ends ragged: 1 182 tiles on 256
+// workgroups are 4.6 rounds, so in the last round 38 % of the CUs have nothing left to do for a whole tile time.
+// With LNT the kernel does not end there: a wave that has run out of tiles draws tickets — 32 rows each, in the order
+// the row tiles were walked — waits until every tile of the ticket's row tile has been PUBLISHED, and normalises those
+// rows (ln_row.hpp: the LayerNorm kernel's arithmetic, bit for bit) into the next GEMM's operand buffer.  The separate
+// LayerNorm launch, its 310-MB read in a low-occupancy-free interval of its own, and the ragged tail disappear together.
+//
+// Coherence.  Everything a ticket touches lives in ONE XCD's L2: row tiles are dealt to XCDs (row tile = mt * 8 + xcd,
+// xcd = blockIdx & 7 — all workgroups with the same blockIdx & 7 share an XCD; mcm_api.hip verifies that on the device
+// before it ever sets ln_y), a row tile's counters sit in that XCD's region of ln_state, and only waves of that XCD
+// normalise its rows.  Publication: a wave's epilogue stores are complete when the vmcnt(0) that ends its next compute
+// phase (or follows the last epilogue) has passed; then lane 0 adds 1 to the row tile's counter with an L2 atomic.
+// A counter reaches N/256 x 8 (tiles x waves) when the whole 256 x N block is in L2.  The consumer polls with a
+// returning L2 atomic (add 0), drops its CU's L1 (buffer_inv sc1) and reads the rows.  All atomics are inline asm
+// without scope bits: performed in the XCD's own L2, invisible to hipcc's waitcnt pass.
+// Deadlock-free: every workgroup of the grid is resident (one per CU) and a tile's producers never wait for anybody.
+// ln_state (per XCD region of ln_rs words): [ln_cap8] counters, tickets drawn, workgroups finished, timeouts.  The
+// last workgroup of an XCD to finish zeroes the region's first three parts: the state is all zero between launches
+// (no memset launch, no launch parity: a captured graph replays it unchanged).
+// =========================================================================================
+__device__ __forceinline__ void l2_atomic_add(const void* sbase, uint32_t voff, uint32_t val) {
+  asm volatile("global_atomic_add %0, %1, %2" ::"v"(voff), "v"(val), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ uint32_t l2_atomic_add_ret(const void* sbase, uint32_t voff, uint32_t val) {
+  uint32_t r;
+  asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(r)
+               : "v"(voff), "v"(val), "s"(sbase)
+               : "memory");
+  return r;
+}
+// one lane of the wave performs the atomic; every lane gets the value
+__device__ __forceinline__ uint32_t wave_l2_add_ret(const void* sbase, uint32_t off, uint32_t val, int lane) {
+  uint32_t r = 0;
+  if (lane == 0) r = l2_atomic_add_ret(sbase, off, val);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+template <int PREC, int NVU>
+__device__ __forceinline__ void ln_tail_nv(const GemmArgs& a, int xcd, int nmt_x, int lane, float& amax) {
+  const unsigned int* reg = a.ln_state + (size_t)xcd * a.ln_rs;  // this XCD's region
+  const uint32_t need = (uint32_t)(a.N / 256) * 8u;
+  const uint32_t ntick = (uint32_t)nmt_x * 8u;
+  constexpr int D = NVU * 256;
+  for (;;) {
+    const uint32_t t = wave_l2_add_ret(reg, (uint32_t)a.ln_cap8 * 4u, 1u, lane);
+    if (t >= ntick) break;
+    const int mtl = (int)(t >> 3), sub = (int)(t & 7);
+    const int mt = a.rev ? nmt_x - 1 - mtl : mtl;
+    int spins = 0;
+    while (wave_l2_add_ret(reg, (uint32_t)mt * 4u, 0u, lane) < need) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > (1 << 20)) {  // never in a correct run: count it and go on (wrong rows beat a hung box)
+        if (lane == 0) l2_atomic_add(reg, (uint32_t)(a.ln_cap8 + 2) * 4u, 1u);
+        break;
+      }
+    }
+    asm volatile("buffer_inv sc1" ::: "memory");
+    const size_t row0 = ((size_t)mt * 8 + xcd) * 256 + (size_t)sub * 32;
+#pragma unroll 1
+    for (int r0 = 0; r0 < 32; r0 += 8) {  // 8 rows side by side: 24 - 32 loads in flight, 8 reductions per exchange
+      float4 v[8][LN_MAXV];
+      float acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* xr = a.resid + (row0 + r0 + r) * (size_t)D;
+#pragma unroll
+        for (int i = 0; i < NVU; ++i) {
+          typedef float f4_t __attribute__((ext_vector_type(4)));
+          const f4_t q = __builtin_nontemporal_load((const f4_t*)(xr + (i * 64 + lane) * 4));
+          v[r][i] = make_float4(q.x, q.y, q.z, q.w);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = ln_part_sum<NVU>(v[r], D, lane);
+      wave_sum_n<8>(acc);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = ln_center_sq<NVU>(v[r], ln_mean(acc[r], D), D, lane);
+      wave_sum_n<8>(acc);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        ln_scale<NVU>(v[r], ln_rstd(acc[r], D, a.ln_eps), a.ln_g, a.ln_b, D, lane);
+        ln_row_store<PREC, NVU>(v[r], (uint16_t*)a.ln_y + (row0 + r0 + r) * (size_t)D, D, lane, amax);
+      }
+    }
+  }
+}
+template <int PREC>
+__device__ __forceinline__ void ln_tail(const GemmArgs& a, int xcd, int nmt_x, int lane, float& amax) {
+  if (a.N == 768) ln_tail_nv<PREC, 3>(a, xcd, nmt_x, lane, amax);  // the widths of the CLIP vision towers
+  else ln_tail_nv<PREC, 4>(a, xcd, nmt_x, lane, amax);             // (launch_one admits 768 and 1024 only)
+}
+// end of an LNT kernel: the last workgroup of this XCD to get here zeroes the XCD's counters, tickets and finish count
+__device__ __forceinline__ void ln_finish(const GemmArgs& a, int xcd, char* smem) {
+  const unsigned int* reg = a.ln_state + (size_t)xcd * a.ln_rs;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = (int*)smem;
+  if (threadIdx.x == 0) *flag = l2_atomic_add_ret(reg, (uint32_t)(a.ln_cap8 + 1) * 4u, 1u) == (gridDim.x >> 3) - 1;
+  __syncthreads();
+  if (*flag) {
+    const uint32_t zero = 0u;
+    for (int i = threadIdx.x; i < a.ln_cap8 + 2; i += blockDim.x)
+      asm volatile("global_store_dword %0, %1, %2" ::"v"((uint32_t)i * 4u), "v"(zero), "s"(reg) : "memory");
+  }
+}
+
 // BAL (balanced DMA): waves 0-3 stage their X half and W rows 0-127, waves 4-7 their X half and W rows 128-255 —
 // 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
 // waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
@@ -1108,8 +1217,10 @@ __device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uin
 // FOLD (LayerNorm fold, 16-bit modes): EPI_RESID runs the producer epilogue (wave_epilogue_resid_fold), EPI_STORE /
 // EPI_GELU the consumer form of wave_epilogue_lds; a wave then carries 6 registers of row / column data across its last
 // compute phase instead of 16 bias registers.
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false>
+// LNT: LayerNorm in the tail (above)
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
+  static_assert(!LNT || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG), "LNT: plain residual form");
   using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1124,7 +1235,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const int nmt_x = (nbm - xcd + 7) >> 3;
   const int ntl_x = nmt_x * nbn;
   const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) return;
+  if (ntl == 0) {  // no tile for this workgroup (small problems): it still takes LayerNorm tickets
+    if constexpr (LNT) {
+      float am = 0.f;
+      ln_tail<PREC>(a, xcd, nmt_x, lane, am);
+      sat_report<PREC>(am, a.sat);
+      ln_finish(a, xcd, smem);
+    }
+    return;
+  }
   const int nk = (a.K * ES) / ROWB;
   const int total = ntl * nk;
 
@@ -1323,6 +1442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   }
   int ktc = 0;
   bool pend = false;
+  int pub = -1;  // LNT: row tile (index within this XCD) whose epilogue this wave has issued but not yet published
   auto phase_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1351,6 +1471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
         if constexpr (!STAG) phase_barrier();
       }
       epilogue();
+      if constexpr (LNT) pub = (em0 / BM) >> 3;
       if (!grp) {
         const LaneK lk = lane_consts();
         fo1 = lk.fo1;
@@ -1424,6 +1545,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
     PPT(2);
     wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
+    if constexpr (LNT) {  // ... and, in the first phase after an epilogue, its stores: the tile is published
+      if (pub >= 0) {
+        if (lane == 0) l2_atomic_add(a.ln_state + (size_t)xcd * a.ln_rs, (uint32_t)pub * 4u, 1u);
+        pub = -1;
+      }
+    }
     phase_barrier();
     PPT(3);
     pend = false;
@@ -1440,7 +1567,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
-  if constexpr (EPI <= EPI_GELU || FOLD) sat_report<PREC>(amax, a.sat);
+  if constexpr (LNT) {
+    if (pend) pub = (em0 / BM) >> 3;
+    wait_vmcnt<0>();
+    if (pub >= 0 && lane == 0) l2_atomic_add(a.ln_state + (size_t)xcd * a.ln_rs, (uint32_t)pub * 4u, 1u);
+    ln_tail<PREC>(a, xcd, nmt_x, lane, amax);
+  }
+  if constexpr (EPI <= EPI_GELU || FOLD || LNT) sat_report<PREC>(amax, a.sat);
+  if constexpr (LNT) ln_finish(a, xcd, smem);
   PPT_DUMP();
 }
 
@@ -1928,16 +2062,16 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false>
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1985,6 +2119,18 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
       if constexpr (EPI <= EPI_GELU) {
         if (v == 0 && sides) return launch_tile<PREC, EPI, true>(a, s);
       }
+    }
+#endif
+    return hipErrorInvalidValue;
+  }
+  if (a.ln_y) {  // LayerNorm in the tail: the ping-pong kernel's residual form only (the caller asked gemm_ln_tail_ok).
+                 // An A/B arm (harness / -DMCM_LN_TAIL builds): measured equal at ViT-B/16 batch 512 and slower on smaller
+                 // problems, so the shipped library launches its LayerNorms and does not carry the kernel.
+#if defined(MCM_HARNESS) || defined(MCM_LN_TAIL)
+    if constexpr (EPI == EPI_RESID && PREC != MCM_PREC_F32) {
+      if (v == 5 && a.M % p256::BM == 0 && a.N % p256::BN == 0 && (a.N == 768 || a.N == 1024) && a.ldo == a.N && a.ln_g &&
+          a.ln_b && a.ln_state && a.ln_cap8 * 8 >= a.M / p256::BM && persistent_grid() % 8 == 0)
+        return launch_pp<PREC, EPI, false, false, false, true>(a, s);
     }
 #endif
     return hipErrorInvalidValue;
@@ -2044,6 +2190,17 @@ void gemm_set_group_n(int gn) { g_group_n = gn > 0 ? gn : 0; }
 constexpr int g_group_n = 0, g_dbg = 0;
 #endif
 
+// LayerNorm in the tail: whether launch_gemm takes a residual GEMM of this size with GemmArgs::ln_y set (the ping-pong
+// kernel, whole tiles, rows of at most 1024 columns); the host then does not launch the LayerNorm that follows
+int gemm_persistent_grid() { return persistent_grid(); }  // workgroups of the persistent kernels (one per CU, multiple of 8)
+bool gemm_ln_tail_ok(int prec, int M, int N) {
+#if !defined(MCM_HARNESS) && !defined(MCM_LN_TAIL)
+  return false;
+#endif
+  if (prec == MCM_PREC_F32 || M <= 0 || M % p256::BM || (N != 768 && N != 1024)) return false;
+  return size_policy(M, N) == 5 && persistent_grid() >= 8;
+}
+
 int gemm_fold_kind(int epi, int M, int N) {
   if (epi == EPI_PATCH || M <= 0 || N <= 0) return 0;
   const int v = size_policy(M, N);
@@ -2089,7 +2246,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   {
     const int G = persistent_grid();
     const bool fold = a.fold_z != nullptr || a.fold_rs != nullptr;
-    if (epi != EPI_PATCH && !fold && variant() < 0 && G >= 8 && a.M % p256::BM == 0 && a.N % p256::BN == 0 &&
+    if (epi != EPI_PATCH && !fold && !a.ln_y && variant() < 0 && G >= 8 && a.M % p256::BM == 0 && a.N % p256::BN == 0 &&
         size_policy(a.M, a.N) == 5) {
       const long nbn = a.N / p256::BN, rt = a.M / p256::BM, T = rt * nbn, R = T / G, left = T - R * G;
       const long rt1 = 8 * ((R * (G / 8)) / nbn);  // row tiles of R whole rounds on each XCD

@@ -6,11 +6,11 @@
 // keeps it in registers for the exact two-pass mean / centred variance, writes the
 // normalised row in the GEMM operand dtype (bf16 or fp32).  In-place (y == x, fp32) is
 // safe: a wave has its whole row in registers before it stores.
-#include "common.hpp"
+#include "ln_row.hpp"
 
 namespace {
 
-constexpr int MAXV = 4;  // float4 per lane: D <= 64*4*4 = 1024
+constexpr int MAXV = LN_MAXV;  // float4 per lane: D <= 64*4*4 = 1024
 
 template <int OUT>  // OUT = MCM_PREC_F32: fp32 rows; BF16 / F16: packed 16-bit rows
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
   if (rev) row = M - 1 - row;
   const float* xr = x + (size_t)row * xs;
   float4 v[MAXV];
-  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int d = (i * 64 + lane) * 4;
@@ -37,44 +36,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
       } else {
         v[i] = *(const float4*)(xr + d);
       }
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int d = (i * 64 + lane) * 4;
-    if (d < D) {
-      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  ln_row_apply(v, g, b, D, eps, lane);
   float amax = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int d = (i * 64 + lane) * 4;
-    if (d < D) {
-      const float4 gv = *(const float4*)(g + d);
-      const float4 bv = *(const float4*)(b + d);
-      float4 o;
-      o.x = v[i].x * rstd * gv.x + bv.x;
-      o.y = v[i].y * rstd * gv.y + bv.y;
-      o.z = v[i].z * rstd * gv.z + bv.z;
-      o.w = v[i].w * rstd * gv.w + bv.w;
-      if constexpr (OUT != MCM_PREC_F32) {
-        uint2 pk;
-        pk.x = pack2<OUT>(o.x, o.y);
-        pk.y = pack2<OUT>(o.z, o.w);
-        sat_track<OUT>(amax, o.x, o.y);
-        sat_track<OUT>(amax, o.z, o.w);
-        *(uint2*)((uint16_t*)y + (size_t)row * ys + d) = pk;
-      } else {
-        *(float4*)((float*)y + (size_t)row * ys + d) = o;
-      }
-    }
-  }
+  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT>(v, (uint16_t*)y + (size_t)row * ys, D, lane, amax);
+  else ln_row_store<OUT>(v, (float*)y + (size_t)row * ys, D, lane, amax);
   sat_report<OUT>(amax, sat);
 }
 
@@ -99,63 +66,22 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
   float4 v[MAXV];
   float amax = 0.f;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const float* g = pass ? g1 : g0;
-    const float* b = pass ? b1 : b0;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int d = (i * 64 + lane) * 4;
-      if (d < D) {
-        if (pass == 0) {
-          if (cls != nullptr && row % ntok == 0) {  // CLS row: class_embedding + position_embedding[0] (HF :212-217)
-            const float4 c = *(const float4*)(cls + d), p = *(const float4*)(pos0 + d);
-            v[i] = make_float4(c.x + p.x, c.y + p.y, c.z + p.z, c.w + p.w);
-          } else {
-            v[i] = *(const float4*)(xr + d);
-          }
-        }
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      }
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int d = (i * 64 + lane) * 4;
-      if (d < D) {
-        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-      }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int d = (i * 64 + lane) * 4;
-      if (d < D) {
-        const float4 gv = *(const float4*)(g + d);
-        const float4 bv = *(const float4*)(b + d);
-        float4 o;
-        o.x = v[i].x * rstd * gv.x + bv.x;
-        o.y = v[i].y * rstd * gv.y + bv.y;
-        o.z = v[i].z * rstd * gv.z + bv.z;
-        o.w = v[i].w * rstd * gv.w + bv.w;
-        if (pass == 0) {
-          *(float4*)(xr + d) = o;
-          v[i] = o;
-        } else if constexpr (OUT != MCM_PREC_F32) {
-          uint2 pk;
-          pk.x = pack2<OUT>(o.x, o.y);
-          pk.y = pack2<OUT>(o.z, o.w);
-          sat_track<OUT>(amax, o.x, o.y);
-          sat_track<OUT>(amax, o.z, o.w);
-          *(uint2*)((uint16_t*)y + (size_t)row * D + d) = pk;
-        } else {
-          *(float4*)((float*)y + (size_t)row * D + d) = o;
-        }
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = (i * 64 + lane) * 4;
+    if (d < D) {
+      if (cls != nullptr && row % ntok == 0) {  // CLS row: class_embedding + position_embedding[0] (HF :212-217)
+        const float4 c = *(const float4*)(cls + d), p = *(const float4*)(pos0 + d);
+        v[i] = make_float4(c.x + p.x, c.y + p.y, c.z + p.z, c.w + p.w);
+      } else {
+        v[i] = *(const float4*)(xr + d);
       }
     }
   }
+  ln_row_apply(v, g0, b0, D, eps, lane);       // pre_layrnorm: the residual stream, written back in fp32
+  ln_row_store<MCM_PREC_F32>(v, xr, D, lane, amax);
+  ln_row_apply(v, g1, b1, D, eps, lane);       // layer 0's layer_norm1 of exactly those fp32 values
+  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT>(v, (uint16_t*)y + (size_t)row * D, D, lane, amax);
+  else ln_row_store<OUT>(v, (float*)y + (size_t)row * D, D, lane, amax);
   sat_report<OUT>(amax, sat);
 }
 

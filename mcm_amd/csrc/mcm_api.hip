@@ -79,6 +79,10 @@ struct mcm_handle {
   unsigned int* sat_dev = nullptr;  // sticky fp16 saturation counter (common.hpp sat_report)
   bool sat_on = true;
   float2 *fold_part = nullptr, *fold_rs = nullptr;  // LayerNorm fold: row moments [v_width / 64][rows], (rstd, mean rstd) [rows]
+  // LayerNorm in the tail of the residual GEMMs (gemm.hip): per-XCD regions of counters, all zero between launches;
+  // nullptr when the device did not pass the workgroup -> XCD check (xcd_round_robin) or the widths do not qualify
+  unsigned int* ln_state = nullptr;
+  int ln_rs = 0, ln_cap8 = 0;
   std::string err;
 };
 
@@ -242,6 +246,45 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
                           h->sat_on ? h->sat_dev : nullptr);
 }
 
+// LayerNorm in the tail of the residual GEMMs (gemm.hip "LayerNorm in the tail"): 1 = the LayerNorm that follows a
+// whole-batch out-proj / fc2 of a 16-bit tower is computed by that GEMM's own waves; 0 = every LayerNorm is a launch
+// An A/B arm: bit-identical, equal at ViT-B/16 batch 512, +0.5 % at ViT-L/14, -1 ... -7 % on smaller problems
+#ifdef MCM_HARNESS
+int g_ln_tail = 0;  // mcm_debug_ln_tail
+#elif defined(MCM_LN_TAIL)  // A/B build of the shipped library with the tail on
+constexpr int g_ln_tail = 1;
+#else
+constexpr int g_ln_tail = 0;
+#endif
+// The tail's coherence argument needs every workgroup with the same blockIdx & 7 on the same XCD (one L2).  That is
+// how the dispatcher deals workgroups in the default (SPX) mode; it is checked on the device, once per handle, with
+// the grid the persistent kernels use: XCC_ID of every workgroup.  Anything else (another partition mode, a masked
+// lease) and the tail is simply not used.
+__global__ void xcc_probe_kernel(unsigned int* out) {
+  if (threadIdx.x == 0) {
+    unsigned int id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    out[blockIdx.x] = id & 0xfu;
+  }
+}
+bool xcd_round_robin(mcm_handle* h, int grid) {
+  if (grid < 8 || grid % 8 || grid > 1024) return false;
+  unsigned int* dev = nullptr;
+  if (hipMalloc((void**)&dev, (size_t)grid * sizeof(unsigned int)) != hipSuccess) return false;
+  std::vector<unsigned int> ids((size_t)grid, 0xffu);
+  bool ok = true;
+  for (int rep = 0; rep < 3 && ok; ++rep) {  // (the mapping must not depend on what ran before)
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(grid), dim3(512), 0, 0, dev);
+    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+         hipMemcpy(ids.data(), dev, (size_t)grid * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess;
+    for (int b = 0; ok && b < grid; ++b) ok = ids[(size_t)b] == ids[(size_t)(b & 7)];
+    for (int i = 0; ok && i < 8; ++i)
+      for (int j = 0; ok && j < i; ++j) ok = ids[(size_t)i] != ids[(size_t)j];
+  }
+  (void)hipFree(dev);
+  return ok;
+}
+
 // CLIPEncoderLayer.forward ×layers on x [nseq*L, D] (fp32, in place).
 // pooled_row0: the caller consumes only row 0 of every sequence (CLS pooling, HF
 // modeling_clip.py:649-651).  The last layer then computes K/V for all tokens but Q, the
@@ -276,11 +319,20 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     return e == hipSuccess ? fold_stats(h, s, Mp, D) : e;
   };
   bool ln1_folded = false;  // h->ln holds gamma1 o x and h->fold_rs the row statistics of this layer's layer_norm1
+  // LayerNorm in the tail: the residual GEMMs of whole-batch layers also produce the LayerNorm that follows them
+  const bool tail_ok = g_ln_tail && !can_fold && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
+                       gemm_ln_tail_ok(P, Mp, D);
+  auto with_tail = [&](GemmArgs& g, const float* gamma, const float* beta) {
+    g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
+    g.ln_state = h->ln_state; g.ln_rs = h->ln_rs; g.ln_cap8 = h->ln_cap8;
+  };
+  bool ln1_by_tail = false;  // h->ln already holds this layer's layer_norm1 (written by the previous layer's fc2)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
-    if (!(l == 0 && ln1_of_layer0_done) && !ln1_folded)
+    if (!(l == 0 && ln1_of_layer0_done) && !ln1_folded && !ln1_by_tail)
       HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+    ln1_by_tail = false;
     if (!cls) {
       const int nch = (g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
       for (int c = 0; c < nch; ++c) {
@@ -317,6 +369,9 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
     if (fold2) {
       HIP_TRY(h, produce(o, w.ln2w));
+    } else if (tail_ok && !cls) {
+      with_tail(o, w.ln2w, w.ln2b);  // layer_norm2 by the out-proj kernel's idle waves
+      HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
     } else {
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
       if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
@@ -332,8 +387,15 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
     f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
-    if (ln1_folded) HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
-    else HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
+    if (ln1_folded) {
+      HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
+    } else {
+      if (tail_ok && !cls && l + 1 < t.layers) {  // the next layer's layer_norm1 (all rows, also in front of a row-0-only layer)
+        with_tail(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b);
+        ln1_by_tail = true;
+      }
+      HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
+    }
   }
   return MCM_OK;
 }
@@ -494,6 +556,15 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc && c.precision != MCM_PREC_F32 && c.v_width % 256 == 0 && c.v_mlp % 256 == 0) {
     rc = dev_alloc(h, (void**)&h->fold_part, (size_t)(c.v_width / 64) * mv * sizeof(float2));
     if (!rc) rc = dev_alloc(h, (void**)&h->fold_rs, (size_t)mv * sizeof(float2));
+  }
+#endif
+#if defined(MCM_HARNESS) || defined(MCM_LN_TAIL)  // LayerNorm in the tail (A/B arm): its counters, if the device qualifies
+  if (!rc && c.precision != MCM_PREC_F32 && (c.v_width == 768 || c.v_width == 1024) && xcd_round_robin(h, gemm_persistent_grid())) {
+    h->ln_cap8 = (int)((mv / 256 + 7) / 8);
+    h->ln_rs = (h->ln_cap8 + 3 + 63) / 64 * 64;  // words per XCD region: whole 256-B blocks, no line shared between XCDs
+    const size_t bytes = (size_t)8 * h->ln_rs * sizeof(unsigned int);
+    rc = dev_alloc(h, (void**)&h->ln_state, bytes);
+    if (!rc && hipMemset(h->ln_state, 0, bytes) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset LayerNorm-tail state");
   }
 #endif
   if (!rc) rc = dev_alloc(h, (void**)&h->sat_dev, 16);
@@ -931,6 +1002,22 @@ int mcm_debug_ln_fold(int32_t on) {  // 0 (shipped behaviour): every LayerNorm a
   return MCM_OK;
 }
 
+int mcm_debug_ln_tail(int32_t on) {  // 1: LayerNorm in the tail of the residual GEMMs; 0 (shipped behaviour): LayerNorm launches
+  g_ln_tail = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host) {  // tickets that gave up waiting (0 in a correct run)
+  if (!h || !count_host) return MCM_EINVAL;
+  *count_host = 0;
+  if (!h->ln_state) return MCM_OK;
+  HIP_TRY(h, hipDeviceSynchronize());
+  for (int x = 0; x < 8; ++x) {
+    unsigned int v = 0;
+    HIP_TRY(h, hipMemcpy(&v, h->ln_state + (size_t)x * h->ln_rs + h->ln_cap8 + 2, sizeof(v), hipMemcpyDeviceToHost));
+    *count_host += v;
+  }
+  return MCM_OK;
+}
 int mcm_debug_qkv_head_major(int32_t on) {
   g_qkv_head_major = on ? 1 : 0;
   return MCM_OK;

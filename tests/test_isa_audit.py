@@ -32,12 +32,12 @@ def gemm_isa(tmp_path_factory):
 
 @pytest.fixture(scope="module")
 def gemm_isa_harness(tmp_path_factory):
-    """The shipped flags plus -DMCM_LN_FOLD: the build the LayerNorm-fold arm was timed in (in the -DMCM_HARNESS build the
+    """The shipped flags plus -DMCM_LN_FOLD -DMCM_LN_TAIL: the build the LayerNorm-fold / LayerNorm-tail arms were timed in (in the -DMCM_HARNESS build the
     ablation branches around every epilogue store cost the fp16 consumer form four spilled registers)."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("isa_h")
-    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMCM_LN_FOLD", "-I",
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DMCM_LN_FOLD", "-DMCM_LN_TAIL", "-I",
            os.path.join(ROOT, "mcm_amd", "csrc"), "-c", os.path.join(ROOT, "mcm_amd", "csrc", "gemm.hip"), "-o",
            str(out / "gemm.o"), "-save-temps=obj"]
     subprocess.run(cmd, check=True, cwd=str(out), capture_output=True, timeout=600)
@@ -47,8 +47,8 @@ def gemm_isa_harness(tmp_path_factory):
 
 
 def _kernel(isa, prec, epi, fold=0):
-    """gemm_pp_kernel<PREC, EPI, BAL = false, STAG = false, FOLD = fold>"""
-    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dELb0ELb0ELb%dEEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold), isa,
+    """gemm_pp_kernel<PREC, EPI, BAL = false, STAG = false, FOLD = fold, LNT = false>"""
+    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dELb0ELb0ELb%dELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold), isa,
                   re.S | re.M)
     assert m, "gemm_pp_kernel<%d,%d,fold=%d> not found" % (prec, epi, fold)
     return m.group(0)
@@ -95,3 +95,25 @@ def test_pingpong_ln_fold_producer_has_no_scratch_and_only_hand_counted_waits(ge
     assert waits == sorted([0, 0] + 2 * [4, 12, 12, 12, 13, 12, 12, 8]), waits
     assert len(re.findall(r"v_mfma_f32_16x16x32", body)) == 64
     assert not re.search(r"v_fma_f32|v_fmac_f32|v_pk_fma_f32", body)  # the moments are explicitly rounded operations
+
+
+@pytest.mark.parametrize("prec", [0, 2], ids=["bf16", "fp16"])
+def test_pingpong_residual_kernel_with_the_layernorm_tail_keeps_the_k_loop_clean(gemm_isa_harness, prec):
+    """gemm_pp_kernel<PREC, EPI_RESID, ..., LNT = true> (LayerNorm in the tail): the publication of a finished tile adds a
+    uniform branch and one asm atomic behind the wait that ends a compute phase, the tail itself sits behind the loop —
+    the K loop must look exactly like the plain residual kernel's: no scratch, 64 MFMAs, no wait between the LDS-DMA
+    issues and the MFMAs, and up to the last MFMA only the hand-written waits."""
+    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi2ELb0ELb0ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
+                  re.S | re.M)
+    assert m, "LNT kernel not found"
+    lines = m.group(0).splitlines()
+    assert not any("scratch_" in l for l in lines)
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32" in l]
+    dma = [i for i, l in enumerate(lines) if "global_load_lds_dwordx4" in l]
+    assert len(mfma) == 64
+    between = lines[max(i for i in dma if i < mfma[0]):mfma[0]]
+    assert not any("s_waitcnt vmcnt" in l for l in between)
+    plain = _kernel(gemm_isa_harness, prec, 2).splitlines()
+    plain_mfma = [i for i, l in enumerate(plain) if "v_mfma_f32_16x16x32" in l]
+    waits = lambda ls, end: [l.strip() for l in ls[:end] if "s_waitcnt vmcnt" in l]  # noqa: E731
+    assert waits(lines, mfma[-1]) == waits(plain, plain_mfma[-1])
