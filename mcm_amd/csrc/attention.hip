@@ -285,9 +285,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   // qkv layout.  Row-major (hm = 0): [rows][3 D], a head's q / k / v are 128-B segments of 4.6-KB rows.  Head-major
   // (hm = rows of the array, what the QKV projection writes in the model): [3 heads][hm][64] — this workgroup's Q, K
   // and V are three runs of L x 128 consecutive bytes.  rs: row stride, KO / VO: from a q row to the k / v row (elements)
-  const size_t rs = hm ? (size_t)64 : (size_t)3 * D;
-  const size_t KO = hm ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
-  const uint16_t* base = hm ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
+  const size_t rs = MCM_HM(hm) ? (size_t)64 : (size_t)3 * D;
+  const size_t KO = MCM_HM(hm) ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
+  const uint16_t* base = MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
 
   // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
@@ -649,6 +649,9 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
   if (hm && (prec == MCM_PREC_F32 || (int64_t)hm < (int64_t)nseq * L)) return hipErrorInvalidValue;
+#ifndef MCM_HARNESS
+  if (hm) return hipErrorInvalidValue;  // head-major qkv: harness library only
+#endif
 #ifdef MCM_HARNESS
   if (hm && g_attn_variant == 0) return hipErrorInvalidValue;  // the round-1 kernel reads row-major qkv only
 #endif

@@ -271,7 +271,7 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
       }
     };
     // head-major outputs (a.hm): the wave's 64 columns are one head's block, whose rows are 128 B apart
-    const int ldo_e = a.hm ? 64 : a.ldo;
+    const int ldo_e = MCM_HM(a.hm) ? 64 : a.ldo;
     const int lane_off = rrow * ldo_e + c8 * 8;  // elements
     // INTERIOR: scalar base + one 32-bit lane offset; the base walks down the tile 8 rows per store (two scalar adds
     // per store instead of a 64-bit multiply-add chain and a vector 64-bit add)
@@ -2235,6 +2235,9 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
     return hipErrorInvalidValue;
   // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
   if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
+#ifndef MCM_HARNESS
+  if (a.hm) return hipErrorInvalidValue;  // the head-major store path exists in the harness library only
+#endif
 #ifndef MCM_NO_SLIVER_SPLIT
   // Sliver round.  The persistent kernel walks T = row tiles x N tiles on G workgroups; when T is a little more than
   // a whole number of rounds, the last round keeps a few CUs busy for a full tile time while the rest of the chip

@@ -1,7 +1,8 @@
 // ln_row.hpp — the arithmetic of one LayerNorm row on one 64-lane wave, shared by every place that normalises a
 // row: layernorm_kernel / layernorm_pre_kernel (layernorm.hip) and the LayerNorm tail of the residual ping-pong GEMM
-// (gemm.hip, "LayerNorm in the tail").  One definition with floating-point contraction switched off, so the same row
-// gives the same bits whichever kernel — whichever batch size — it went through.  The steps are separate functions so
+// (gemm.hip, "LayerNorm in the tail").  One definition with floating-point contraction switched off and the fused
+// multiply-adds written out (the forms hipcc contracted the round-1 LayerNorm kernel to), so the same row gives the same
+// bits whichever kernel — whichever batch size — it went through.  The steps are separate functions so
 // that the GEMM tail can run them on 8 rows side by side (8 independent cross-lane reductions in flight instead of one
 // latency chain); per row the operations and their order are the same.
 //
@@ -41,7 +42,7 @@ __device__ __forceinline__ float ln_center_sq(float4 (&v)[LN_MAXV], float mean, 
   for (int i = 0; i < LN_MAXV; ++i)
     if (ln_has<NVU>(i, lane, D)) {
       v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      q += __builtin_fmaf(v[i].x, v[i].x, v[i].y * v[i].y) + __builtin_fmaf(v[i].z, v[i].z, v[i].w * v[i].w);
     }
   return q;
 }
@@ -59,10 +60,10 @@ __device__ __forceinline__ void ln_scale(float4 (&v)[LN_MAXV], float rstd, const
     if (ln_has<NVU>(i, lane, D)) {
       const float4 gv = *(const float4*)(g + d);
       const float4 bv = *(const float4*)(b + d);
-      v[i].x = v[i].x * rstd * gv.x + bv.x;
-      v[i].y = v[i].y * rstd * gv.y + bv.y;
-      v[i].z = v[i].z * rstd * gv.z + bv.z;
-      v[i].w = v[i].w * rstd * gv.w + bv.w;
+      v[i].x = __builtin_fmaf(v[i].x * rstd, gv.x, bv.x);
+      v[i].y = __builtin_fmaf(v[i].y * rstd, gv.y, bv.y);
+      v[i].z = __builtin_fmaf(v[i].z * rstd, gv.z, bv.z);
+      v[i].w = __builtin_fmaf(v[i].w * rstd, gv.w, bv.w);
     }
   }
 }
