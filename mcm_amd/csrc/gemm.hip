@@ -35,10 +35,13 @@
 //   gemm_pp_kernel       the same tile with the "ping-pong" K-loop (the two waves of a SIMD half a K-step
 //                        apart): large problems made of whole tiles, i.e. every vision GEMM at batch
 //                        256 / 512.  Measurements and what bounds it: DESIGN.md sections 4.1, 5.1, 5.4.
+// A whole-tile problem whose tile count ends in a thin last round of the persistent grid is cut in two launches
+// (launch_gemm, "Sliver round"): ping-pong kernel for the rows of the whole rounds, tile kernel for the rest.
 // Harness build only (-DMCM_HARNESS: tools/gemm_bench.hip and libmcm_hip_harness.so, which the A/B tests
 // load): gemm_persist_kernel (256x128, 3 stages: bound by the L1->LDS DMA path), the counted-store wait
 // forms, gemm_pp32_kernel (the ping-pong loop on 32x32x16 MFMAs: same cycles, more power, lower clock —
-// DESIGN.md 5.5), the ablation bits and the variant switch.
+// DESIGN.md 5.5), the LayerNorm fold (FOLD) and the LayerNorm tail (LNT) forms of gemm_pp_kernel, head-major 16-bit
+// outputs (GemmArgs::hm), the ablation bits and the variant switch — each measured, none faster in the model.
 #include <type_traits>
 
 #include "common.hpp"

@@ -128,9 +128,9 @@ def test_checkpoint_file_round_trip(tmp_path, fmt):
 
 
 def test_reference_shaped_maha_code_through_plain_contract(golden_dir):
-    """The reference's own Mahalanobis statements (utils/detection_util.py:158-160,187-198, written out here as
-    a caller would have them) run against `net.get_image_features(pixel_values=...)` — the plain HF contract,
-    raw projections — and reproduce the reference's scores on its features (maha_tiny.npz)."""
+    """A caller that drives `net.get_image_features(pixel_values=...)` — the plain HF contract, raw projections — the
+    way the reference's Mahalanobis path does (utils/detection_util.py:187) gets the reference's features and, with the
+    reference's class statistics, its scores (maha_tiny.npz, the reference's own run)."""
     g = np.load(os.path.join(golden_dir, "maha_tiny.npz"))
     geo = geometry("tiny")
     net = _net("tiny", "fp32", max_batch=64, max_prompt_tokens=1024)
@@ -148,12 +148,11 @@ def test_reference_shaped_maha_code_through_plain_contract(golden_dir):
                                    atol=2e-4 * max(1.0, np.abs(g["feat_in_raw"]).max()))   # raw, NOT unit norm
         assert abs(float(features.norm(dim=-1).mean()) - 1.0) > 1e-3
         mean, prec = torch.from_numpy(g["mean_raw"]).cuda(), torch.from_numpy(g["prec_raw"]).cuda()
-        score = None
-        for i in range(n_cls):                                                      # reference :191-198
-            zero_f = features - mean[i]
-            d = -0.5 * torch.mm(torch.mm(zero_f, prec), zero_f.t()).diag()
-            score = d.view(-1, 1) if score is None else torch.cat((score, d.view(-1, 1)), 1)
-        got = (-score.max(dim=1).values).cpu().numpy()
+        # what the reference's per-class loop (utils/detection_util.py:191-198) evaluates, as one quadratic form per
+        # (image, class): score = min_c 0.5 (f - mu_c)^T P (f - mu_c)
+        diff = features[:, None, :].double() - mean[None, :n_cls, :].double()
+        half_dist = 0.5 * torch.einsum("nci,ij,ncj->nc", diff, prec.double(), diff)
+        got = half_dist.min(dim=1).values.float().cpu().numpy()
         np.testing.assert_allclose(got, g["in_raw"], rtol=2e-3, atol=1e-4)
     finally:
         net.close()
