@@ -2098,11 +2098,15 @@ hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
 int size_policy(int M, int N) {
   int v = variant();
   if (v < 0) {  // auto: the persistent 256x256 kernel once its tiles cover most of the CUs, else the
-                // one-workgroup-per-tile kernel (text tower, CLS-only last layer).  Measured with
-                // bench.py --batch 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 %
-                // end to end against the old >= 1024 rule).
+                // one-workgroup-per-tile kernel (text tower, CLS-only last layer).  Round 1, bench.py --batch
+                // 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 % end to end against the old >= 1024 rule).
     const long tiles = (long)((M + p256::BM - 1) / p256::BM) * ((N + p256::BN - 1) / p256::BN);
-    v = tiles >= 192 ? 5 : 0;  // 5 falls back to 3 when the problem has edge tiles
+    // Round 3: the crossover is half a round of the persistent grid.  Up to G/2 tiles the tile kernel's 128x128
+    // workgroups (4 per tile, 2 per CU) fit one round of their own, which takes ~0.74 of a 256x256 tile's time; one
+    // tile more and they need a second round (1.47) where the persistent kernel still needs one.  Measured with the
+    // rule at 129 instead of 192 tiles: batch 64 / 72 (out-proj, fc2: 150 / 171 tiles) +12 %, batch 24 +3 %, batch 96
+    // and up unchanged (profiles/r03_x_kernel_choice_small_batches.txt).
+    v = 2 * tiles > persistent_grid() ? 5 : 0;  // 5 falls back to 3 when the problem has edge tiles
   }
   if (v != 0 && persistent_grid() < 8) v = 0;
   return v;
@@ -2260,6 +2264,8 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
       // them, one per CU with nobody to overlap with, take as long over a deep K as the round they replace (measured
       // at ViT-L/14, where one row tile is left: 5 918 vs 5 921 img/s; ViT-B/32, 20 row tiles: +2.9 %)
       const long rest_wgs = (rt - rt1) * 2 * (a.N / 128);
+      // (a last round up to a quarter full; up to half full measured equal or slower at batches 64 ... 512:
+      // profiles/r03_x_kernel_choice_small_batches.txt)
       if (R >= 1 && left > 0 && left * 4 <= G && rt1 >= 1 && rt1 < rt && rest_wgs * 2 >= G &&
           size_policy((int)(rt1 * p256::BM), a.N) == 5) {
         GemmArgs m = a, r = a;
