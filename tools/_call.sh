@@ -1,12 +1,7 @@
 #!/bin/bash
-# scratch driver (round 3, call 54): sliver split up to a quarter (shipped) vs half a round left over, batches 64 ... 512
-mkdir -p gpurun_out/r3c54
-O=$PWD/gpurun_out/r3c54
-for b in 64 128 192 256 320 384 448 512; do for lib in libmcm_hip.so libmcm_hip_s2.so; do
-  timeout 600 python tools/bench_with_lib.py mcm_amd/$lib --batch $b --no-drift --cpu-seconds 0 --sustain-seconds 0 --steps 40 > $O/b.json 2> $O/b.err || tail -3 $O/b.err
-  python - <<PY
-import json
-d=json.load(open("$O/b.json"))
-print("batch $b $lib", round(d["value"]), round(d["ms_per_step"],3), d["kernel_ms_per_step"]["gemm"])
-PY
-done; done 2>&1 | tee $O/sweep.txt
+# scratch driver (round 3, call 55): new kernel-choice rule — the tests whose shapes cross it
+mkdir -p gpurun_out/r3c55
+O=$PWD/gpurun_out/r3c55
+( time timeout 2400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_round2.py tests/test_gpu_configs.py tests/test_gpu_ln_fold.py tests/test_gpu_ln_tail.py tests/test_gpu_qkv_layout.py tests/test_gpu_c_abi.py -m gpu -x -q ) > $O/pytest.txt 2>&1
+grep -E "passed|failed|^E |^real" $O/pytest.txt | head -5
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
