@@ -1,7 +1,10 @@
 #!/bin/bash
-# scratch driver (round 3, call 55): new kernel-choice rule — the tests whose shapes cross it
-mkdir -p gpurun_out/r3c55
-O=$PWD/gpurun_out/r3c55
-( time timeout 2400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_round2.py tests/test_gpu_configs.py tests/test_gpu_ln_fold.py tests/test_gpu_ln_tail.py tests/test_gpu_qkv_layout.py tests/test_gpu_c_abi.py -m gpu -x -q ) > $O/pytest.txt 2>&1
-grep -E "passed|failed|^E |^real" $O/pytest.txt | head -5
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+# scratch driver (round 3, call 57): bench.py --gpus 2 on the one GPU of the box (two ranks share it: gloo fallback) — the N > 1 path of the final tree
+mkdir -p gpurun_out/r3c57
+O=$PWD/gpurun_out/r3c57
+timeout 240 python bench.py --gpus 2 --steps 6 --warmup 2 --sustain-seconds 0 > $O/bench2.json 2> $O/bench2.err; echo rc=$?; tail -2 $O/bench2.err
+python - <<PY
+import json
+d=json.load(open("$O/bench2.json"))
+print(d["n_gpus"], round(d["value"]), d["ms_per_step"], d.get("collective"), d["config"]["parallelism"])
+PY
