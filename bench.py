@@ -266,6 +266,9 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
     ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
     ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
+    ap.add_argument("--idle-ms", type=float, default=-1.0,
+                    help="measurement hook (DESIGN.md 5.5, the energy reading of the step): >= 0 = synchronise after every "
+                         "timed step and leave the device idle for this long; the line is then NOT a throughput figure")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
@@ -343,6 +346,9 @@ def main():
         if n_prof:
             net.profile(i % pe == 0)  # a host-side flag: events are recorded on profiled steps only
         net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[i])
+        if args.idle_ms >= 0:  # measurement hook: an idle device between steps (kernel times come from the HIP events)
+            torch.cuda.synchronize()
+            time.sleep(args.idle_ms * 1e-3)
     if ws > 1:  # the path's only exchange: per-dataset all-gather of the score shards
         full = mdist.all_gather_scores(scores.reshape(-1), ws * args.steps * B)
         assert full.numel() == ws * args.steps * B
@@ -406,6 +412,9 @@ def main():
             line["harness_ln_fold"] = args.ln_fold
         if args.ln_tail >= 0:
             line["harness_ln_tail"] = args.ln_tail
+        if args.idle_ms >= 0:
+            line["idle_ms_between_steps"] = args.idle_ms
+            line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"
         if args.gemm_variant >= 0:
             line["harness"] = f"libmcm_hip_harness.so, GEMM variant {args.gemm_variant} forced (A/B run, not the shipped policy)"
         if ws > 1:

@@ -1,10 +1,12 @@
 #!/bin/bash
-# scratch driver (round 3, call 57): bench.py --gpus 2 on the one GPU of the box (two ranks share it: gloo fallback) — the N > 1 path of the final tree
-mkdir -p gpurun_out/r3c57
-O=$PWD/gpurun_out/r3c57
-timeout 240 python bench.py --gpus 2 --steps 6 --warmup 2 --sustain-seconds 0 > $O/bench2.json 2> $O/bench2.err; echo rc=$?; tail -2 $O/bench2.err
-python - <<PY
+# scratch driver (round 3, call 58): kernel time per step with the device left idle between steps (the energy reading)
+mkdir -p gpurun_out/r3c58
+O=$PWD/gpurun_out/r3c58
+for idle in -1 0 5 20 60; do
+  timeout 200 python bench.py --no-drift --cpu-seconds 0 --sustain-seconds 0 --steps 48 --warmup 6 --profile-every 1 --idle-ms $idle > $O/b.json 2> $O/b.err || tail -3 $O/b.err
+  python - <<PY
 import json
-d=json.load(open("$O/bench2.json"))
-print(d["n_gpus"], round(d["value"]), d["ms_per_step"], d.get("collective"), d["config"]["parallelism"])
+d=json.load(open("$O/b.json"))
+print("idle_ms $idle", d["kernel_ms_per_step"], "sum", round(sum(d["kernel_ms_per_step"].values()),3))
 PY
+done 2>&1 | tee $O/idle.txt
