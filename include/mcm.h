@@ -293,7 +293,9 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
  * 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3),
  * 6 = the ping-pong loop on 32x32x16 MFMAs (16-bit modes; others run as 5),
  * 7 = ping-pong with balanced DMA (8 + 8 pieces per step), 8 = ping-pong with staggered epilogues (both: whole tiles,
- *     others run as 5).
+ *     others run as 5),
+ * 11 = the shipped size policy with a 64x128 tile kernel wherever the 128x128 one would get fewer workgroups than
+ *     two per CU (small batches).
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
 /* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel, 2 ... 9 = priority / wave-count /

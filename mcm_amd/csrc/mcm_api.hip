@@ -1029,7 +1029,7 @@ int mcm_debug_qkv_chunks(int32_t n) {
 }
 
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || variant > 8) return MCM_EINVAL;
+  if (variant < -1 || (variant > 8 && variant != 11)) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }

@@ -285,6 +285,39 @@ def test_linear_sliver_split_bitwise(tiny_net, harness_net, M, N, K, epi, prec):
         harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("M,N,K,epi", [(3152, 768, 768, 2), (3152, 2304, 768, 0), (3152, 768, 3072, 2), (197, 768, 768, 2),
+                                       (1000, 3072, 768, 1), (77, 512, 512, 0)])
+def test_linear_tile64_bitwise(harness_net, M, N, K, epi, prec):
+    """Harness variant 11: the 64x128 tile kernel (small batches: twice the workgroups of the 128x128 kernel) against the
+    128x128 tile kernel, bit for bit, ragged row counts included."""
+    dt = DTYPE[prec]
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
+    x = torch.randn((M, K), generator=g, device="cuda").to(dt)
+    w = (torch.randn((N, K), generator=g, device="cuda") * K ** -0.5).to(dt)
+    bias = 0.1 * torch.randn(N, generator=g, device="cuda")
+    resid0 = torch.randn((M, N), generator=g, device="cuda") if epi == 2 else None
+    net = harness_net
+
+    def run(variant):
+        assert net._lib.mcm_debug_gemm_variant(variant) == 0
+        y = torch.zeros((M, N), device="cuda", dtype=dt)
+        rd = resid0.clone() if epi == 2 else y
+        rc = net._lib.mcm_op_linear(net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(rd), M, N, K, epi, None)
+        assert rc == 0, net._lib.mcm_last_error(net._h)
+        torch.cuda.synchronize()
+        return rd if epi == 2 else y
+
+    try:
+        ref = run(0)
+        got = run(11)
+        assert torch.isfinite(ref.float()).all()
+        view = torch.int32 if ref.element_size() == 4 else torch.int16
+        assert torch.equal(got.view(view), ref.view(view))
+    finally:
+        net._lib.mcm_debug_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("N,K,epi", [(3072, 1024, 0), (4096, 1024, 1), (1024, 4096, 2), (1024, 1024, 2)])
 def test_linear_l14_shapes_pingpong_bitwise(tiny_net, harness_net, N, K, epi):
     """BASELINE config 4 (ViT-L/14, batch 256: M = 256 * 257 rows, K = 1024 / 4096): the ping-pong kernel against
