@@ -58,7 +58,7 @@ def test_folded_tower_vs_unfolded_and_fp32(prec, affine):
         ref.close()
     net = NativeCLIP(geo, sd, device=0, precision=prec, max_batch=128, max_prompt_tokens=77, harness=True)
     try:
-        on = _features(net, px, fold=True)     # 128 images: 99 M tiles x 3 >= 192 -> ping-pong kernel, fused epilogues
+        on = _features(net, px, fold=True)     # 128 images: 99 M tiles x 3 > half a round -> ping-pong kernel, fused epilogues
         off = _features(net, px, fold=False)
         assert not torch.equal(on, off), "the switch did nothing: the fold path was not taken"
         small_on = _features(net, px[:5], fold=True)   # 5 images: tile kernel, fold_rows producer, tile consumer
