@@ -250,6 +250,11 @@ def main():
     ap.add_argument("--prompts", type=int, default=1000, help="K: size of the concept bank")
     ap.add_argument("--ckpt", default="ViT-B/16")
     ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--weights-regime", default="fp16-exact", choices=["fp16-exact", "fp32"],
+                    help="seeded weights rounded to fp16 values (the reference's checkpoints were trained and released in "
+                         "fp16: one fp16 operand per weight is lossless) or as drawn (fp32-valued: the 16-bit arms then run "
+                         "the split-weight GEMMs unless --weight-operands single)")
+    ap.add_argument("--weight-operands", default="auto", choices=["auto", "single", "split"])
     ap.add_argument("--cpu-seconds", type=float, default=150.0,
                     help="hard cap on the CPU baseline's timed part (it stops after 256 images); 0 disables it")
     ap.add_argument("--cpu-batch", type=int, default=64)
@@ -297,11 +302,11 @@ def main():
     dev = torch.device("cuda", local)
 
     geo = geometry(args.ckpt)
-    sd = synth_state_dict(geo, 0)
+    sd = synth_state_dict(geo, 0, args.weights_regime)
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
@@ -401,6 +406,8 @@ def main():
                                    f"fp32 NCHW pixels resident in HBM → [B] scores",
                        "batch_per_gpu": B, "prompts": K, "parallelism": f"image-sharded x{ws}"},
             "gflop_per_image": nominal,
+            "weights": {"regime": args.weights_regime, "gemm_weight_elements_not_operand_numbers": net.weights_inexact,
+                        "split_weight_gemms": net.split_weights},
         }
         if args.qkv_chunks > 1:
             line["harness_qkv_chunks"] = args.qkv_chunks

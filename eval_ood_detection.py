@@ -61,6 +61,12 @@ def process_args(argv=None):
     p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
     p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
                    help="MFMA operand format of the vision tower (fp16 holds AUROC/FPR95 to the fp32 arm at 1e-4; the text tower is always fp32)")
+    p.add_argument("--synthetic-weights", default="fp16-exact", choices=["fp16-exact", "fp32"],
+                   help="without --weights: seeded parameters rounded to fp16 values, as the reference's checkpoints are "
+                        "(default), or as drawn (fp32-valued: the 16-bit arms then run the split-weight GEMMs)")
+    p.add_argument("--weight-operands", default="auto", choices=["auto", "single", "split"],
+                   help="16-bit modes: one operand per GEMM weight, or W_hi + W_lo (exact for fp32-valued weights, twice "
+                        "the GEMM work); auto = split exactly when a weight is not a number of the operand dtype")
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
@@ -148,13 +154,25 @@ def main(argv=None):
     ws_env = int(os.environ.get("WORLD_SIZE", "1"))
     # more ranks than devices (a 1-GPU box running the 2-rank logic check): the ranks share devices and the
     # score all-gather goes over gloo with a host bounce, because RCCL refuses two ranks on one device
-    rank, ws, local = mdist.init_from_env(backend="gloo" if ws_env > ndev else None)
+    # (LOCAL_WORLD_SIZE: the ranks of THIS node — a multi-node torchrun has WORLD_SIZE > device_count() with one GPU per rank)
+    ws_local = int(os.environ.get("LOCAL_WORLD_SIZE", ws_env))
+    rank, ws, local = mdist.init_from_env(backend="gloo" if ws_local > ndev else None)
     log = setup_log(args)
     dev = (local % ndev) if ws > 1 else args.gpu
     torch.cuda.set_device(dev)
     net = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision=args.dtype,
-                      max_batch=args.batch_size)
+                      max_batch=args.batch_size, synthetic_regime=args.synthetic_weights,
+                      weight_operands=args.weight_operands)
     net.eval()
+    if args.dtype != "fp32":
+        log.debug(f"vision GEMM weights: {net.weights_inexact} element(s) are not {args.dtype} numbers -> "
+                  f"{'split-weight GEMMs (W_hi + W_lo, exact for the weight operand)' if net.split_weights else 'one operand per weight'}")
+        if net.weights_inexact and not net.split_weights:
+            log.debug("NOTE: --weight-operands single ROUNDS those weights: measured 1.5 - 2e-4 in AUROC against the fp32 "
+                      "reference in this regime (DESIGN.md section 2.1)")
+    if args.dtype == "bf16":
+        log.debug("NOTE: bf16 operands do not hold the reference's AUROC / FPR95 to 1e-4 (measured 1e-4 ... 1e-3 against "
+                  "HF fp32, DESIGN.md section 2.1); --dtype fp16 (the default) does")
     args.ckpt = HUB_IDS[args.CLIP_ckpt]  # reference utils/train_eval_util.py:19-22 (ckpt_mapping)
     if args.in_dataset == "ImageNet10":
         out_datasets = ["ImageNet20"]

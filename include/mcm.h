@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define MCM_ABI_VERSION 1
+#define MCM_ABI_VERSION 2 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
+                          * arm and mcm_weights_operand_exact; mcm_op_linear_ex / mcm_op_split_weight; the round-2
+                          * mcm_debug_* exports live in libmcm_hip_harness.so only */
 
 /* error codes */
 #define MCM_OK 0
@@ -49,6 +51,22 @@ extern "C" {
 #define MCM_PREC_F32 1    /* exact fp32 MFMA     (v_mfma_f32_16x16x4_f32) — parity arm  */
 #define MCM_PREC_F16 2    /* fp16 MFMA operands  (v_mfma_f32_16x16x32_f16): same rate as bf16,
                            * 10-bit mantissa; BASELINE config 4 (ViT-L/14 fp16)        */
+
+/* element type of a host parameter buffer handed to mcm_set_weight */
+#define MCM_DT_F32 0
+#define MCM_DT_F16 1      /* IEEE binary16 (the dtype OpenAI's CLIP checkpoints carry their Linear / conv weights in) */
+#define MCM_DT_BF16 2
+
+/* How the 16-bit vision modes hold a GEMM weight (cfg.weight_operands).  A weight that IS an fp16 (bf16) number —
+ * the reference's checkpoints: values trained and released in fp16, widened to fp32 by the HF conversion — is
+ * lossless as one 16-bit MFMA operand.  A weight that is not (seeded fp32 parameters, a fine-tuned fp32 checkpoint)
+ * would be ROUNDED, a fixed perturbation of the model that moves AUROC / FPR95 by more than the activation rounding
+ * does.  The split form keeps such a weight as W_hi + W_lo (two 16-bit operands, 22 significand bits), two MFMAs per
+ * fragment pair into the same fp32 accumulator: exact for the weight operand at twice the GEMM work. */
+#define MCM_WEIGHTS_AUTO 0   /* split exactly when some GEMM weight of the vision tower does not round-trip through
+                              * the operand dtype (counted on the device in mcm_finalize_weights)               */
+#define MCM_WEIGHTS_SINGLE 1 /* one rounded operand whatever the values (rounds 1 - 3 behaviour)                 */
+#define MCM_WEIGHTS_SPLIT 2  /* always the split form                                                            */
 
 /* score kinds — the epilogues of utils/detection_util.py:233-248 */
 #define MCM_SCORE_MCM 0       /* -max_k softmax(cos/T)             (:236,:248) */
@@ -84,6 +102,7 @@ typedef struct mcm_config {
   /* workspace bounds */
   int32_t max_batch;        /* images per mcm_encode_image / mcm_score call           */
   int32_t max_prompt_tokens;/* K*S per mcm_encode_text call                           */
+  int32_t weight_operands;  /* MCM_WEIGHTS_*; ignored in MCM_PREC_F32                 */
 } mcm_config;
 
 int mcm_abi_version(void);
@@ -95,13 +114,20 @@ void mcm_destroy(mcm_handle* h);
 const char* mcm_last_error(const mcm_handle* h); /* h may be NULL: last create error */
 
 /* Replaces load_state_dict / from_pretrained (utils/train_eval_util.py:23): copies one
- * fp32 parameter, keyed by its HF state_dict name, host → device.
- * The caller keeps ownership of host_ptr.  `shape`/`ndim` are checked against cfg. */
-int mcm_set_weight(mcm_handle* h, const char* hf_name, const float* host_ptr,
+ * parameter, keyed by its HF state_dict name, host → device.  `dtype` = MCM_DT_*: the element
+ * type of host_ptr (an fp16 / bf16 checkpoint is handed over as it is; the fp32 master the library keeps is the exact
+ * widening).  The caller keeps ownership of host_ptr.  `shape`/`ndim` are checked against cfg. */
+int mcm_set_weight(mcm_handle* h, const char* hf_name, const void* host_ptr, int32_t dtype,
                    const int64_t* shape, int32_t ndim);
-/* Verifies every parameter was set and builds the packed operand copies the kernels
- * read (concatenated QKV, bf16 copies).  Must be called once before any encode. */
+/* Verifies every parameter was set, counts the vision-tower GEMM weights that are not exactly representable in the
+ * operand dtype, chooses the weight form (cfg.weight_operands) and builds the packed operand copies the kernels
+ * read (concatenated QKV, 16-bit or split copies).  Must be called once before any encode. */
 int mcm_finalize_weights(mcm_handle* h);
+/* After mcm_finalize_weights: *inexact_host = number of GEMM-weight elements of the vision tower (q/k/v/out_proj, fc1,
+ * fc2 of every layer and the patch embedding) whose fp32 value is not an fp16 (bf16 in MCM_PREC_BF16) number — 0 for the
+ * reference's checkpoints in fp16, ~99.9 % of the elements for fp32-valued parameters; always 0 in MCM_PREC_F32.
+ * *split_host = 1 when the handle runs the split-weight GEMMs (MCM_WEIGHTS_*), else 0.  Either pointer may be NULL. */
+int mcm_weights_operand_exact(mcm_handle* h, uint64_t* inexact_host, int32_t* split_host);
 
 /* Replaces `net.get_text_features(input_ids, attention_mask).float()` followed by
  * `/= norm` (utils/detection_util.py:229-231; modeling_clip.py:683-715).
@@ -261,6 +287,15 @@ int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, doubl
 int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev,
                   const float* bias_dev, void* y_dev, float* resid_dev, int32_t M, int32_t N,
                   int32_t K, int32_t epi, void* stream);
+/* mcm_op_linear with flags: bit 0 = w_dev is the split image [N, 2K] written by mcm_op_split_weight (16-bit modes;
+ * K % 64 == 0): y = x (W_hi + W_lo)^T, both products in one fp32 accumulator chain. */
+#define MCM_LINEAR_SPLIT_W 1
+int mcm_op_linear_ex(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev,
+                     const float* bias_dev, void* y_dev, float* resid_dev, int32_t M, int32_t N,
+                     int32_t K, int32_t epi, int32_t flags, void* stream);
+/* fp32 w [N,K] (device) → split operand image [N, 2K] in the 16-bit dtype of `prec` (K % 64 == 0). */
+int mcm_op_split_weight(mcm_handle* h, int32_t prec, const float* w_dev, int32_t N, int32_t K,
+                        void* out_dev, void* stream);
 /* LayerNorm over the last dim (modeling_clip.py:370,379,605,608): x fp32 [M,D] →
  * y (operand dtype of `prec`, or fp32 when out_f32 != 0) [M,D]. */
 int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const float* gamma_dev,

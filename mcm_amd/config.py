@@ -11,10 +11,12 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass, asdict, replace
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2                       # include/mcm.h MCM_DT_*
+WEIGHT_OPERANDS = {"auto": 0, "single": 1, "split": 2}  # include/mcm.h MCM_WEIGHTS_*
 
 SCORE_KINDS = {"MCM": 0, "max-logit": 1, "energy": 2, "entropy": 3, "var": 4}
 
@@ -42,6 +44,7 @@ class CConfig(ctypes.Structure):
         ("ln_eps", ctypes.c_float),
         ("max_batch", ctypes.c_int32),
         ("max_prompt_tokens", ctypes.c_int32),
+        ("weight_operands", ctypes.c_int32),
     ]
 
 
@@ -86,11 +89,12 @@ class ClipGeometry:
         return float(L * (8 * d * d + 4 * d * ff))
 
     def to_c(self, *, device: int = 0, precision: int = PREC_BF16, max_batch: int = 512,
-             max_prompt_tokens: int = 1024 * 77) -> CConfig:
+             max_prompt_tokens: int = 1024 * 77, weight_operands: int = 0) -> CConfig:
         d = asdict(self)
         d.pop("name")
         return CConfig(abi_version=ABI_VERSION, device=device, precision=precision,
-                       max_batch=max_batch, max_prompt_tokens=max_prompt_tokens, **d)
+                       max_batch=max_batch, max_prompt_tokens=max_prompt_tokens,
+                       weight_operands=weight_operands, **d)
 
     def hf_configs(self):
         """HF `CLIPConfig` of the same geometry (golden-fixture generation and the

@@ -193,6 +193,11 @@ struct GemmArgs {
   int rev;            // persistent kernel: walk the M tiles from the last to the first
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
   unsigned int* sat;  // fp16 saturation counter of the handle (nullptr: not reported), see sat_report
+  // Split weights (16-bit modes; gemm.hip "Split weights"): 1 = `w` is the [N, K] image cvt_weight_split writes for a
+  // logical [N, K/2] weight — per 128-byte K-step the fp16/bf16 rounding W_hi of the fp32 weight followed by the
+  // rounding W_lo of the remainder — and `x` is the logical [M, K/2] operand (ldx counts its elements): K-steps 2s and
+  // 2s+1 of W meet K-step s of X, so acc = X W_hi^T + X W_lo^T in one fp32 accumulator chain.  0 = plain operands.
+  int ksplit;
   // LayerNorm fold (16-bit modes, ping-pong kernel, gemm.hip "LayerNorm fold"): the LayerNorm between a residual GEMM
   // and the GEMM that consumes its output is not launched; both sides are set or null together per GEMM.
   void* fold_z;           // EPI_RESID (producer): [M, N] operand dtype, z = gamma o (new residual row)
@@ -276,6 +281,12 @@ hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* 
                              int K, int S, int D, hipStream_t s);
 hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, int cols,
                              int cols_pad, hipStream_t s);
+// split form (16-bit modes): dst [rows, 2 * cols_pad], per 64-element K-step hi[64] then lo[64] with
+// hi = round(w), lo = round(w - hi) in the operand dtype (GemmArgs::ksplit); cols_pad % 64 == 0
+hipError_t launch_cvt_weight_split(int prec, const float* src, void* dst, int rows, int cols,
+                                   int cols_pad, hipStream_t s);
+// *count (device, uint64) += elements of src [n] that do not round-trip through the 16-bit operand dtype of `prec`
+hipError_t launch_count_inexact(int prec, const float* src, size_t n, unsigned long long* count, hipStream_t s);
 
 // pooled row → LayerNorm → projection (no bias) → L2 normalise; out fp32 [n, P]
 hipError_t launch_pool_project(const float* x, const int32_t* row_idx, int row_stride, int n,

@@ -142,6 +142,50 @@ __global__ __launch_bounds__(256) void cvt_weight_kernel(const float* __restrict
   }
 }
 
+// Split weights (GemmArgs::ksplit): an fp32 weight as the sum of two 16-bit operands, hi = round(w) and
+// lo = round(w - hi) (w - hi is exact in fp32: hi is w's own leading bits), stored K-step-interleaved — 64 hi
+// elements then the 64 lo elements of the same columns — so that the GEMM kernels meet both with one staging of the
+// X K-step.  hi + lo carries 22 significand bits of w (fp16; lo is subnormal below 2^-14 and then exact to 2^-24
+// absolute): the weight operand is exact for every purpose of a 16-bit-activation GEMM.
+template <int OUT>
+__global__ __launch_bounds__(256) void cvt_weight_split_kernel(const float* __restrict__ src, void* dst,
+                                                               int rows, int cols, int cols_pad) {
+  const size_t total = (size_t)rows * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % cols_pad);
+    const size_t r = i / cols_pad;
+    const float v = c < cols ? src[r * cols + c] : 0.f;
+    const size_t o = r * 2 * cols_pad + (size_t)(c >> 6) * 128 + (c & 63);
+    if constexpr (OUT == MCM_PREC_BF16) {
+      const uint16_t hi = f2bf(v);
+      ((uint16_t*)dst)[o] = hi;
+      ((uint16_t*)dst)[o + 64] = f2bf(v - bf2f(hi));
+    } else {
+      const _Float16 hi = (_Float16)v;
+      ((_Float16*)dst)[o] = hi;
+      ((_Float16*)dst)[o + 64] = (_Float16)(v - (float)hi);
+    }
+  }
+}
+
+// elements that are not exactly representable in the 16-bit operand dtype (mcm_weights_operand_exact)
+template <int OUT>
+__global__ __launch_bounds__(256) void count_inexact_kernel(const float* __restrict__ src, size_t n,
+                                                            unsigned long long* count) {
+  unsigned int mine = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = src[i];
+    float back;
+    if constexpr (OUT == MCM_PREC_BF16) back = bf2f(f2bf(v));
+    else back = (float)(_Float16)v;
+    mine += (back != v && v == v) ? 1u : 0u;  // (an out-of-range value comes back as inf: counted)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+}
+
 // one workgroup (16 waves) per pooled row; D <= 1024, P <= 1024.  The projection is a chain
 // of dependent load -> fma -> cross-lane reductions per output feature, so it is spread over
 // 16 waves (32 features each at P=512) rather than 4.
@@ -260,6 +304,24 @@ hipError_t launch_cvt_weight(int prec, const float* src, void* dst, int rows, in
   const size_t total = (size_t)rows * cols_pad;
   const dim3 grid(grid_for(total)), block(256);
   MCM_LAUNCH_BY_PREC(cvt_weight_kernel, src, dst, rows, cols, cols_pad);
+  return hipGetLastError();
+}
+
+hipError_t launch_cvt_weight_split(int prec, const float* src, void* dst, int rows, int cols,
+                                   int cols_pad, hipStream_t s) {
+  if (prec == MCM_PREC_F32 || cols_pad % 64) return hipErrorInvalidValue;
+  const size_t total = (size_t)rows * cols_pad;
+  const dim3 grid(grid_for(total)), block(256);
+  if (prec == MCM_PREC_BF16) hipLaunchKernelGGL(cvt_weight_split_kernel<MCM_PREC_BF16>, grid, block, 0, s, src, dst, rows, cols, cols_pad);
+  else hipLaunchKernelGGL(cvt_weight_split_kernel<MCM_PREC_F16>, grid, block, 0, s, src, dst, rows, cols, cols_pad);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_inexact(int prec, const float* src, size_t n, unsigned long long* count, hipStream_t s) {
+  if (prec == MCM_PREC_F32 || n == 0) return hipSuccess;
+  const dim3 grid(grid_for(n)), block(256);
+  if (prec == MCM_PREC_BF16) hipLaunchKernelGGL(count_inexact_kernel<MCM_PREC_BF16>, grid, block, 0, s, src, n, count);
+  else hipLaunchKernelGGL(count_inexact_kernel<MCM_PREC_F16>, grid, block, 0, s, src, n, count);
   return hipGetLastError();
 }
 

@@ -35,6 +35,9 @@
 //   gemm_pp_kernel       the same tile with the "ping-pong" K-loop (the two waves of a SIMD half a K-step
 //                        apart): large problems made of whole tiles, i.e. every vision GEMM at batch
 //                        256 / 512.  Measurements and what bounds it: DESIGN.md sections 4.1, 5.1, 5.4.
+// Split weights (GemmArgs::ksplit, include/mcm.h MCM_WEIGHTS_*): W as W_hi + W_lo, stored K-step-interleaved; every
+// kernel stages the X K-step s / 2 with W K-step s, so acc = X W_hi^T + X W_lo^T runs through the unchanged K loop
+// (twice the steps; X is re-staged from L2 for the lo step: no third LDS stage, no extra registers).
 // A whole-tile problem whose tile count ends in a thin last round of the persistent grid is cut in two launches
 // (launch_gemm, "Sliver round"): ping-pong kernel for the rows of the whole rounds, tile kernel for the rest.
 // Harness build only (-DMCM_HARNESS: tools/gemm_bench.hip and libmcm_hip_harness.so, which the A/B tests
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int blk = i * 4 + wave;
-      glds16(gx[i] + (size_t)kt * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+      glds16(gx[i] + (size_t)(kt >> a.ksplit) * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
       glds16(gw[i] + (size_t)kt * ROWB,
              __builtin_amdgcn_readfirstlane(base + TILE_BYTES + blk * 1024));
     }
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile64_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int blk = i * 4 + wave;
-      if (i < 2) glds16(gx[i] + (size_t)kt * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+      if (i < 2) glds16(gx[i] + (size_t)(kt >> a.ksplit) * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
       glds16(gw[i] + (size_t)kt * ROWB, __builtin_amdgcn_readfirstlane(base + X_BYTES + blk * 1024));
     }
   };
@@ -858,10 +861,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   const uint32_t lds0 = lds_addr(smem);
   auto issue = [&](int st) {
     const uint32_t base = lds0 + st * STAGE_BYTES;
-    const size_t ko = (size_t)kti * ROWB;
+    const size_t ko = (size_t)kti * ROWB, kox = (size_t)(kti >> a.ksplit) * ROWB;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      glds16(gx[p] + ko, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
+      glds16(gx[p] + kox, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
       glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
     }
     if (++kti == nk) {
@@ -1393,13 +1396,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     const size_t ko = (size_t)kti * ROWB;
     if (ABL(1)) return;  // ablation build: no LDS-DMA
     if (i < 4) {
+      const size_t kox = (size_t)(kti >> a.ksplit) * ROWB;  // split weights: X K-step s / 2 meets W' K-steps s (hi), s + 1 (lo)
 #if defined(MCM_HARNESS) && defined(MCM_GEMM_ABLATE)
       if (ABL(32)) {
-        glds16s_nt(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+        glds16s_nt(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
         return;
       }
 #endif
-      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
+      glds16s(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
       const int q = BAL ? grp * 4 + (i - 4) : i - 4;
       glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
@@ -2358,6 +2362,12 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K * es) % ROWB || a.N % 16 || (a.ldx * es) % 16 ||
       a.ldo % 4)
     return hipErrorInvalidValue;
+  // split weights: 16-bit modes, an even number of K-steps (hi, lo pairs); the shipped kernels only
+  if (a.ksplit && (a.ksplit != 1 || prec == MCM_PREC_F32 || ((a.K * es) / ROWB) % 2 || a.fold_z || a.fold_rs || a.ln_y))
+    return hipErrorInvalidValue;
+#ifdef MCM_HARNESS
+  if (a.ksplit && (variant() == 1 || variant() == 2 || variant() == 6)) return hipErrorInvalidValue;
+#endif
   // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
   if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
 #ifndef MCM_HARNESS

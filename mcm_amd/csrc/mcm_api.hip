@@ -16,6 +16,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -42,6 +43,7 @@ struct Tower {
   int D = 0, heads = 0, layers = 0, ff = 0;
   int prec = MCM_PREC_BF16;  // operand mode of this tower's GEMMs / attention / LayerNorm output
   std::vector<LayerW> L;
+  bool split = false;        // GEMM weights held as W_hi + W_lo (GemmArgs::ksplit; include/mcm.h MCM_WEIGHTS_*)
 };
 
 struct EvPair {
@@ -56,7 +58,8 @@ struct mcm_handle {
   std::map<std::string, Param> params;
   bool finalized = false;
   Tower vis, txt;
-  void* wpatch = nullptr;  // [v_width, kpad] operand dtype
+  void* wpatch = nullptr;  // [v_width, kpad] operand dtype ([v_width, 2 kpad] split)
+  uint64_t w_inexact = 0;  // vision GEMM-weight elements that are not operand-dtype numbers (mcm_finalize_weights)
   int kpad = 0, np = 0, ntok = 0;
   // workspace
   float* x = nullptr;
@@ -173,7 +176,7 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
   GemmArgs a = a_in;
   a.rev = next_dir(h) ? 1 : 0;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
-  Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);
+  Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);  // algorithmic FLOP: the logical K, split or not
   // Row padding into the workspace: the ping-pong kernel takes problems made of whole 256-row tiles only, so a
   // dense activation GEMM whose M is not a multiple of 256 is run on M rounded up.  The extra rows exist (every
   // activation buffer is allocated in whole 256-row tiles and zeroed once), every output row depends on its own
@@ -184,6 +187,7 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
     const int64_t mp = ((int64_t)a.M + 255) / 256 * 256;
     if (mp <= h->max_rows) a.M = (int)mp;
   }
+  if (a.ksplit) a.K *= 2;  // the callers describe the logical problem; the split image has 2 K columns per row
   return launch_gemm(prec, epi, a, s);
 }
 hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b,
@@ -303,10 +307,12 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   const int M = nseq * L, D = t.D, P = t.prec;
   const int es = prec_esize(P);
   const int Mp = (int)padded_rows(h, M);
+  const int ks = t.split ? 1 : 0;
+  const size_t wrow = (size_t)D * es * (t.split ? 2 : 1);  // bytes per row of a [*, D] weight image
   // producer form: 1 = fused into the residual GEMM's epilogue (ping-pong kernel), 2 = plain residual GEMM + fold_rows
   // (tile kernel: small batches) - bit-identical; the consumers need a fold epilogue in whichever kernel they take
   const int pkind = gemm_fold_kind(EPI_RESID, Mp, D);
-  const bool can_fold = fold_ok && g_ln_fold && g_qkv_chunks == 1 && h->fold_part && P != MCM_PREC_F32 &&
+  const bool can_fold = fold_ok && g_ln_fold && g_qkv_chunks == 1 && h->fold_part && P != MCM_PREC_F32 && !t.split &&
                         t.L[0].cqkv != nullptr && pkind != 0 && gemm_fold_kind(EPI_STORE, Mp, 3 * D) != 0 &&
                         gemm_fold_kind(EPI_GELU, Mp, t.ff) != 0;
   auto produce = [&](GemmArgs& g, const float* gamma) -> hipError_t {  // residual GEMM + z / moments / statistics
@@ -340,7 +346,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
         GemmArgs a{};
         a.x = (const char*)h->ln + (size_t)r0 * D * es; a.w = w.wqkv; a.bias = w.bqkv;
         a.out = (char*)h->qkv + (size_t)r0 * 3 * D * es;
-        a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D;
+        a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D; a.ksplit = ks;
         if (ln1_folded) { a.bias = w.bqkvf; a.fold_rs = h->fold_rs; a.fold_c = w.cqkv; }
         // whole-batch launches of a 16-bit tower hand q / k / v over head-major (same bytes in h->qkv, other order;
         // the row-0-only layer below and the fp32 towers keep [rows][3 D])
@@ -351,13 +357,13 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
       }
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
-      kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * D * es; kv.bias = w.bqkv + D;
+      kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * wrow; kv.bias = w.bqkv + D;
       kv.out = (char*)h->qkv + (size_t)D * es;
-      kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D;
+      kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D; kv.ksplit = ks;
       HIP_TRY(h, gemm(h, s, P, EPI_STORE, kv));
       GemmArgs q{};   // Q of row 0 of every sequence (row stride L*D in, L*3D out)
       q.x = h->ln; q.w = w.wqkv; q.bias = w.bqkv; q.out = h->qkv;
-      q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D;
+      q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D; q.ksplit = ks;
       HIP_TRY(h, gemm(h, s, P, EPI_STORE, q));
       HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal, 1));
     }
@@ -366,7 +372,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     const bool fold2 = can_fold && !cls;      // layer_norm2 folded into out-proj / fc1
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
-    o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs;
+    o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs; o.ksplit = ks;
     if (fold2) {
       HIP_TRY(h, produce(o, w.ln2w));
     } else if (tail_ok && !cls) {
@@ -379,14 +385,14 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     }
     GemmArgs f1{};
     f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
-    f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff;
+    f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff; f1.ksplit = ks;
     if (fold2) { f1.bias = w.b1f; f1.fold_rs = h->fold_rs; f1.fold_c = w.c1; }
     HIP_TRY(h, gemm(h, s, P, EPI_GELU, f1));
     // the next layer's layer_norm1 folded into fc2 / the next QKV projection (not into the row-0-only layer)
     ln1_folded = fold2 && l + 1 < t.layers && !(pooled_row0 && l + 1 == t.layers - 1 && L > 1);
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
-    f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs;
+    f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs; f2.ksplit = ks;
     if (ln1_folded) {
       HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
     } else {
@@ -401,7 +407,12 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
 }
 
 int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s) {
-  const int prec = t.prec, es = prec_esize(prec), D = t.D, ff = t.ff;
+  const int prec = t.prec, D = t.D, ff = t.ff;
+  const int es = prec_esize(prec) * (t.split ? 2 : 1);  // bytes per logical weight element
+  auto cvt = [&](const float* src, void* dst, int rows, int cols) {
+    return t.split ? launch_cvt_weight_split(prec, src, dst, rows, cols, cols, s)
+                   : launch_cvt_weight(prec, src, dst, rows, cols, cols, s);
+  };
   t.L.resize(t.layers);
   for (int l = 0; l < t.layers; ++l) {
     LayerW& w = t.L[l];
@@ -414,15 +425,14 @@ int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s
     if ((rc = dev_alloc(h, (void**)&w.bqkv, (size_t)3 * D * sizeof(float)))) return rc;
     const char* parts[3] = {"q_proj", "k_proj", "v_proj"};
     for (int p = 0; p < 3; ++p) {
-      HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".self_attn." + parts[p] + ".weight"),
-                                   (char*)w.wqkv + (size_t)p * D * D * es, D, D, D, s));
+      HIP_TRY(h, cvt(W(h, pre + ".self_attn." + parts[p] + ".weight"), (char*)w.wqkv + (size_t)p * D * D * es, D, D));
       HIP_TRY(h, hipMemcpyAsync(w.bqkv + (size_t)p * D, W(h, pre + ".self_attn." + parts[p] + ".bias"),
                                 (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".self_attn.out_proj.weight"), w.wo, D, D, D, s));
-    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc1.weight"), w.w1, ff, D, D, s));
-    HIP_TRY(h, launch_cvt_weight(prec, W(h, pre + ".mlp.fc2.weight"), w.w2, D, ff, ff, s));
-    if (&t == &h->vis && h->fold_part) {  // LayerNorm fold: the column vectors of the two LayerNorm consumers
+    HIP_TRY(h, cvt(W(h, pre + ".self_attn.out_proj.weight"), w.wo, D, D));
+    HIP_TRY(h, cvt(W(h, pre + ".mlp.fc1.weight"), w.w1, ff, D));
+    HIP_TRY(h, cvt(W(h, pre + ".mlp.fc2.weight"), w.w2, D, ff));
+    if (&t == &h->vis && h->fold_part && !t.split) {  // LayerNorm fold: the column vectors of the two LayerNorm consumers
       if ((rc = dev_alloc(h, (void**)&w.cqkv, (size_t)3 * D * sizeof(float)))) return rc;
       if ((rc = dev_alloc(h, (void**)&w.bqkvf, (size_t)3 * D * sizeof(float)))) return rc;
       if ((rc = dev_alloc(h, (void**)&w.c1, (size_t)ff * sizeof(float)))) return rc;
@@ -463,6 +473,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   const mcm_config& c = *cfg;
   if (c.precision != MCM_PREC_BF16 && c.precision != MCM_PREC_F32 && c.precision != MCM_PREC_F16)
     return fail(nullptr, MCM_EINVAL, "unknown precision");
+  if (c.weight_operands < MCM_WEIGHTS_AUTO || c.weight_operands > MCM_WEIGHTS_SPLIT)
+    return fail(nullptr, MCM_EINVAL, "unknown weight_operands");
   if (c.v_heads <= 0 || c.t_heads <= 0 || c.v_width != c.v_heads * 64 || c.t_width != c.t_heads * 64)
     return fail(nullptr, MCM_EINVAL, "head_dim must be 64");
   if (c.patch_size <= 0 || c.image_size % c.patch_size)
@@ -537,7 +549,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->att, attb);
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
-  // zeroed once: pad rows (gemm()) then only ever hold zeros, bias-only results or a previous batch's valid rows
+  // zeroed once (a ragged vision batch zeroes its pad rows again: encode_image_impl, "Pad rows")
   if (!rc && (hipMemset(h->x, 0, xb) != hipSuccess || hipMemset(h->ln, 0, lnb) != hipSuccess ||
               hipMemset(h->qkv, 0, qkvb) != hipSuccess || hipMemset(h->att, 0, attb) != hipSuccess ||
               hipMemset(h->hbuf, 0, h->hbuf_bytes) != hipSuccess))
@@ -546,7 +558,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
   if (!rc) rc = dev_alloc(h, (void**)&h->rowidx_dev, (size_t)mt * sizeof(int32_t));
-  if (!rc) rc = dev_alloc(h, &h->wpatch, (size_t)c.v_width * h->kpad * es);
+  if (!rc) rc = dev_alloc(h, &h->wpatch, (size_t)c.v_width * h->kpad * es * 2);  // (x 2: room for the split image)
   if (!rc && hipHostMalloc((void**)&h->ids_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc ids");
   if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
@@ -594,16 +606,56 @@ void mcm_destroy(mcm_handle* h) {
   delete h;
 }
 
-int mcm_set_weight(mcm_handle* h, const char* hf_name, const float* host_ptr, const int64_t* shape,
+namespace {
+float half_bits_to_float(uint16_t v) {  // IEEE binary16 -> binary32, exact (host side of mcm_set_weight)
+  const uint32_t sign = (uint32_t)(v & 0x8000u) << 16, e = (v >> 10) & 0x1fu, m = v & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) {
+      u = sign;
+    } else {  // subnormal: m * 2^-24
+      const float f = (float)m * (1.0f / 16777216.0f);
+      uint32_t fu;
+      memcpy(&fu, &f, 4);
+      u = sign | fu;
+    }
+  } else if (e == 31) {
+    u = sign | 0x7f800000u | (m << 13);
+  } else {
+    u = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float out;
+  memcpy(&out, &u, 4);
+  return out;
+}
+}  // namespace
+
+int mcm_set_weight(mcm_handle* h, const char* hf_name, const void* host_ptr, int32_t dtype, const int64_t* shape,
                    int32_t ndim) {
   if (!h || !hf_name || !host_ptr || (ndim > 0 && !shape)) return fail(h, MCM_EINVAL, "null argument");
+  if (dtype != MCM_DT_F32 && dtype != MCM_DT_F16 && dtype != MCM_DT_BF16) return fail(h, MCM_EINVAL, "unknown dtype");
   auto it = h->params.find(hf_name);
   if (it == h->params.end()) return fail(h, MCM_ENAME, std::string("unknown parameter ") + hf_name);
   Param& p = it->second;
   bool ok = (size_t)ndim == p.shape.size();
   for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == p.shape[i];
   if (!ok) return fail(h, MCM_ESHAPE, std::string("shape mismatch for ") + hf_name);
-  HIP_TRY(h, hipMemcpy(p.dev, host_ptr, (size_t)p.numel * sizeof(float), hipMemcpyHostToDevice));
+  const void* src = host_ptr;
+  std::vector<float> wide;
+  if (dtype != MCM_DT_F32) {  // the fp32 master is the exact widening of a 16-bit checkpoint value
+    wide.resize((size_t)p.numel);
+    const uint16_t* q = (const uint16_t*)host_ptr;
+    for (int64_t i = 0; i < p.numel; ++i) {
+      if (dtype == MCM_DT_F16) {
+        wide[(size_t)i] = half_bits_to_float(q[i]);
+      } else {
+        const uint32_t u = (uint32_t)q[i] << 16;
+        memcpy(&wide[(size_t)i], &u, 4);
+      }
+    }
+    src = wide.data();
+  }
+  HIP_TRY(h, hipMemcpy(p.dev, src, (size_t)p.numel * sizeof(float), hipMemcpyHostToDevice));
   p.set = true;
   h->finalized = false;
   return MCM_OK;
@@ -613,20 +665,49 @@ int mcm_finalize_weights(mcm_handle* h) {
   if (!h) return MCM_EINVAL;
   for (auto& kv : h->params)
     if (!kv.second.set) return fail(h, MCM_ENOWEIGHT, "parameter never set: " + kv.first);
-  // operand copies are re-built from the fp32 masters each time (pointers are stable)
-  if (h->vis.L.empty()) {
-    int rc;
-    if ((rc = build_tower(h, h->vis, "vision_model", nullptr))) return rc;
-    if ((rc = build_tower(h, h->txt, "text_model", nullptr))) return rc;
-  } else {
-    return fail(h, MCM_EINVAL, "weights already finalized; create a new handle to reload");
-  }
+  if (!h->vis.L.empty()) return fail(h, MCM_EINVAL, "weights already finalized; create a new handle to reload");
   const mcm_config& c = h->cfg;
-  HIP_TRY(h, launch_cvt_weight(c.precision, W(h, "vision_model.embeddings.patch_embedding.weight"),
-                               h->wpatch, c.v_width, 3 * c.patch_size * c.patch_size, h->kpad,
-                               nullptr));
+  // Which vision GEMM weights are NOT numbers of the operand dtype?  (include/mcm.h MCM_WEIGHTS_*: a weight that is one
+  // is lossless as a single 16-bit operand; one that is not is rounded - unless the split form carries the remainder.)
+  h->w_inexact = 0;
+  if (c.precision != MCM_PREC_F32) {
+    unsigned long long* cnt = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&cnt, sizeof(*cnt)));
+    hipError_t e = hipMemset(cnt, 0, sizeof(*cnt));
+    for (auto& kv : h->params) {
+      const std::string& n = kv.first;
+      const bool gemm_w = n.rfind("vision_model.", 0) == 0 && kv.second.shape.size() >= 2 &&
+                          (n.find("_proj.weight") != std::string::npos || n.find(".mlp.fc") != std::string::npos ||
+                           n.find("patch_embedding.weight") != std::string::npos);
+      if (gemm_w && e == hipSuccess)
+        e = launch_count_inexact(c.precision, kv.second.dev, (size_t)kv.second.numel, cnt, nullptr);
+    }
+    unsigned long long v = 0;
+    if (e == hipSuccess) e = hipMemcpy(&v, cnt, sizeof(v), hipMemcpyDeviceToHost);
+    (void)hipFree(cnt);
+    if (e != hipSuccess) return fail(h, MCM_EHIP, std::string("counting inexact weights: ") + hipGetErrorString(e));
+    h->w_inexact = v;
+  }
+  h->vis.split = c.precision != MCM_PREC_F32 &&
+                 (c.weight_operands == MCM_WEIGHTS_SPLIT || (c.weight_operands == MCM_WEIGHTS_AUTO && h->w_inexact > 0));
+  // operand copies are built from the fp32 masters once (pointers are stable afterwards)
+  int rc;
+  if ((rc = build_tower(h, h->vis, "vision_model", nullptr))) return rc;
+  if ((rc = build_tower(h, h->txt, "text_model", nullptr))) return rc;
+  const float* wp = W(h, "vision_model.embeddings.patch_embedding.weight");
+  const int kreal = 3 * c.patch_size * c.patch_size;
+  if (h->vis.split) HIP_TRY(h, launch_cvt_weight_split(c.precision, wp, h->wpatch, c.v_width, kreal, h->kpad, nullptr));
+  else HIP_TRY(h, launch_cvt_weight(c.precision, wp, h->wpatch, c.v_width, kreal, h->kpad, nullptr));
   HIP_TRY(h, hipDeviceSynchronize());
   h->finalized = true;
+  return MCM_OK;
+}
+
+int mcm_weights_operand_exact(mcm_handle* h, uint64_t* inexact_host, int32_t* split_host) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (inexact_host) *inexact_host = h->w_inexact;
+  if (split_host) *split_host = h->vis.split ? 1 : 0;
   return MCM_OK;
 }
 
@@ -658,8 +739,21 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
   GemmArgs a{};
   a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
   a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
-  a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np;
+  a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np; a.ksplit = h->vis.split ? 1 : 0;
   HIP_TRY(h, gemm(h, s, c.precision, EPI_PATCH, a));
+  {  // Pad rows.  gemm() runs the dense activation GEMMs on whole 256-row tiles; the rows between B * ntok and the next
+     // multiple of 256 are computed and never read.  The buffers they live in are shared with the fp32 text tower, so
+     // what they hold is arbitrary (fp32 bit patterns read as fp16 decode to inf / NaN, which would trip the saturation
+     // watch): a ragged batch zeroes them first, and they then only ever carry bias-only values.
+    const int64_t M = (int64_t)B * h->ntok, mp = padded_rows(h, (int)M);
+    if (mp > M) {
+      const size_t es = (size_t)prec_esize(c.precision), pad = (size_t)(mp - M);
+      HIP_TRY(h, hipMemsetAsync(h->x + M * D, 0, pad * D * sizeof(float), s));
+      HIP_TRY(h, hipMemsetAsync((char*)h->ln + (size_t)M * D * es, 0, pad * D * es, s));
+      HIP_TRY(h, hipMemsetAsync((char*)h->att + (size_t)M * D * es, 0, pad * D * es, s));
+      HIP_TRY(h, hipMemsetAsync((char*)h->hbuf + (size_t)M * c.v_mlp * es, 0, pad * c.v_mlp * es, s));
+    }
+  }
   // the CLS row of every image (class_embedding + position_embedding[0], HF :212-217) is produced inside the
   // LayerNorm pass below instead of by a launch of its own
   {  // pre_layrnorm (fp32, in place) and layer 0's layer_norm1 in one pass over x; a 1-layer tower whose only
@@ -670,11 +764,6 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
                                     h->ln, B * h->ntok, D, c.ln_eps, s, next_dir(h),
                                     h->sat_on ? h->sat_dev : nullptr,
                                     W(h, "vision_model.embeddings.class_embedding"), a.pos, h->ntok));
-  }
-  if (g_ln_fold) {  // pad rows of the residual stream (gemm() runs whole 256-row tiles): the residual epilogues add to
-                    // them on every call; the fold's fp16 z of a pad row must not saturate, so they start from zero
-    const int64_t M = (int64_t)B * h->ntok, mp = padded_rows(h, (int)M);
-    if (mp > M) HIP_TRY(h, hipMemsetAsync(h->x + M * D, 0, (size_t)(mp - M) * D * sizeof(float), s));
   }
   if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true, true))) return rc;
   {
@@ -958,13 +1047,31 @@ int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, doubl
 int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev, const float* bias_dev,
                   void* y_dev, float* resid_dev, int32_t M, int32_t N, int32_t K, int32_t epi,
                   void* stream) {
+  return mcm_op_linear_ex(h, prec, x_dev, w_dev, bias_dev, y_dev, resid_dev, M, N, K, epi, 0, stream);
+}
+
+int mcm_op_linear_ex(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev, const float* bias_dev,
+                     void* y_dev, float* resid_dev, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t flags,
+                     void* stream) {
   if (!h) return MCM_EINVAL;
   if (epi < EPI_STORE || epi > EPI_RESID) return fail(h, MCM_EINVAL, "bad epilogue");
+  const bool split = (flags & MCM_LINEAR_SPLIT_W) != 0;
+  if ((flags & ~MCM_LINEAR_SPLIT_W) || (split && (prec == MCM_PREC_F32 || K % 64)))
+    return fail(h, MCM_EINVAL, "bad flags (split weights: 16-bit modes, K % 64 == 0)");
   GemmArgs a{};
   a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.out = y_dev; a.resid = resid_dev;
-  a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldo = N;
+  a.M = M; a.N = N; a.K = split ? 2 * K : K; a.ldx = K; a.ldo = N; a.ksplit = split ? 1 : 0;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
   HIP_TRY(h, launch_gemm(prec, epi, a, (hipStream_t)stream));
+  return MCM_OK;
+}
+
+int mcm_op_split_weight(mcm_handle* h, int32_t prec, const float* w_dev, int32_t N, int32_t K, void* out_dev,
+                        void* stream) {
+  if (!h) return MCM_EINVAL;
+  if (!w_dev || !out_dev || N <= 0 || K <= 0 || K % 64 || prec == MCM_PREC_F32)
+    return fail(h, MCM_EINVAL, "split weights: 16-bit modes, K % 64 == 0");
+  HIP_TRY(h, launch_cvt_weight_split(prec, w_dev, out_dev, N, K, K, (hipStream_t)stream));
   return MCM_OK;
 }
 

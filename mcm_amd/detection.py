@@ -143,15 +143,18 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
     n_total = len(loader.dataset)
     with torch.no_grad():
         text_features = prompt_bank(args, net, test_labels)
-        if ws > 1 and hasattr(loader, "shard"):
+        by_index = True  # this rank's shard is the contiguous index range shard_range gives
+        mine = lambda i: True  # noqa: E731
+        batches = loader
+        if ws > 1:
             lo, hi = mdist.shard_range(n_total, rank, ws)
-            batches = loader.shard(lo, hi)
-            mine = lambda i: True  # noqa: E731
-        else:
-            nb = len(loader)
-            blo, bhi = mdist.shard_range(nb, rank, ws)
-            batches = loader
-            mine = lambda i: blo <= i < bhi  # noqa: E731
+            batches = shard_loader(loader, lo, hi)
+            if batches is None:  # an opaque iterable: batch-range shards (every rank still pays its decode)
+                by_index = False
+                nb = len(loader)
+                blo, bhi = mdist.shard_range(nb, rank, ws)
+                batches = loader
+                mine = lambda i: blo <= i < bhi  # noqa: E731
         parts = []
         for batch_idx, (images, _labels) in enumerate(batches):
             if not mine(batch_idx):
@@ -159,16 +162,39 @@ def get_ood_scores_clip(args, net, loader, test_labels, in_dist=False, device_ou
             parts.append(net.score_images(images, text_features, float(args.T), args.score))
         local = torch.cat(parts) if parts else torch.empty(0, dtype=torch.float32,
                                                            device=text_features.device)
-        if ws > 1:
-            if hasattr(loader, "shard"):
+        if mdist.group_active():  # (also a 1-rank group: the collective really runs — RCCL on a GPU box)
+            if by_index:
                 full = mdist.all_gather_scores(local, n_total)
-            else:  # batch-range shards of a generic loader: sizes follow the batch split
+            else:  # batch-range shards of an opaque loader: sizes follow the batch split
                 full = _gather_batch_shards(local, n_total, ws)
         else:
             full = local
     if device_out:
         return full.detach()[:n_total]
     return full.detach().cpu().numpy().astype(np.float32, copy=False)[:n_total].copy()
+
+
+def shard_loader(loader, lo: int, hi: int):
+    """A loader over samples [lo, hi) of `loader.dataset`, in order — a rank's shard BEFORE any decode happens.
+    The build's own loaders have `.shard`; a torch-style DataLoader (map-style `dataset`, `batch_size`, the reference's
+    kind: utils/train_eval_util.py:96-146, shuffle=False) is re-built over `Subset(dataset, range(lo, hi))` with the same
+    batch size, workers and collate function; anything else returns None (the caller falls back to skipping batches)."""
+    if hasattr(loader, "shard"):
+        return loader.shard(lo, hi)
+    ds, bs = getattr(loader, "dataset", None), getattr(loader, "batch_size", None)
+    if ds is None or not bs or not hasattr(ds, "__getitem__"):
+        return None
+    try:
+        from torch.utils.data import DataLoader, Subset
+    except Exception:
+        return None
+    if not isinstance(loader, DataLoader):
+        return None
+    kw = dict(batch_size=bs, shuffle=False, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+              pin_memory=loader.pin_memory, drop_last=False)
+    if loader.num_workers > 0:
+        kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=False)
+    return DataLoader(Subset(ds, range(lo, hi)), **kw)
 
 
 def get_mean_prec(args, net, train_loader):
@@ -229,16 +255,29 @@ def get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_
 
     state = net.maha_prepare(classwise_mean, precision)
     total_len = len(test_loader.dataset)
-    out = []
+    # the samples the reference scores: everything for the ID set, whole batches only for an OOD set
+    n_scored = total_len if in_dist else min(total_len, (total_len // args.batch_size) * args.batch_size)
+    rank, ws = mdist.world()
+    batches, lo, hi = test_loader, 0, n_scored
+    if ws > 1:  # image-sharded like get_ood_scores_clip: a contiguous index range per rank, all-gathered at the end
+        lo, hi = mdist.shard_range(n_scored, rank, ws)
+        batches = shard_loader(test_loader, lo, hi)
+        if batches is None:
+            raise TypeError("--score maha under world_size > 1 needs a loader that can be sharded by index")
+    out, seen = [], 0
     with torch.no_grad():
-        for batch_idx, (images, _labels) in enumerate(test_loader):
-            if (batch_idx >= total_len // args.batch_size) and in_dist is False:
+        for images, _labels in batches:
+            if seen >= hi - lo:
                 break
+            images = images[: hi - lo - seen]
             features = net.get_image_features(pixel_values=images).float()
             if args.normalize:
                 features = features / features.norm(dim=-1, keepdim=True)
             out.append(net.maha_scores(features, state))
-    res = torch.cat(out) if out else torch.empty(0)
+            seen += images.shape[0]
+    res = torch.cat(out) if out else torch.empty(0, device=state["prec"].device)
+    if mdist.group_active():
+        res = mdist.all_gather_scores(res, n_scored)
     return res.cpu().numpy().astype(np.float32)
 
 

@@ -25,16 +25,28 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
-def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+def group_active() -> bool:
+    """A default process group exists — of any size.  A 1-rank group (torchrun --nproc-per-node 1) still sends the
+    score shards through the collective: that is how the RCCL path is exercised on a 1-GPU box."""
+    try:
+        import torch.distributed as dist
+
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
+
+
+def init_from_env(backend: str | None = None, force: bool = False) -> Tuple[int, int, int]:
     """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK /
-    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); no-op for 1 process."""
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); no-op for 1 process unless `force`
+    (a 1-rank process group: every collective of the path then really runs, on RCCL when a GPU is there)."""
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -59,6 +71,29 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, ws, local
 
 
+def broadcast_tensors(tensors, src: int = 0):
+    """Broadcast CPU or device tensors from `src` to every rank, in place (a no-op without a process group).  RCCL moves
+    device tensors; CPU tensors take a device bounce under nccl (gloo moves them as they are)."""
+    import torch
+    import torch.distributed as dist
+
+    if not group_active():
+        return tensors
+    nccl = dist.get_backend() == "nccl"
+    for t in tensors:
+        if nccl and not t.is_cuda:
+            d = t.cuda()
+            dist.broadcast(d, src=src)
+            t.copy_(d.cpu())
+        elif not nccl and t.is_cuda:
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h.to(t.device))
+        else:
+            dist.broadcast(t, src=src)
+    return tensors
+
+
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous index range of `rank`: [r·ceil(n/W), (r+1)·ceil(n/W)) ∩ [0,n).
     Concatenating shards in rank order reproduces the dataset order the reference's
@@ -76,7 +111,7 @@ def all_gather_scores(local, n_total: int):
     import torch.distributed as dist
 
     rank, ws = world()
-    if ws == 1:
+    if not group_active():
         return local
     home = local.device
     if dist.get_backend() == "gloo" and local.is_cuda:  # ranks sharing a device (logic checks): host bounce
@@ -106,12 +141,16 @@ def all_gather_histograms(local_scores, edges, net=None):
     rank, ws = world()
     if getattr(local_scores, "is_cuda", False) and net is not None:
         hist = net.histogram(local_scores, edges)
-        if ws > 1:
+        if group_active():
+            if dist.get_backend() == "gloo":  # ranks sharing a device (logic checks): host bounce
+                h = hist.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                return h.numpy()
             dist.all_reduce(hist, op=dist.ReduceOp.SUM)
         return hist.cpu().numpy()
     x = local_scores.detach().float().cpu().numpy() if hasattr(local_scores, "detach") else np.asarray(local_scores)
     hist = torch.from_numpy(np.histogram(x, bins=np.asarray(edges, dtype=np.float32))[0].astype(np.int64))
-    if ws > 1:
+    if group_active():
         backend = dist.get_backend()
         h = hist.cuda() if backend == "nccl" else hist
         dist.all_reduce(h, op=dist.ReduceOp.SUM)

@@ -23,7 +23,8 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .config import CConfig, ClipGeometry, PREC_BF16, PREC_F16, PREC_F32, SCORE_KINDS, geometry
+from .config import (ABI_VERSION, CConfig, ClipGeometry, DT_BF16, DT_F16, DT_F32, PREC_BF16, PREC_F16, PREC_F32,
+                     SCORE_KINDS, WEIGHT_OPERANDS, geometry)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcm_hip.so")
@@ -57,7 +58,8 @@ def load_library(harness: bool = False):
     L.mcm_destroy.restype = None
     L.mcm_last_error.argtypes = [vp]
     L.mcm_last_error.restype = ctypes.c_char_p
-    L.mcm_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
+    L.mcm_set_weight.argtypes = [vp, ctypes.c_char_p, vp, i32, ctypes.POINTER(ctypes.c_int64), i32]
+    L.mcm_weights_operand_exact.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(i32)]
     L.mcm_finalize_weights.argtypes = [vp]
     L.mcm_encode_text.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mcm_encode_image.argtypes = [vp, vp, i32, vp, vp]
@@ -67,6 +69,8 @@ def load_library(harness: bool = False):
     L.mcm_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     L.mcm_op_linear.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.mcm_op_linear_ex.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.mcm_op_split_weight.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
     if harness:
@@ -100,8 +104,8 @@ def load_library(harness: bool = False):
                                ctypes.POINTER(ctypes.c_double), vp]
     L.mcm_saturation_check.argtypes = [vp, i32]
     L.mcm_saturation_count.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64), vp]
-    if L.mcm_abi_version() != 1:
-        raise RuntimeError("libmcm_hip.so ABI version mismatch")
+    if L.mcm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {L.mcm_abi_version()}, this package speaks {ABI_VERSION} — rebuild (make -C mcm_amd/csrc)")
     _libs[harness] = L
     return L
 
@@ -116,6 +120,7 @@ EXPORTED_SYMBOLS = [
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
     "mcm_saturation_check", "mcm_saturation_count",
+    "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
@@ -134,7 +139,7 @@ class NativeCLIP:
     def __init__(self, geo: ClipGeometry | str, state_dict: Dict[str, np.ndarray], *,
                  device: int = 0, precision: str = "fp16", max_batch: int = 512,
                  max_prompt_tokens: int = 1024 * 77, synthetic_weights: Optional[bool] = None,
-                 harness: bool = False):
+                 harness: bool = False, weight_operands: str = "auto"):
         import torch
 
         if not torch.cuda.is_available():
@@ -150,8 +155,11 @@ class NativeCLIP:
         self._lib = load_library(harness)  # harness=True: A/B tests and tools only
         torch.cuda.set_device(self.device)
         torch.cuda.init()
+        # 16-bit modes: how a GEMM weight is held (include/mcm.h MCM_WEIGHTS_*).  "auto": one 16-bit operand when every
+        # weight IS a number of that dtype (the reference's fp16-trained checkpoints), W_hi + W_lo otherwise
         self._cfg = self.geo.to_c(device=device, precision=self.precision, max_batch=max_batch,
-                                  max_prompt_tokens=max_prompt_tokens)
+                                  max_prompt_tokens=max_prompt_tokens,
+                                  weight_operands=WEIGHT_OPERANDS[weight_operands])
         self._h = ctypes.c_void_p()
         rc = self._lib.mcm_create(ctypes.byref(self._cfg), ctypes.byref(self._h))
         if rc:
@@ -159,11 +167,22 @@ class NativeCLIP:
         for name, arr in state_dict.items():
             if name == "logit_scale" or name.endswith("position_ids"):
                 continue  # unused by MCM (reference utils/detection_util.py:232) / HF buffers
-            a = np.ascontiguousarray(arr, dtype=np.float32)
+            arr = np.asarray(arr)
+            if arr.dtype == np.float16:  # an fp16 checkpoint is handed over as it is (the library widens exactly)
+                a, dt = np.ascontiguousarray(arr), DT_F16
+            elif str(arr.dtype) == "bfloat16":  # ml_dtypes / safetensors views: raw 16-bit patterns
+                a, dt = np.ascontiguousarray(arr).view(np.uint16), DT_BF16
+            else:
+                a, dt = np.ascontiguousarray(arr, dtype=np.float32), DT_F32
             shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
-            self._check(self._lib.mcm_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+            self._check(self._lib.mcm_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), dt,
                                                  shape, a.ndim))
         self._check(self._lib.mcm_finalize_weights(self._h))
+        n, sp = ctypes.c_uint64(0), ctypes.c_int32(0)
+        self._check(self._lib.mcm_weights_operand_exact(self._h, ctypes.byref(n), ctypes.byref(sp)))
+        # vision GEMM-weight elements that are not numbers of the operand dtype, and whether the split-weight
+        # GEMMs run (weight_operands="auto": exactly when that count is non-zero)
+        self.weights_inexact, self.split_weights = int(n.value), bool(sp.value)
 
     # -- plumbing ------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -393,12 +412,13 @@ class NativeCLIP:
 
 
 def build_model(ckpt: str = "ViT-B/16", *, weights: Optional[str] = None, seed: int = 0,
-                **kw) -> NativeCLIP:
+                synthetic_regime: str = "fp16-exact", **kw) -> NativeCLIP:
     """`set_model_clip` counterpart (reference utils/train_eval_util.py:15-36): checkpoint
     name → NativeCLIP.  `weights` = path to a real checkpoint; default = seeded synthetic
-    parameters (no checkpoint exists offline)."""
+    parameters (no checkpoint exists offline), by default rounded to fp16 values like the reference's
+    checkpoints are (`synthetic_regime="fp32"`: as drawn — a 16-bit arm then runs the split-weight GEMMs)."""
     from .weights import load_state_dict_file, synth_state_dict
 
     geo = geometry(ckpt)
-    sd = load_state_dict_file(weights, geo) if weights else synth_state_dict(geo, seed)
+    sd = load_state_dict_file(weights, geo) if weights else synth_state_dict(geo, seed, synthetic_regime)
     return NativeCLIP(geo, sd, synthetic_weights=not weights, **kw)

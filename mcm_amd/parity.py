@@ -32,18 +32,36 @@ HEADLINE_PIXELS = dict(amp=1.5, tile=0.0, weights="fp16-exact")
 CONFIG3_OOD_SETS = (("iNaturalist", 10000, 11), ("SUN", 10000, 12), ("places365", 10000, 13), ("dtd", 5640, 14))
 
 
+# A second operating point: the same construction with a strong per-class texture, ID and OOD sets at
+# different strengths, so that a random-init tower gives a real checkpoint's kind of numbers — a score spread of a few %
+# of |score| and a well-separated AUROC — instead of the ordering stress above (tools/spread_probe.py chose the values).
+REALISTIC_PIXELS = dict(amp=1.5, tile=30.0, tile_ood=3.0, weights="fp16-exact")
+
+
+def _arm_spec(arm: str):
+    """"fp16" | "bf16" | "fp32", optionally ":single" / ":split" (the weight-operand form, include/mcm.h MCM_WEIGHTS_*;
+    default "auto": split exactly when a GEMM weight is not a number of the operand dtype)."""
+    prec, _, wo = arm.partition(":")
+    return prec, (wo or "auto")
+
+
 def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n_ood: int = 10000,
                   batch: int = 512, arms: Sequence[str] = ("bf16", "fp16"), ref: str = "fp32",
                   device: int = 0, score: str = "MCM", T: float = 1.0, amp: float = 1.5,
                   tile: float = 0.0, weights: str = "fp32", seed: int = 1,
                   external: Optional[Dict[str, Callable]] = None,
-                  ood_sets: Optional[Sequence] = None) -> Dict:
+                  ood_sets: Optional[Sequence] = None, tile_ood: Optional[float] = None,
+                  state_dict: Optional[Dict] = None) -> Dict:
     """weights="fp16-exact": every parameter of the seeded state dict is rounded to the nearest fp16 value
     first (for ALL arms, the fp32 reference included) — the situation of the reference's checkpoints, whose
     Linear / conv / projection weights were trained and released in fp16, so an fp16 operand copy of them is
-    lossless and only activation rounding separates the fp16 arm from the fp32 one.
+    lossless and only activation rounding separates the fp16 arm from the fp32 one.  weights="fp32": as drawn; a 16-bit
+    arm then runs the split-weight GEMMs (arm "fp16") unless it says "fp16:single".
     ood_sets = ((name, size, seed), ...): several OOD sets against the one ID set; d_auroc / d_aupr / d_fpr95 of an
-    arm are then the differences of the AVG row (mean of the per-set metrics), `per_set` holds each set's own."""
+    arm are then the differences of the AVG row (mean of the per-set metrics), `per_set` holds each set's own and
+    `max_set` the largest per-set difference (what "identical FPR95 per dataset" is judged on).
+    tile_ood: texture strength of the OOD sets when it differs from the ID set's `tile`.
+    state_dict: score with these parameters instead of the seeded ones (`weights` then only labels the result)."""
     import torch
 
     from .config import geometry
@@ -52,12 +70,11 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
     from .weights import synth_state_dict
 
     geo = geometry(ckpt)
-    import numpy as np
-
-    sd = synth_state_dict(geo, 0)
-    if weights == "fp16-exact":
-        sd = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
-    elif weights != "fp32":
+    if state_dict is not None:
+        sd = state_dict
+    elif weights in ("fp16-exact", "fp32"):
+        sd = synth_state_dict(geo, 0, weights)
+    else:
         raise ValueError(weights)
     ids, mask = make_token_ids(K, seed=2)
     dev = torch.device("cuda", device)
@@ -68,7 +85,8 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         for name, factory in (external or {}).items():
             ext[name] = factory(geo, sd, ids, mask, dev)
         for p in names:
-            nets[p] = NativeCLIP(geo, sd, device=device, precision=p, max_batch=batch,
+            prec, wo = _arm_spec(p)
+            nets[p] = NativeCLIP(geo, sd, device=device, precision=prec, max_batch=batch, weight_operands=wo,
                                  max_prompt_tokens=max(K * ids.shape[1], 77))
             banks[p] = nets[p].get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         # one OOD set (the default) or several: BASELINE config 3 scores the ID set once against four OOD sets and
@@ -76,8 +94,10 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         sets = [("ood", n_ood, seed)] if not ood_sets else [(str(n), int(c), int(sd_)) for n, c, sd_ in ood_sets]
         tags = ["id"] + [n for n, _, _ in sets]
         scores = {p: {} for p in names + list(ext)}
+        t_ood = tile if tile_ood is None else tile_ood
         for tag, n, ood, sd_ in [("id", n_id, False, seed)] + [(n, c, True, s_) for n, c, s_ in sets]:
-            loader = DevicePatternLoader(n, geo.image_size, K, batch, dev, ood=ood, seed=sd_, amp=amp, tile=tile)
+            loader = DevicePatternLoader(n, geo.image_size, K, batch, dev, ood=ood, seed=sd_, amp=amp,
+                                         tile=t_ood if ood else tile)
             parts = {p: [] for p in names + list(ext)}
             for px, _ in loader:
                 for p in names:
@@ -87,10 +107,13 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             for p in parts:
                 scores[p][tag] = torch.cat(parts[p])
         out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood if not ood_sets else {n: c for n, c, _ in sets},
-               "batch": batch, "score": score, "T": T, "reference_arm": ref, "pixels": {"amp": amp, "tile": tile},
-               "weights": weights, "arms": {}}
+               "batch": batch, "score": score, "T": T, "reference_arm": ref,
+               "pixels": {"amp": amp, "tile": tile, "tile_ood": t_ood},
+               "weights": weights if state_dict is None else "caller's state dict", "arms": {}}
         # fp16 activations that hit +-65504 anywhere in the run (sticky per-handle counters; 0 = none)
-        out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in names if p == "fp16"}
+        out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in names if _arm_spec(p)[0] == "fp16"}
+        out["weight_operands"] = {p: {"split": nets[p].split_weights, "inexact_elements": nets[p].weights_inexact}
+                                  for p in names}
 
         def measures(p):  # per OOD set, and the AVG row (mean over the sets) — what the metrics are quoted on
             per = {n: nets[ref].measures(scores[p]["id"], scores[p][n], negate=True) for n, _, _ in sets}
@@ -102,10 +125,13 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             d = torch.cat([(scores[p][t] - scores[q][t]).abs() for t in tags])
             r = {"d_auroc": abs(pa[0] - qa[0]), "d_aupr": abs(pa[1] - qa[1]), "d_fpr95": abs(pa[2] - qa[2]),
                  "max_abs_dscore": float(d.max()), "rms_dscore": float(d.pow(2).mean().sqrt())}
-            if len(sets) > 1:  # the keys above are the AVG row; every set on its own, FPR95 also as an image count
-                r["per_set"] = {n: {"d_auroc": abs(pp[n][0] - qp[n][0]), "d_aupr": abs(pp[n][1] - qp[n][1]),
-                                    "d_fpr95": abs(pp[n][2] - qp[n][2]),
-                                    "d_fpr95_images": round(abs(pp[n][2] - qp[n][2]) * c)} for n, c, _ in sets}
+            per = {n: {"d_auroc": abs(pp[n][0] - qp[n][0]), "d_aupr": abs(pp[n][1] - qp[n][1]),
+                       "d_fpr95": abs(pp[n][2] - qp[n][2]),
+                       "d_fpr95_images": round(abs(pp[n][2] - qp[n][2]) * c)} for n, c, _ in sets}
+            # the largest per-set difference: opposite-sign drifts of different sets cancel in the AVG row, not here
+            r["max_set"] = {k: max(v[k] for v in per.values()) for k in ("d_auroc", "d_aupr", "d_fpr95", "d_fpr95_images")}
+            if len(sets) > 1:  # the top-level keys are the AVG row; every set on its own, FPR95 also as an image count
+                r["per_set"] = per
             return r
 
         meas = {p: measures(p) for p in names + list(ext)}
@@ -130,6 +156,14 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         for n in nets.values():
             n.close()
         ext.clear()
+
+
+def meets_bar(d: Dict, bar: float = 1e-4, fpr_images: int = 1) -> bool:
+    """north_star's tolerance on one `delta` record, judged per OOD set (not on the AVG row, where opposite-sign drifts
+    cancel): |dAUROC|, |dAUPR| <= bar on every set, FPR95 within `fpr_images` images of the reference on every set (its
+    quantum: one image of a 10 000-image set IS 1e-4)."""
+    m = d["max_set"]
+    return bool(m["d_auroc"] <= bar and m["d_aupr"] <= bar and m["d_fpr95_images"] <= fpr_images)
 
 
 if __name__ == "__main__":  # python -m mcm_amd.parity [n_id n_ood [amp]]

@@ -97,8 +97,42 @@ def synth_param(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
-def synth_state_dict(geo: ClipGeometry, seed: int = 0) -> Dict[str, np.ndarray]:
-    return {n: synth_param(n, s, seed) for n, s in param_shapes(geo).items()}
+def synth_state_dict(geo: ClipGeometry, seed: int = 0, regime: str = "fp32") -> Dict[str, np.ndarray]:
+    """regime="fp32": the seeded values as drawn (fp32-valued: nothing like an fp16 number — a 16-bit arm then
+    runs the split-weight GEMMs, include/mcm.h MCM_WEIGHTS_*).  regime="fp16-exact": every parameter rounded to the
+    nearest fp16 value, returned as fp32 — the situation of the reference's checkpoints (`openai/clip-vit-*`: Linear /
+    conv / projection weights trained and released in fp16, widened to fp32 by the HF conversion), for which one
+    fp16 operand per weight is lossless."""
+    sd = {n: synth_param(n, s, seed) for n, s in param_shapes(geo).items()}
+    if regime == "fp16-exact":
+        sd = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    elif regime != "fp32":
+        raise ValueError(f"unknown weight regime {regime!r}")
+    return sd
+
+
+def inject_outlier_channels(sd: Dict[str, np.ndarray], geo: ClipGeometry, *, channels: int = 6, scale: float = 100.0,
+                            gamma_scale: float = None, seed: int = 7) -> Tuple[Dict[str, np.ndarray], np.ndarray]:
+    """Outlier-channel stress checkpoint.  Real CLIP ViTs carry a handful of residual-stream
+    channels whose activations are 50 - 200 x the rest ("massive activations"), written by a few rows of `out_proj` /
+    `fc2` and read through LayerNorm gains; seeded weights at HF init scales have none, so the fp16 arm's range and
+    precision are never exercised where a real checkpoint exercises them.  This returns a copy of `sd` in which
+    `channels` residual channels of the VISION tower are such outliers: in every layer the rows of
+    `out_proj.weight` / `fc2.weight` (and their bias entries) that write those channels are multiplied by `scale`, and the
+    `layer_norm1/2.weight` entries that read them by `gamma_scale` (default: `scale` — the harshest reading of the
+    stress: the outlier also reaches the next GEMM's operand amplified).  Returns (state dict, channel indices)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    ch = np.sort(rng.choice(geo.v_width, size=channels, replace=False))
+    g = scale if gamma_scale is None else gamma_scale
+    out = {k: v.copy() for k, v in sd.items()}
+    for i in range(geo.v_layers):
+        pre = f"vision_model.encoder.layers.{i}"
+        for lin in ("self_attn.out_proj", "mlp.fc2"):
+            out[f"{pre}.{lin}.weight"][ch, :] *= np.float32(scale)
+            out[f"{pre}.{lin}.bias"][ch] *= np.float32(scale)
+        for ln in ("layer_norm1", "layer_norm2"):
+            out[f"{pre}.{ln}.weight"][ch] *= np.float32(g)
+    return out, ch
 
 
 def load_state_dict_file(path: str, geo: ClipGeometry) -> Dict[str, np.ndarray]:

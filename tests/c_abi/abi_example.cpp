@@ -69,7 +69,7 @@ static int set_param(const char* name, int ndim, int64_t d0, int64_t d1, int64_t
   for (int i = 0; i < ndim; ++i) n *= shape[i];
   float* v = (float*)malloc(sizeof(float) * (size_t)n);
   for (int64_t i = 0; i < n; ++i) v[i] = center + amp * frand();
-  int rc = mcm_set_weight(h, name, v, shape, ndim);
+  int rc = mcm_set_weight(h, name, v, MCM_DT_F32, shape, ndim);
   if (!rc) rc = orc_set_weight(o, name, v, shape, ndim);
   if (rc) fprintf(stderr, "set %s: rc=%d (%s)\n", name, rc, mcm_last_error(h));
   free(v);
@@ -136,6 +136,11 @@ int main(int argc, char** argv) {
   rc |= set_param("text_projection.weight", 2, P, c.t_width, 0, 0, 0.f, 0.15f);
   if (rc) return 1;
   CHECK(mcm_finalize_weights(h));
+  uint64_t inexact = 0;
+  int32_t split = 0;
+  CHECK(mcm_weights_operand_exact(h, &inexact, &split)); /* these random weights are fp32-valued: a 16-bit mode splits them */
+  printf("vision GEMM-weight elements that are not operand-dtype numbers: %llu; split-weight GEMMs: %d\n",
+         (unsigned long long)inexact, (int)split);
 
   /* prompts: BOS r.. EOS pad(=EOS); pixels: [B,3,S,S] fp32, already normalised */
   int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * K * S);

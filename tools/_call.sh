@@ -1,5 +1,7 @@
 #!/bin/bash
-# scratch driver (round 3, call 62): the harness-library tests once more on the final harness build
-mkdir -p gpurun_out/r3c62
-O=$PWD/gpurun_out/r3c62
-timeout 110 python -m pytest tests/test_gpu_ln_tail.py tests/test_gpu_qkv_layout.py tests/test_gpu_ln_fold.py tests/test_gpu_kernels.py -m gpu -x -q -k "tail or layout or fold or sliver or tile64 or full_size_variants" > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+# scratch driver (round 4, call 1): split-weight arm — new tests, model tests, bench in both weight regimes
+mkdir -p gpurun_out/r4c01
+O=$PWD/gpurun_out/r4c01
+timeout 900 python -m pytest tests/test_gpu_split_weights.py tests/test_gpu_c_abi.py tests/test_gpu_model.py -m gpu -x -q > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt
+timeout 300 python bench.py --no-drift --cpu-seconds 0 > $O/bench_fp16exact.json 2> $O/bench_fp16exact.err; tail -c 600 $O/bench_fp16exact.json
+timeout 300 python bench.py --no-drift --cpu-seconds 0 --weights-regime fp32 > $O/bench_fp32w_split.json 2> $O/bench_fp32w_split.err; tail -c 600 $O/bench_fp32w_split.json
