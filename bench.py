@@ -185,6 +185,8 @@ def parity_leg(args, K, B, device):
                 hf_note = f"transformers unavailable on this box ({why}): vs_hf not measured"
         except Exception as e:
             hf_note = f"HF reference scorer unavailable ({type(e).__name__}: {e}): vs_hf not measured"
+    from mcm_amd.parity import REALISTIC_PIXELS, meets_bar
+
     arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16")))
     c3 = tuple(args.drift_n) == (50000, 10000)  # default: BASELINE config 3 — ImageNet-1k vs the four OOD sets
     ood_sets = CONFIG3_OOD_SETS if c3 else None
@@ -201,17 +203,21 @@ def parity_leg(args, K, B, device):
     keys = ("d_auroc", "d_aupr", "d_fpr95", "max_abs_dscore", "rms_dscore")
     for regime, weights in (("fp16_exact_weights", "fp16-exact"), ("fp32_valued_weights", "fp32")):
         t0 = time.perf_counter()
-        d = measure_drift(args.ckpt, K=K, n_id=args.drift_n[0], n_ood=args.drift_n[1], batch=B, arms=arms,
+        # fp32-valued weights: the 16-bit arms run the split-weight GEMMs (weight_operands auto); "fp16:single" is what
+        # rounds 1 - 3 did there (one rounded operand per weight), kept as the comparison
+        arms_w = arms + (("fp16:single",) if weights == "fp32" else ())
+        d = measure_drift(args.ckpt, K=K, n_id=args.drift_n[0], n_ood=args.drift_n[1], batch=B, arms=arms_w,
                           device=device, amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights,
                           external=external, ood_sets=ood_sets)
         r = {"auroc_fp32_arm": d["reference"]["auroc"], "fpr95_fp32_arm": d["reference"]["fpr95"],
              "score_std_id": d["reference"]["score_std_id"], "seconds": time.perf_counter() - t0,
              "fp16_saturation_events": d["fp16_saturation_events"].get("fp16"),
-             "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys + (("per_set",) if c3 else ())} for p in arms}}
+             "weight_operands": d["weight_operands"],
+             "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys + ("max_set",) + (("per_set",) if c3 else ())} for p in arms_w}}
         if "external" in d:
             r["auroc_hf"], r["fpr95_hf"] = d["external"]["hf"]["auroc"], d["external"]["hf"]["fpr95"]
             r["vs_hf"] = {"fp32_arm": d["reference"]["vs_external"]["hf"],
-                          **{p: d["arms"][p]["vs_external"]["hf"] for p in arms}}
+                          **{p: d["arms"][p]["vs_external"]["hf"] for p in arms_w}}
         out[regime] = r
     head = out["fp16_exact_weights"]
     # headline keys (what round 2's line carried): the benchmarked dtype, fp16-exact weights
@@ -223,10 +229,109 @@ def parity_leg(args, K, B, device):
         out["vs_hf"] = {"fp16_exact_weights": head["vs_hf"], "fp32_valued_weights": out["fp32_valued_weights"]["vs_hf"]}
     out["bf16"] = {w: out[w]["vs_hf" if "vs_hf" in out[w] else "vs_fp32_arm"]["bf16"]
                    for w in ("fp16_exact_weights", "fp32_valued_weights")}
-    out["meets_1e-4"] = {w: {p: bool(v["d_auroc"] <= 1e-4 and v["d_fpr95"] <= 1e-4 + 1e-12)
-                             for p, v in out[w]["vs_hf" if "vs_hf" in out[w] else "vs_fp32_arm"].items()}
-                         for w in ("fp16_exact_weights", "fp32_valued_weights")}
+    # judged PER OOD SET (the AVG row lets opposite-sign drifts cancel): |dAUROC|, |dAUPR| <= 1e-4 on every set and FPR95
+    # within N images of the reference on every set — N = 1 is the quantum of a 10 000-image set; on this ordering-stress
+    # set a 16-bit arm's activation rounding moves 0 - 2 images depending on the draw
+    for key, n_img in (("meets_1e-4", 2), ("meets_1e-4_fpr95_within_1_image", 1)):
+        out[key] = {w: {p: meets_bar(v, 1e-4, n_img) and bool(v["d_fpr95"] <= 1e-4 + 1e-12)
+                        for p, v in out[w]["vs_hf" if "vs_hf" in out[w] else "vs_fp32_arm"].items()}
+                    for w in ("fp16_exact_weights", "fp32_valued_weights")}
+    # the realistic operating point (mcm_amd/parity.py REALISTIC_PIXELS): reference AUROC 0.9, score noise ~0.1 % of the spread
+    if c3:
+        t0 = time.perf_counter()
+        d = measure_drift(args.ckpt, K=K, n_id=30000, n_ood=30000, batch=500, arms=arms, device=device,
+                          amp=REALISTIC_PIXELS["amp"], tile=REALISTIC_PIXELS["tile"], tile_ood=REALISTIC_PIXELS["tile_ood"],
+                          weights="fp16-exact", operating_point=0.9)
+        out["operating_point_auroc_0.9"] = dict(d["operating_point"], seconds=time.perf_counter() - t0,
+                                                pixels=d["pixels"], vs="exact-fp32 MFMA arm")
     return out
+
+
+def ingest_legs(net, txt, B, steps, which):
+    """uint8 host → scores, end to end (§7 hard part 4).  `host_u8`: 224² uint8 crops sitting in PINNED
+    host memory → double-buffered asynchronous copies on a copy stream → mcm_score_u8 (ToTensor + Normalize fused into the
+    patch gather).  `host_raw`: variable-size decoded RGB images (an ImageNet-like size mix, mean ≈ 0.5 MB) → packed into
+    one pinned buffer per batch by the host → ONE copy per batch → mcm_resize_crop_u8 (Resize 224 + CenterCrop 224,
+    bit-exact vs Pillow) → mcm_score_u8.  JPEG decode itself is host-CPU work outside this path.  Outside the timed
+    region of the headline number; reported next to it."""
+    import numpy as np
+    import torch
+
+    from mcm_amd.ingest import PackedImagePipe, PinnedBatchPipe
+
+    S = net.geo.image_size
+    out = {}
+    sc = torch.empty(B, device=net.device)
+    if "host-u8" in which:
+        g = torch.Generator().manual_seed(7)
+        host = [torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(3)]
+        pipe = PinnedBatchPipe(net, B)
+        for px in pipe.stream(host[:2]):  # warm-up: pinned buffers, copy stream, the u8 patchify kernel
+            net.score_images(px, txt, 1.0, "MCM", out=sc)
+        torch.cuda.synchronize()
+        b0, t0 = pipe.bytes_copied, time.perf_counter()
+        for px in pipe.stream(host[i % 3] for i in range(steps)):
+            net.score_images(px, txt, 1.0, "MCM", out=sc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["host_u8"] = {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                          "pcie_gb_per_sec": (pipe.bytes_copied - b0) / dt / 1e9, "bytes_per_image": S * S * 3,
+                          "source": "uint8 [B,224,224,3] crops in pinned host memory, one async copy per batch on a copy "
+                                    "stream, 2 device buffers"}
+        del pipe, host
+    if "host-raw" in which:
+        rng = np.random.default_rng(11)
+        sizes = [(375, 500), (500, 375), (333, 500), (500, 333), (480, 640), (400, 400), (256, 341), (600, 800)]
+        base = {hw: rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8) for hw in sizes}
+        batch = [base[sizes[i % len(sizes)]] for i in range(B)]
+        nbytes = PackedImagePipe.packed_bytes(batch)
+        pipe = PackedImagePipe(net, B, nbytes + (1 << 20), pack_threads=min(16, os.cpu_count() or 1))
+        for px in pipe.stream([batch, batch]):
+            net.score_images(px, txt, 1.0, "MCM", out=sc)
+        torch.cuda.synchronize()
+        b0, t0 = pipe.bytes_copied, time.perf_counter()
+        for px in pipe.stream(batch for _ in range(steps)):
+            net.score_images(px, txt, 1.0, "MCM", out=sc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["host_raw"] = {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                           "pcie_gb_per_sec": (pipe.bytes_copied - b0) / dt / 1e9, "bytes_per_image": nbytes / B,
+                           "pack_threads": pipe.pack_threads,
+                           "source": "decoded RGB images of 8 sizes (256x341 ... 600x800) in pageable host memory, packed "
+                                     "into one pinned buffer and copied once per batch, Resize + CenterCrop on the device"}
+        del pipe
+    return out
+
+
+def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3):
+    """Throughput of one more arm on the same workload, 3 timed steps after one warm-up step, outside the timed region
+    of the headline number: (images/s, GEMM-family TFLOP/s by HIP events, fraction of that dtype's dense MFMA peak)."""
+    import torch
+
+    from mcm_amd.engine import NativeCLIP
+
+    net = NativeCLIP(geo, sd, device=device, precision=precision, max_batch=B, weight_operands=weight_operands,
+                     max_prompt_tokens=max(K * ids.shape[1], 77))
+    try:
+        txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+        out = torch.empty(B, device=px.device)
+        net.score_images(px, txt, 1.0, "MCM", out=out)
+        net.profile(True)
+        net.profile_read()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.score_images(px, txt, 1.0, "MCM", out=out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        g = net.profile_read()["gemm"]
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
+        peak = MFMA_PEAK_TFLOPS[precision]
+        return {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "gemm_tflops": ach, "peak_tflops": peak, "frac": ach / peak if ach else None,
+                "split_weight_gemms": net.split_weights, "finite": bool(torch.isfinite(out).all())}
+    finally:
+        net.close()
 
 
 def respawn_under_torchrun(n):
@@ -259,6 +364,14 @@ def main():
                     help="hard cap on the CPU baseline's timed part (it stops after 256 images); 0 disables it")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="0 disables the sustained-throughput leg")
+    ap.add_argument("--ingest", default="host-u8,host-raw",
+                    help="comma list of ingest legs reported next to the device-resident number (N = 1): host-u8 (pinned "
+                         "224x224 uint8 crops -> copy stream -> mcm_score_u8), host-raw (variable-size decoded images -> one "
+                         "packed copy -> resize/crop on the device -> mcm_score_u8); 'none' skips them")
+    ap.add_argument("--no-arms", action="store_true", help="skip the 3-step runs of the other precision arms (N = 1)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group even for one rank, so that the score all-gather really runs "
+                         "(torchrun --nproc-per-node 1: RCCL on the one device)")
     ap.add_argument("--no-drift", action="store_true", help="skip the AUROC/FPR95 parity leg (N = 1 only)")
     ap.add_argument("--no-hf", action="store_true", help="parity leg without the HF-on-device reference scorer")
     ap.add_argument("--drift-n", type=int, nargs=2, default=[50000, 10000], metavar=("N_ID", "N_OOD"))
@@ -296,7 +409,8 @@ def main():
                          f"`python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     ndev = torch.cuda.device_count()
     shared = ws_env > ndev  # more ranks than devices: logic check only
-    rank, ws, local = mdist.init_from_env(backend="gloo" if shared else None)
+    rank, ws, local = mdist.init_from_env(backend="gloo" if shared else None, force=args.force_collective)
+    coll = mdist.group_active()  # a process group exists (N > 1, or --force-collective): the all-gather runs
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -329,14 +443,14 @@ def main():
     scores = torch.empty((args.steps, B), device=dev)
 
     def barrier():
-        if ws > 1:
+        if coll:
             torch.distributed.barrier()
 
     for i in range(args.warmup):
         if not args.no_profile and i == args.warmup - 1:
             net.profile(True)  # creates the event pool outside the timed region
         net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[0])
-    if ws > 1:  # warm the collective too (RCCL builds its rings on first use)
+    if coll:  # warm the collective too (RCCL builds its rings on first use)
         mdist.all_gather_scores(scores[0], ws * B)
     torch.cuda.synchronize()
     if not args.no_profile:
@@ -354,13 +468,13 @@ def main():
         if args.idle_ms >= 0:  # measurement hook: an idle device between steps (kernel times come from the HIP events)
             torch.cuda.synchronize()
             time.sleep(args.idle_ms * 1e-3)
-    if ws > 1:  # the path's only exchange: per-dataset all-gather of the score shards
+    if coll:  # the path's only exchange: per-dataset all-gather of the score shards
         full = mdist.all_gather_scores(scores.reshape(-1), ws * args.steps * B)
         assert full.numel() == ws * args.steps * B
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if ws > 1:
+    if coll:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -389,6 +503,10 @@ def main():
         sustained = {"steps": n_sus, "seconds": dts, "images_per_sec": ws * n_sus * B / dts}
         if sampler:
             sustained.update(sampler.stop())
+
+    ingest = None
+    if ws == 1 and args.ingest != "none":
+        ingest = ingest_legs(net, txt, B, max(6, min(args.steps, 12)), set(args.ingest.split(",")))
 
     line = None
     if rank == 0:
@@ -424,10 +542,13 @@ def main():
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"
         if args.gemm_variant >= 0:
             line["harness"] = f"libmcm_hip_harness.so, GEMM variant {args.gemm_variant} forced (A/B run, not the shipped policy)"
-        if ws > 1:
+        if coll:
             line["collective"] = ("gloo: %d ranks share %d device(s), RCCL refuses duplicate devices — logic "
                                   "check, not a scaling number" % (ws, ndev)) if shared else \
-                "nccl (RCCL) all_gather_into_tensor of the score shards, inside the timed region"
+                "%s all_gather_into_tensor of the score shards (device tensors, no host bounce), inside the timed region" % \
+                ("nccl (RCCL)" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend())
+        if ingest:
+            line["ingest"] = ingest
         if sustained:
             line["sustained_images_per_sec"] = sustained.pop("images_per_sec")
             line["sustained"] = sustained
@@ -485,13 +606,31 @@ def main():
             native = first_scores.cpu().numpy() if args.steps >= 1 else None
             line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
     net.close()
+    px0 = bufs[0]
     del bufs, scores
+    if rank == 0 and ws == 1 and not args.no_arms:
+        # The other arms on the same workload, witnessed by the same run (3 timed steps each): the exact-fp32 arm (the
+        # reference's own precision: fp32 everywhere), bf16 (the dtype BASELINE.md names), and the split-weight fp16 arm on
+        # fp32-VALUED seeded weights (what a checkpoint that is not fp16-exact runs, include/mcm.h MCM_WEIGHTS_*)
+        arms = {}
+        for name, prec, regime, wo in (("fp32", "fp32", args.weights_regime, "auto"),
+                                       ("bf16", "bf16", args.weights_regime, "auto"),       # fp16 values are not bf16 numbers: split
+                                       ("bf16_single_operand", "bf16", args.weights_regime, "single"),  # BASELINE.md's dtype, rounded weights
+                                       ("fp16_split_weights", "fp16", "fp32", "split")):
+            if prec == args.precision and wo == args.weight_operands and regime == args.weights_regime:
+                continue
+            torch.cuda.empty_cache()
+            arms[name] = arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
+                                 ids, px0, local)
+            arms[name]["weights_regime"] = regime
+        line["arms"] = arms
+    del px0
     torch.cuda.empty_cache()
     if rank == 0:
         if ws == 1 and not args.no_drift and args.precision != "fp32":
             line["parity"] = parity_leg(args, K, B, local)
         print(json.dumps(line), flush=True)
-    if ws > 1:
+    if coll:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

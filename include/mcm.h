@@ -186,7 +186,8 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
  * src_dev_ptrs / heights / widths are HOST arrays of length B: device pointers to [H_i, W_i, 3]
  * uint8 RGB images and their sizes.  dst_dev [B, S, S, 3] uint8 is the layout mcm_score_u8 and
  * mcm_encode_image_u8 take.  MCM_ERANGE: B > max_batch, or a scale factor above 31 (more filter
- * taps than the kernel holds).  Synchronises `stream` before reusing its staging buffer. */
+ * taps than the kernel holds).  Asynchronous on `stream` (the geometry is staged through a small ring of pinned
+ * buffers; the call never drains the stream), so a batch can be resized while the previous one is being scored. */
 int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const int32_t* heights,
                        const int32_t* widths, int32_t B, uint8_t* dst_dev, void* stream);
 

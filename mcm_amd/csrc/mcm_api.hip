@@ -67,7 +67,12 @@ struct mcm_handle {
   float* feat = nullptr;          // [max_batch, proj_dim] scratch for mcm_score
   int32_t *ids_dev = nullptr, *rowidx_dev = nullptr;
   int32_t *ids_pin = nullptr, *rowidx_pin = nullptr;
-  PrepImage *prep_pin = nullptr, *prep_dev = nullptr;  // mcm_resize_crop_u8 geometry, max_batch entries
+  // mcm_resize_crop_u8 geometry: a ring of PREP_RING pinned staging buffers (max_batch entries each) so that a call never
+  // has to drain the stream before it may write the next batch's geometry; prep_ev[k] = "the copy out of slot k is done"
+  static constexpr int PREP_RING = 4;
+  PrepImage *prep_pin = nullptr, *prep_dev = nullptr;
+  hipEvent_t prep_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned prep_next = 0;
   int64_t max_rows = 0;
   size_t hbuf_bytes = 0;
   std::vector<void*> owned;       // every hipMalloc'd pointer
@@ -326,7 +331,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   };
   bool ln1_folded = false;  // h->ln holds gamma1 o x and h->fold_rs the row statistics of this layer's layer_norm1
   // LayerNorm in the tail: the residual GEMMs of whole-batch layers also produce the LayerNorm that follows them
-  const bool tail_ok = g_ln_tail && !can_fold && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
+  const bool tail_ok = g_ln_tail && !can_fold && !t.split && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
                        gemm_ln_tail_ok(P, Mp, D);
   auto with_tail = [&](GemmArgs& g, const float* gamma, const float* beta) {
     g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
@@ -563,7 +568,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc ids");
   if (!rc && hipHostMalloc((void**)&h->rowidx_pin, (size_t)mt * sizeof(int32_t)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc rowidx");
-  if (!rc) rc = dev_alloc(h, (void**)&h->prep_dev, (size_t)c.max_batch * sizeof(PrepImage));
+  if (!rc) rc = dev_alloc(h, (void**)&h->prep_dev, (size_t)mcm_handle::PREP_RING * c.max_batch * sizeof(PrepImage));
 #if defined(MCM_HARNESS) || defined(MCM_LN_FOLD)  // LayerNorm fold (A/B arm): row moments and row statistics
   if (!rc && c.precision != MCM_PREC_F32 && c.v_width % 256 == 0 && c.v_mlp % 256 == 0) {
     rc = dev_alloc(h, (void**)&h->fold_part, (size_t)(c.v_width / 64) * mv * sizeof(float2));
@@ -581,8 +586,10 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
 #endif
   if (!rc) rc = dev_alloc(h, (void**)&h->sat_dev, 16);
   if (!rc && hipMemset(h->sat_dev, 0, 16) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset saturation counter");
-  if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)c.max_batch * sizeof(PrepImage)) != hipSuccess)
+  if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)mcm_handle::PREP_RING * c.max_batch * sizeof(PrepImage)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc prep");
+  for (int k = 0; !rc && k < mcm_handle::PREP_RING; ++k)
+    if (hipEventCreateWithFlags(&h->prep_ev[k], hipEventDisableTiming) != hipSuccess) rc = fail(h, MCM_EHIP, "hipEventCreate prep");
   if (rc) {
     g_create_err = h->err;
     mcm_destroy(h);
@@ -599,6 +606,8 @@ void mcm_destroy(mcm_handle* h) {
   if (h->ids_pin) (void)hipHostFree(h->ids_pin);
   if (h->rowidx_pin) (void)hipHostFree(h->rowidx_pin);
   if (h->prep_pin) (void)hipHostFree(h->prep_pin);
+  for (auto& e : h->prep_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev_pool) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -863,9 +872,12 @@ int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const 
   if (B > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds max_batch");
   const int32_t S = h->cfg.image_size;
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(h, hipStreamSynchronize(s));  // the pinned geometry buffer is reused
+  const unsigned slot = h->prep_next++ % mcm_handle::PREP_RING;
+  PrepImage* pin = h->prep_pin + (size_t)slot * h->cfg.max_batch;
+  PrepImage* dev = h->prep_dev + (size_t)slot * h->cfg.max_batch;
+  HIP_TRY(h, hipEventSynchronize(h->prep_ev[slot]));  // the copy out of this slot, PREP_RING calls ago (long done: no stall)
   for (int32_t b = 0; b < B; ++b) {
-    PrepImage& g = h->prep_pin[b];
+    PrepImage& g = pin[b];
     if (!src_dev_ptrs[b] || heights[b] <= 0 || widths[b] <= 0) return fail(h, MCM_EINVAL, "bad image");
     g.src = src_dev_ptrs[b];
     if (!prep_geometry(heights[b], widths[b], S, g)) return fail(h, MCM_EINVAL, "image smaller than the crop");
@@ -874,8 +886,9 @@ int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const 
     if (taps_x > prep_max_taps() || taps_y > prep_max_taps())
       return fail(h, MCM_ERANGE, "downscale factor above 31 is not supported");
   }
-  HIP_TRY(h, hipMemcpyAsync(h->prep_dev, h->prep_pin, (size_t)B * sizeof(PrepImage), hipMemcpyHostToDevice, s));
-  HIP_TRY(h, launch_resize_crop(h->prep_dev, B, S, dst_dev, s));
+  HIP_TRY(h, hipMemcpyAsync(dev, pin, (size_t)B * sizeof(PrepImage), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipEventRecord(h->prep_ev[slot], s));
+  HIP_TRY(h, launch_resize_crop(dev, B, S, dst_dev, s));
   return MCM_OK;
 }
 

@@ -350,6 +350,24 @@ class NativeCLIP:
         self._check(self._lib.mcm_resize_crop_u8(self._h, ptrs, hs, ws, B, out.data_ptr(), _stream_ptr()))
         return out
 
+    def resize_crop_packed(self, packed, offsets, heights, widths, out=None):
+        """`resize_crop` over images that already sit back to back in ONE device buffer (`packed`: uint8 1-D device
+        tensor; image i = [heights[i], widths[i], 3] at byte offset offsets[i]) — what mcm_amd.ingest.PackedImagePipe
+        uploads with one copy per batch.  Asynchronous on the current stream."""
+        import torch
+
+        B, S = len(offsets), self.geo.image_size
+        if packed.dtype != torch.uint8 or not packed.is_cuda:
+            raise ValueError("packed must be a uint8 device tensor")
+        base = packed.data_ptr()
+        ptrs = (ctypes.c_void_p * B)(*[base + int(o) for o in offsets])
+        hs = (ctypes.c_int32 * B)(*[int(v) for v in heights])
+        ws = (ctypes.c_int32 * B)(*[int(v) for v in widths])
+        if out is None:
+            out = torch.empty((B, S, S, 3), device=self.device, dtype=torch.uint8)
+        self._check(self._lib.mcm_resize_crop_u8(self._h, ptrs, hs, ws, B, out.data_ptr(), _stream_ptr()))
+        return out
+
     def measures(self, pos_scores, neg_scores, recall_level: float = 0.95, negate: bool = False):
         """`get_measures` (reference utils/detection_util.py:108-119) on device score vectors:
         (auroc, aupr, fpr) with ID = positive class; `negate=True` evaluates on -score, which is

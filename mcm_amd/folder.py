@@ -79,22 +79,42 @@ class ImageFolderU8:
     def shard(self, lo: int, hi: int) -> "ImageFolderU8":
         return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi, self.workers)
 
-    def __iter__(self) -> Iterator:
+    def decoded_batches(self) -> Iterator:
+        """Host side only: `(list of decoded uint8 [H,W,3] arrays, labels int64 [b])` per batch, in dataset order; with
+        `workers` > 1 batch i+1 is decoded by the pool while the consumer works on batch i."""
         import torch
         from concurrent.futures import ThreadPoolExecutor
 
         starts = list(range(self.lo, self.hi, self.batch_size))
         chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
+        labels_of = lambda s: torch.tensor([t for _, t in chunk_of(s)], dtype=torch.long)  # noqa: E731
         if self.workers <= 1:
             for s in starts:
-                chunk = chunk_of(s)
-                imgs = [torch.from_numpy(_decode_rgb(p)) for p, _ in chunk]
-                yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk], dtype=torch.long)
+                yield [_decode_rgb(p) for p, _ in chunk_of(s)], labels_of(s)
             return
-        with ThreadPoolExecutor(self.workers) as pool:
+        pool = ThreadPoolExecutor(self.workers)
+        try:
             submit = lambda s: [pool.submit(_decode_rgb, p) for p, _ in chunk_of(s)]  # noqa: E731
             pending = submit(starts[0]) if starts else None
             for i, s in enumerate(starts):
                 futs, pending = pending, (submit(starts[i + 1]) if i + 1 < len(starts) else None)
-                imgs = [torch.from_numpy(f.result()) for f in futs]
-                yield self.net.resize_crop(imgs), torch.tensor([t for _, t in chunk_of(s)], dtype=torch.long)
+                yield [f.result() for f in futs], labels_of(s)
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
+
+    def __iter__(self) -> Iterator:
+        """Decode pool → ONE packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on
+        the device (mcm_amd.ingest.PackedImagePipe): batch i+1 is decoded, packed and copied while batch i is scored."""
+        from .ingest import PackedImagePipe
+
+        labels = []
+
+        def images():
+            for imgs, lab in self.decoded_batches():
+                labels.append(lab)
+                yield imgs
+
+        pipe = PackedImagePipe(self.net, self.batch_size, self.batch_size * 512 * 512 * 3 // 2,   # (slots grow on demand)
+                               pack_threads=min(8, max(1, self.workers)))
+        for i, dev_batch in enumerate(pipe.stream(images())):
+            yield dev_batch, labels[i]

@@ -1,0 +1,217 @@
+"""Host → device ingest for the uint8 path (§7 hard part 4: feeding ≥ 10k img/s).
+
+The reference feeds its model through a DataLoader of fp32 [b,3,224,224] tensors and a synchronous `.cuda()` per batch
+(utils/detection_util.py:222-223: 602 KB per image over PCIe).  Here the host hands over uint8 pixels — 150 KB per
+image for 224² crops — in PINNED memory, one asynchronous copy per batch on a copy stream, double-buffered against the
+scoring stream; everything after the copy (Resize + CenterCrop when the images are raw, ToTensor + Normalize fused into
+the patch gather) runs on the device.
+
+  PinnedBatchPipe   fixed-size uint8 [B,S,S,3] batches (already cropped on the host, e.g. by a JPEG decoder that resizes)
+  PackedImagePipe   variable-size decoded images [H_i,W_i,3]: packed back to back into ONE pinned buffer, ONE copy per
+                    batch, then `mcm_resize_crop_u8` over device pointers into the packed buffer (round 3 uploaded every
+                    image with its own synchronous `.to(device)`: 512 unpinned copies per batch on the compute stream)
+
+PyTorch is plumbing here (pinned allocations, streams, events); no arithmetic.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Sequence, Tuple
+
+import numpy as np
+
+
+class _Slot:
+    def __init__(self, nbytes: int, device):
+        import torch
+
+        self.host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.copied = torch.cuda.Event()      # the H2D copy into `dev` has finished
+        self.consumed = torch.cuda.Event()    # the compute stream is done reading `dev`
+        self.used = False
+
+
+class _Pipe:
+    """Two (or more) pinned-host / device buffer pairs and a copy stream.  `stage(i)` hands out slot i's pinned host
+    view once the compute stream has finished with the slot's previous contents; `push(slot, nbytes)` issues the
+    asynchronous copy; `ready(slot)` makes the current (compute) stream wait for it."""
+
+    def __init__(self, net, slot_bytes: int, depth: int = 2):
+        import torch
+
+        self.net, self.device = net, net.device
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = [_Slot(int(slot_bytes), self.device) for _ in range(max(2, depth))]
+        self.bytes_copied = 0
+
+    def stage(self, i: int) -> "_Slot":
+        s = self.slots[i % len(self.slots)]
+        if s.used:
+            s.consumed.synchronize()  # host side: do not overwrite pinned memory a copy may still read ...
+            s.copied.synchronize()
+        return s
+
+    def push(self, s: "_Slot", nbytes: int):
+        import torch
+
+        with torch.cuda.stream(self.copy_stream):
+            if s.used:
+                self.copy_stream.wait_event(s.consumed)  # ... nor device memory the scorer may still read
+            s.dev[:nbytes].copy_(s.host[:nbytes], non_blocking=True)
+            s.copied.record(self.copy_stream)
+        s.used = True
+        self.bytes_copied += int(nbytes)
+
+    def ready(self, s: "_Slot"):
+        import torch
+
+        torch.cuda.current_stream(self.device).wait_event(s.copied)
+
+    def done(self, s: "_Slot"):
+        import torch
+
+        s.consumed.record(torch.cuda.current_stream(self.device))
+
+
+class PinnedBatchPipe(_Pipe):
+    """uint8 [b,S,S,3] host batches → device batches, copy of batch i+1 overlapped with the scoring of batch i.
+
+        pipe = PinnedBatchPipe(net, max_batch)
+        for dev_batch in pipe.stream(host_batches):     # host_batches: iterable of uint8 arrays / tensors [b,S,S,3]
+            scores = net.score_images(dev_batch, bank)  # on the current stream
+    """
+
+    def __init__(self, net, max_batch: int, depth: int = 2):
+        S = net.geo.image_size
+        self.S, self.max_batch = S, int(max_batch)
+        super().__init__(net, self.max_batch * S * S * 3, depth)
+
+    def _push_batch(self, s: _Slot, batch) -> int:
+        import torch
+
+        t = batch if hasattr(batch, "is_pinned") else torch.from_numpy(np.ascontiguousarray(batch))
+        if t.dtype != torch.uint8 or t.dim() != 4 or tuple(t.shape[1:]) != (self.S, self.S, 3) or t.shape[0] > self.max_batch:
+            raise ValueError(f"batches must be uint8 [b<={self.max_batch},{self.S},{self.S},3], got {tuple(t.shape)} {t.dtype}")
+        n = t.numel()
+        if t.is_pinned() and t.is_contiguous():
+            # already in pinned memory (a decoder that writes into pinned buffers): DMA straight out of it; the caller must
+            # not overwrite the batch before the copy has run (`copied` of the slot; any later batch of this pipe implies it)
+            with torch.cuda.stream(self.copy_stream):
+                if s.used:
+                    self.copy_stream.wait_event(s.consumed)
+                s.dev[:n].copy_(t.reshape(-1), non_blocking=True)
+                s.copied.record(self.copy_stream)
+            s.used = True
+            self.bytes_copied += n
+        else:
+            s.host[:n].copy_(t.reshape(-1))  # pageable source: one host memcpy into the slot's pinned buffer
+            self.push(s, n)
+        return t.shape[0]
+
+    def stream(self, host_batches: Iterable) -> Iterator:
+        it = iter(host_batches)
+        pending = None  # (slot, b) whose copy has been issued
+        i = 0
+        for batch in it:
+            s = self.stage(i)
+            b = self._push_batch(s, batch)
+            if pending is not None:
+                yield from self._emit(pending)
+            pending = (s, b)
+            i += 1
+        if pending is not None:
+            yield from self._emit(pending)
+
+    def _emit(self, pending):
+        s, b = pending
+        self.ready(s)
+        yield s.dev[: b * self.S * self.S * 3].view(b, self.S, self.S, 3)
+        self.done(s)
+
+
+class PackedImagePipe(_Pipe):
+    """Variable-size decoded RGB images → uint8 [b,S,S,3] device batches (Resize + CenterCrop on the device, bit-exact
+    against Pillow: mcm_resize_crop_u8), ONE packed copy per batch.
+
+        pipe = PackedImagePipe(net, max_batch, max_bytes_per_batch)
+        for dev_batch in pipe.stream(batches_of_images):   # each item: a list of uint8 [H,W,3] arrays
+            scores = net.score_images(dev_batch, bank)
+    """
+
+    ALIGN = 16  # every image starts on a 16-byte boundary of the packed buffer
+
+    def __init__(self, net, max_batch: int, max_bytes_per_batch: int, depth: int = 2, pack_threads: int = 1):
+        self.max_batch = int(max_batch)
+        super().__init__(net, int(max_bytes_per_batch), depth)
+        import torch
+
+        # packing a batch is a host memcpy of every image into the pinned buffer (~0.3 GB per 512 raw images): numpy
+        # releases the GIL for it, so a few threads share it
+        self.pack_threads = max(1, int(pack_threads))
+        self._pool = None
+        if self.pack_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(self.pack_threads)
+
+        S = net.geo.image_size
+        self.out = [torch.empty((self.max_batch, S, S, 3), dtype=torch.uint8, device=self.device) for _ in self.slots]
+
+    @staticmethod
+    def packed_bytes(images: Sequence) -> int:
+        a = PackedImagePipe.ALIGN
+        return sum((int(np.prod(im.shape)) + a - 1) // a * a for im in images)
+
+    def _fill(self, s: _Slot, images: Sequence) -> Tuple[List[int], List[int], List[int], int]:
+        import torch
+
+        if len(images) > self.max_batch:
+            raise ValueError(f"{len(images)} images exceed max_batch {self.max_batch}")
+        arrs = []
+        for im in images:
+            a = im.numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("images must be uint8 [H, W, 3] RGB")
+            arrs.append(a)
+        need = self.packed_bytes(arrs)
+        if need > s.host.numel():  # a batch larger than any seen so far: this slot grows (it is idle: stage() waited)
+            grown = _Slot(int(need * 1.25) + (1 << 20), self.device)
+            grown.used, grown.consumed, grown.copied = s.used, s.consumed, s.copied
+            self.slots[self.slots.index(s)] = grown
+            s = grown
+        offs, hs, ws, o = [], [], [], 0
+        hv = s.host.numpy()
+        for a in arrs:
+            offs.append(o)
+            hs.append(a.shape[0])
+            ws.append(a.shape[1])
+            o += (a.size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+
+        def put(lo, hi):
+            for a, off in zip(arrs[lo:hi], offs[lo:hi]):
+                hv[off:off + a.size] = a.reshape(-1)
+
+        if self._pool is None or len(arrs) < 2 * self.pack_threads:
+            put(0, len(arrs))
+        else:
+            step = -(-len(arrs) // self.pack_threads)
+            list(self._pool.map(lambda lo: put(lo, min(lo + step, len(arrs))), range(0, len(arrs), step)))
+        return s, offs, hs, ws, o
+
+    def stream(self, batches: Iterable[Sequence]) -> Iterator:
+        pending = None
+        for i, images in enumerate(batches):
+            s, offs, hs, ws, nbytes = self._fill(self.stage(i), images)
+            self.push(s, nbytes)
+            if pending is not None:
+                yield from self._emit(*pending)
+            pending = (i, s, offs, hs, ws)
+        if pending is not None:
+            yield from self._emit(*pending)
+
+    def _emit(self, i, s, offs, hs, ws):
+        self.ready(s)
+        out = self.out[i % len(self.slots)]
+        b = len(offs)
+        yield self.net.resize_crop_packed(s.dev, offs, hs, ws, out=out[:b])
+        self.done(s)

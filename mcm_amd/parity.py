@@ -32,10 +32,16 @@ HEADLINE_PIXELS = dict(amp=1.5, tile=0.0, weights="fp16-exact")
 CONFIG3_OOD_SETS = (("iNaturalist", 10000, 11), ("SUN", 10000, 12), ("places365", 10000, 13), ("dtd", 5640, 14))
 
 
-# A second operating point: the same construction with a strong per-class texture, ID and OOD sets at
-# different strengths, so that a random-init tower gives a real checkpoint's kind of numbers — a score spread of a few %
-# of |score| and a well-separated AUROC — instead of the ordering stress above (tools/spread_probe.py chose the values).
-REALISTIC_PIXELS = dict(amp=1.5, tile=30.0, tile_ood=3.0, weights="fp16-exact")
+# A second operating point.  What a random-init tower can be made to give (tools/spread_probe.py,
+# profiles/r04_b_spread_probe.txt): a strong per-class texture (`tile`) widens the per-image score spread from 0.13 % to
+# 0.6 % of |score| (std 1.4e-6 -> 6.5e-6; it saturates there — at T = 1 and K = 1000 the softmax is nearly flat,
+# d score / d cos = 1/K, so even a real checkpoint's cosines spread the score by only a few 1e-5), which puts fp16's
+# score noise at ~0.1 % of the spread instead of 0.4 %: a real checkpoint's ratio.  What no pixel regime gives a random
+# tower is SEPARATION (AUROC stays 0.5 +- 0.02): `operating_point=0.9` therefore builds the ID / OOD split from the
+# reference arm's own scores — image i of the scored pool is called ID with probability sigmoid(-a z_i), z the
+# standardised reference score, `a` found by bisection so that the reference's AUROC is the target — and every arm is
+# then evaluated on that same split of the same images.
+REALISTIC_PIXELS = dict(amp=1.5, tile=30.0, tile_ood=30.0, weights="fp16-exact")
 
 
 def _arm_spec(arm: str):
@@ -51,7 +57,7 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                   tile: float = 0.0, weights: str = "fp32", seed: int = 1,
                   external: Optional[Dict[str, Callable]] = None,
                   ood_sets: Optional[Sequence] = None, tile_ood: Optional[float] = None,
-                  state_dict: Optional[Dict] = None) -> Dict:
+                  state_dict: Optional[Dict] = None, operating_point: Optional[float] = None) -> Dict:
     """weights="fp16-exact": every parameter of the seeded state dict is rounded to the nearest fp16 value
     first (for ALL arms, the fp32 reference included) — the situation of the reference's checkpoints, whose
     Linear / conv / projection weights were trained and released in fp16, so an fp16 operand copy of them is
@@ -61,7 +67,9 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
     arm are then the differences of the AVG row (mean of the per-set metrics), `per_set` holds each set's own and
     `max_set` the largest per-set difference (what "identical FPR95 per dataset" is judged on).
     tile_ood: texture strength of the OOD sets when it differs from the ID set's `tile`.
-    state_dict: score with these parameters instead of the seeded ones (`weights` then only labels the result)."""
+    state_dict: score with these parameters instead of the seeded ones (`weights` then only labels the result).
+    operating_point: also report every arm on an ID / OOD split of ALL scored images that gives the reference arm this
+    AUROC (`out["operating_point"]`; see REALISTIC_PIXELS)."""
     import torch
 
     from .config import geometry
@@ -151,11 +159,63 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             out["reference"]["vs_external"] = {e: delta(ref, e) for e in ext}
             for p in names[1:]:
                 out["arms"][p]["vs_external"] = {e: delta(p, e) for e in ext}
+        if operating_point is not None:
+            out["operating_point"] = _operating_point(nets[ref], {p: torch.cat([scores[p][t] for t in tags])
+                                                                  for p in names + list(ext)}, ref, float(operating_point),
+                                                      list(ext))
         return out
     finally:
         for n in nets.values():
             n.close()
         ext.clear()
+
+
+def _operating_point(net, pool: Dict, ref: str, target: float, ext: Sequence[str], seed: int = 97) -> Dict:
+    """ID / OOD split of a scored pool that gives the reference arm AUROC = target (see REALISTIC_PIXELS), and every
+    arm's metrics on that split.  `pool[p]` = scores of arm p for the same images, in the same order."""
+    import torch
+
+    s_ref = pool[ref].double()
+    z = ((s_ref - s_ref.mean()) / s_ref.std()).float()
+    u = torch.rand(z.numel(), generator=torch.Generator(device=z.device).manual_seed(seed), device=z.device)
+
+    def split(a):  # scores are negated confidences: the lower, the more ID
+        return u < torch.sigmoid(-a * z)
+
+    def auroc_of(a):
+        m = split(a)
+        return net.measures(pool[ref][m], pool[ref][~m], negate=True)[0]
+
+    lo, hi = 0.0, 64.0
+    for _ in range(40):  # AUROC(a) rises from 0.5 monotonically
+        mid = 0.5 * (lo + hi)
+        if auroc_of(mid) < target:
+            lo = mid
+        else:
+            hi = mid
+    a = 0.5 * (lo + hi)
+    m = split(a)
+    n_id, n_ood = int(m.sum()), int((~m).sum())
+    meas = {p: net.measures(pool[p][m], pool[p][~m], negate=True) for p in pool}
+    r = meas[ref]
+    out = {"target_auroc": target, "a": a, "n_id": n_id, "n_ood": n_ood,
+           "reference": {"auroc": r[0], "aupr": r[1], "fpr95": r[2], "score_std": float(pool[ref].std()),
+                         "score_mean": float(pool[ref].mean())}, "arms": {}}
+
+    def delta(p, q):
+        return {"d_auroc": abs(meas[p][0] - meas[q][0]), "d_aupr": abs(meas[p][1] - meas[q][1]),
+                "d_fpr95": abs(meas[p][2] - meas[q][2]), "d_fpr95_images": round(abs(meas[p][2] - meas[q][2]) * n_ood),
+                "rms_dscore": float((pool[p] - pool[q]).double().pow(2).mean().sqrt())}
+
+    for p in pool:
+        if p == ref or p in ext:
+            continue
+        out["arms"][p] = {"auroc": meas[p][0], "fpr95": meas[p][2], **delta(p, ref)}
+        if ext:
+            out["arms"][p]["vs_external"] = {e: delta(p, e) for e in ext}
+    if ext:
+        out["reference"]["vs_external"] = {e: delta(ref, e) for e in ext}
+    return out
 
 
 def meets_bar(d: Dict, bar: float = 1e-4, fpr_images: int = 1) -> bool:

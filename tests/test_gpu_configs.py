@@ -58,7 +58,7 @@ def test_config1_imagenet10_vs_imagenet20_b16_batch64(tmp_path, monkeypatch, dty
     tok = detection._tokenizer(args, None)
     ids = tok([detection.PROMPT.format(c=c) for c in labels], padding=True, return_tensors="pt")["input_ids"].numpy()
     px = next(iter(DevicePatternLoader(500, 224, 10, 64, torch.device("cuda", 0), ood=False, seed=cli.SEEDS["id"])))[0]
-    o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
+    o = orc.OracleCLIP(geo, synth_state_dict(geo, 0, "fp16-exact"))  # the CLI's default --synthetic-weights
     want = orc.score_features(o.encode_image(px[:16].cpu().numpy()), o.encode_text(ids), 1.0, 0)
     tol = dict(rtol=0, atol=2e-7) if dtype == "fp32" else dict(rtol=0, atol=2e-5)
     np.testing.assert_allclose(s_in[:16], want, **tol)
@@ -104,17 +104,21 @@ def test_config2_imagenet100_bf16_full_size(tmp_path, monkeypatch):
         report[dt] = {k: tuple(abs(x - y) for x, y in zip(runs[dt]["measures"][k], runs["fp32"]["measures"][k]))
                       for k in sizes}
     print("config 2 drift vs the fp32 arm (dAUROC, dAUPR, dFPR95):", report)
-    # The CLI's seeded stand-in weights are fp32-VALUED, the harder of the two weight regimes (a 16-bit arm also rounds
-    # its operand copy of every weight; the reference's checkpoints were released in fp16).  Measured
-    # here at K = 100: fp16 dAUROC 1.9 - 2.0e-4 / dAUPR 1.0 - 1.2e-4 / dFPR95 0 - 2 samples of the OOD set — above the
-    # 1e-4 bar in this regime, and said so; bf16 2.0e-3 / 1.1e-3 / 0.7 - 1.6e-3.  The bounds keep a regression visible;
-    # the north-star bar itself is asserted against HF in both weight regimes by tests/test_gpu_headline_parity.py
-    # (K = 1000, and K = 100 at this config's set sizes).
+    # The CLI's seeded stand-in weights are fp16-exact by default (--synthetic-weights, like the reference's checkpoints).
+    # Round 3 ran this config on fp32-VALUED weights rounded to one operand and recorded fp16 dAUROC 1.9 - 2.0e-4 — the
+    # one measured miss of the bar; `--synthetic-weights fp32` now runs the split-weight GEMMs instead and is held to the
+    # same bar below.  bf16: 8 significand bits in every activation, the documented coarser arm.
+    runs["fp16_fp32w"] = cli.main(common + ["--dtype", "fp16", "--synthetic-weights", "fp32", "--name", "c2_fp16_fp32w"])
+    runs["fp32_fp32w"] = cli.main(common + ["--dtype", "fp32", "--synthetic-weights", "fp32", "--name", "c2_fp32_fp32w"])
+    report["fp16_fp32w"] = {k: tuple(abs(x - y) for x, y in zip(runs["fp16_fp32w"]["measures"][k],
+                                                                  runs["fp32_fp32w"]["measures"][k])) for k in sizes}
+    print("config 2, fp32-valued weights, split-weight fp16 arm vs the fp32 arm:", report["fp16_fp32w"])
     for k, n in sizes.items():
-        da, dp, df = report["fp16"][k]
-        assert da <= 4e-4 and dp <= 3e-4 and df * n <= 3.5, (k, report["fp16"][k])   # FPR95: at most 3 samples
+        for arm in ("fp16", "fp16_fp32w"):
+            da, dp, df = report[arm][k]
+            assert da <= 1e-4 and dp <= 1e-4 and df * n <= 2.5, (arm, k, report[arm][k])   # FPR95: at most 2 samples
         da, dp, df = report["bf16"][k]
-        assert da <= 5e-3 and df <= 1e-2, (k, report["bf16"][k])                  # the documented coarser arm
+        assert da <= 5e-3 and df <= 1e-2, (k, report["bf16"][k])
 
 
 def test_cli_two_ranks_equal_one_rank(tmp_path):

@@ -1,15 +1,27 @@
-"""North-star parity on the headline configuration: full CLIP-ViT-B/16, K = 1000 prompts, 50 000 ID + 10 000 OOD
-images (ImageNet-1k vs one OOD set).  Every native arm is compared with (a) the exact-fp32 MFMA arm and (b) the
-reference's own arithmetic on the SAME images: HF transformers `CLIPModel`, fp32 eager, running on this device
-(oracle/hf_reference.py — the checker; BASELINE.json north_star: "identical AUROC/FPR95 to the HF-CLIP
-reference").  AUROC / AUPR / FPR95 by the device metric kernels.  Both weight regimes are asserted: fp16-exact
-seeded weights (the reference's checkpoints were released in fp16) and fp32-valued seeded weights.
+"""North-star parity ("identical AUROC/FPR95 to the HF-CLIP reference ... to 1e-4", BASELINE.json) where it is stated:
+full towers, the reference's set sizes, every native arm against (a) the exact-fp32 MFMA arm and (b) the reference's own
+arithmetic on the SAME images — HF transformers `CLIPModel`, fp32 eager, on this device (oracle/hf_reference.py, the
+checker).  AUROC / AUPR / FPR95 by the device metric kernels.
+
+The bar, as asserted here for the fp16 arm in BOTH weight regimes (fp16-exact seeded weights = the reference's
+checkpoints, one operand per weight; fp32-valued seeded weights = the split-weight GEMMs, include/mcm.h MCM_WEIGHTS_*):
+  * |dAUROC|, |dAUPR| <= 1e-4 on EVERY OOD set (`max_set`: opposite-sign drifts of different sets cancel in the AVG row);
+  * |dFPR95| <= 1e-4 on the AVG row;
+  * FPR95 of one set is a COUNT of OOD images on the ID side of one threshold — one image of a 10 000-image set IS
+    1e-4.  On the realistic operating point (`operating_point=0.9`, score noise ~0.1 % of the spread) the arm is within
+    ONE image of the reference; on the headline STRESS set (every score within 0.13 % of every other, noise 0.4 % of
+    the spread) the activation rounding of a 16-bit arm moves 0 - 2 images across the threshold depending on the draw
+    (profiles/r03_drift_seeds.json: 2, 0, 0, 2, 1, 2 over six draws) — asserted as <= FPR_IMAGES_STRESS.
 Numbers and the regimes they were measured in: DESIGN.md §2."""
 import json
 
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+BAR = 1e-4
+FPR_IMAGES_STRESS = 2   # per set, on the ordering-stress pixels (see the module docstring)
+FPR_IMAGES = 1          # per set, on the realistic operating point
 
 
 def _external():
@@ -19,6 +31,13 @@ def _external():
     if why is not None:
         pytest.skip(f"transformers unavailable: {why}")
     return {"hf": hf_scorer_factory()}
+
+
+def _assert_bar(vs, what, fpr_images):
+    m = vs["max_set"]
+    assert m["d_auroc"] <= BAR and m["d_aupr"] <= BAR, (what, vs)
+    assert vs["d_fpr95"] <= BAR + 1e-12, (what, vs)                 # the AVG row
+    assert m["d_fpr95_images"] <= fpr_images, (what, vs)            # every set, as a count
 
 
 @pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
@@ -33,41 +52,66 @@ def test_headline_parity_vs_hf_reference(weights):
     # suite compares against the exact-fp32 arm only — that arm equals HF to 4e-7 there too, measured by every default
     # bench.py run (parity.fp32_valued_weights.vs_hf) — to keep `pytest -m gpu` within a few minutes
     with_hf = weights == "fp16-exact"
-    d = measure_drift("ViT-B/16", K=1000, n_id=50000, batch=512, arms=("fp16", "bf16"), ood_sets=CONFIG3_OOD_SETS,
+    arms = ("fp16", "bf16") if with_hf else ("fp16", "fp16:single", "bf16")
+    d = measure_drift("ViT-B/16", K=1000, n_id=50000, batch=512, arms=arms, ood_sets=CONFIG3_OOD_SETS,
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights,
                       external=_external() if with_hf else None)
     print(f"headline parity ({weights} weights):", json.dumps(d))
     ref = d["reference"]
     assert 0.02 < ref["auroc"] < 0.98 and 0.0 < ref["fpr95"] < 1.0          # non-degenerate operating point
+    # the weight form the auto policy chose: one operand per weight exactly when every weight is an fp16 number
+    assert d["weight_operands"]["fp16"]["split"] == (weights == "fp32")
+    assert (d["weight_operands"]["fp16"]["inexact_elements"] == 0) == (weights == "fp16-exact")
     if with_hf:  # (a) the exact-fp32 arm IS the HF computation, to the metric quantum, on every set
         r = ref["vs_external"]["hf"]
         assert r["d_auroc"] <= 1e-5 and r["d_aupr"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12, r
         assert r["rms_dscore"] <= 1e-9, r
-        assert all(v["d_auroc"] <= 1e-5 and v["d_fpr95_images"] <= 1 for v in r["per_set"].values()), r
-    # (b) the benchmarked dtype against HF: the bar of BASELINE.json's north_star on the AVG row.  AUROC and AUPR are
-    # averages over 5e8 (ID, OOD) pairs per set and are held to 1e-4 on every set (measured <= 5e-5).  FPR95 of one set
-    # is a COUNT — the OOD images on the ID side of one threshold, quantum 1e-4 at 10 000 images; on this stress set
-    # (score spread 0.13 % of |score|) fp16's score noise moves 0 - 4 images across it depending on
-    # the draw (profiles/r03_drift_seeds.json), so: the AVG row to 1e-4, every single set to at most 4 images.
+        assert r["max_set"]["d_auroc"] <= 1e-5 and r["max_set"]["d_fpr95_images"] <= 1, r
+    # (b) the benchmarked dtype: the north-star bar on every set (module docstring)
     arm = d["arms"]["fp16"]
     for vs in (arm, arm["vs_external"]["hf"]) if with_hf else (arm,):
-        assert vs["d_auroc"] <= 1e-4 and vs["d_aupr"] <= 1e-4, (weights, vs)
-        assert vs["d_fpr95"] <= 1e-4 + 1e-12, (weights, vs)
-        for name, v in vs["per_set"].items():
-            assert v["d_auroc"] <= 1e-4 and v["d_aupr"] <= 1e-4 and v["d_fpr95_images"] <= 4, (weights, name, v)
-    # bf16 (the dtype BASELINE configs 2/3/5 name) does NOT meet 1e-4 in either regime — measured 1.2e-4 /
-    # 1.1e-3 in AUROC; bounded here so a regression is visible, and reported by bench.py
+        _assert_bar(vs, weights, FPR_IMAGES_STRESS)
+    if not with_hf:
+        # rounds 1 - 3 rounded fp32-valued weights to ONE fp16 operand: a fixed perturbation of the model, measured
+        # 5.4e-5 here and 1.5e-4 (ViT-B/32) / 2.0e-4 (K = 100) elsewhere.  The split form removes it: its score error
+        # is the fp16-exact regime's (activation rounding only), its AUROC drift several times smaller than the rounded form's
+        single = d["arms"]["fp16:single"]
+        assert not d["weight_operands"]["fp16:single"]["split"]
+        assert arm["rms_dscore"] < 0.85 * single["rms_dscore"], (arm["rms_dscore"], single["rms_dscore"])
+        assert arm["d_auroc"] < 0.5 * single["d_auroc"], (arm["d_auroc"], single["d_auroc"])
+    # bf16 (the dtype BASELINE configs 2/3/5 name) does NOT meet 1e-4 in either regime — 8 significand bits in every
+    # activation; measured 1.2e-4 ... 3.7e-4 in AUROC with its weights exact (split); bounded here so a
+    # regression is visible, reported by bench.py and said by the CLI
     b = d["arms"]["bf16"]["vs_external"]["hf"] if with_hf else d["arms"]["bf16"]
-    assert b["d_auroc"] <= 3e-3 and b["d_fpr95"] <= 3e-3, b
+    assert b["d_auroc"] <= 1e-3 and b["d_fpr95"] <= 1.5e-3, b
     assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
-    assert d["fp16_saturation_events"] == {"fp16": 0}, d["fp16_saturation_events"]  # nothing left the fp16 range
+    assert all(v == 0 for v in d["fp16_saturation_events"].values()), d["fp16_saturation_events"]  # nothing left the fp16 range
+
+
+@pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
+def test_realistic_operating_point(weights):
+    """a set on which the reference separates ID from OOD with AUROC 0.9 and fp16's score noise is ~0.1 %
+    of the score spread (a real checkpoint's ratio) — mcm_amd.parity.REALISTIC_PIXELS.  Here the count of FPR95 images
+    means something: the fp16 arm is within one image of the reference."""
+    from mcm_amd.parity import REALISTIC_PIXELS, measure_drift
+
+    d = measure_drift("ViT-B/16", K=1000, n_id=30000, n_ood=30000, batch=500, arms=("fp16", "bf16"),
+                      amp=REALISTIC_PIXELS["amp"], tile=REALISTIC_PIXELS["tile"], tile_ood=REALISTIC_PIXELS["tile_ood"],
+                      weights=weights, operating_point=0.9)
+    op = d["operating_point"]
+    print(f"realistic operating point ({weights} weights):", json.dumps(op))
+    assert abs(op["reference"]["auroc"] - 0.9) <= 2e-3 and min(op["n_id"], op["n_ood"]) >= 10000, op
+    assert op["reference"]["score_std"] > 4e-6                     # 0.4 % of |score| (stress set: 0.13 %)
+    a = op["arms"]["fp16"]
+    assert a["d_auroc"] <= BAR and a["d_aupr"] <= BAR and a["d_fpr95_images"] <= FPR_IMAGES, a
+    assert a["rms_dscore"] <= 2.5e-3 * op["reference"]["score_std"], a  # the noise-to-spread ratio the set was built for
+    assert a["rms_dscore"] < op["arms"]["bf16"]["rms_dscore"]
 
 
 def test_l14_parity_vs_hf_reference():
-    """BASELINE config 4 (ViT-L/14 fp16, batch 256) with 10 000 OOD images, so that FPR95's quantum is 1e-4
-    (round 2 ran 5 000: one sample = 2e-4).  The full 50 000 + 10 000 run is profiles/r03_parity_L14_50k_vs_hf.json
-    (fp16 vs HF: dAUROC 1.2e-5, dFPR95 0; 4 minutes); here 4 000 + 10 000 (50 s).  FPR95 as an image count, see
-    above: measured 0 and 4 images on two draws of a 20 000 + 10 000 set."""
+    """BASELINE config 4 (ViT-L/14 fp16, batch 256) with 10 000 OOD images, so that FPR95's quantum is 1e-4.  The full
+    50 000 + 10 000 run is profiles/r03_parity_L14_50k_vs_hf.json (fp16 vs HF: dAUROC 1.2e-5, dFPR95 0; 4 minutes); here
+    4 000 + 10 000 (50 s)."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
     d = measure_drift("ViT-L/14", K=1000, n_id=4000, n_ood=10000, batch=256, arms=("fp16",),
@@ -77,14 +121,14 @@ def test_l14_parity_vs_hf_reference():
     r = d["reference"]["vs_external"]["hf"]
     assert r["d_auroc"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12, r
     for vs in (d["arms"]["fp16"], d["arms"]["fp16"]["vs_external"]["hf"]):
-        assert vs["d_auroc"] <= 1e-4 and vs["d_aupr"] <= 1e-4 and vs["d_fpr95"] <= 5e-4 + 1e-12, vs
+        assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
 
 
 @pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
 def test_config2_parity_vs_hf_k100(weights):
     """BASELINE config 2's sizes (ImageNet-100 ID vs one 10 000-image OOD set: K = 100, 5 000 + 10 000 images) against
-    HF on this device, both weight regimes.  Measured (profiles/r03_k100_parity.txt): fp16 dAUROC 3.4e-5 / 5.1e-5,
-    dFPR95 1e-4 / 0; bf16 — the dtype the config names — 5.7e-4 / 5.3e-4: it does not meet the bar."""
+    HF on this device, both weight regimes.  Round 3 (one rounded operand per weight): fp16 dAUROC 3.4e-5 / 5.1e-5, and
+    2.0e-4 through the CLI's fp32-valued weights; bf16 — the dtype the config names — 5.7e-4: it does not meet the bar."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
     d = measure_drift("ViT-B/16", K=100, n_id=5000, n_ood=10000, batch=512, arms=("fp16", "bf16"),
@@ -93,6 +137,60 @@ def test_config2_parity_vs_hf_k100(weights):
     r = d["reference"]["vs_external"]["hf"]
     assert r["d_auroc"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12 and r["rms_dscore"] <= 5e-9, r
     vs = d["arms"]["fp16"]["vs_external"]["hf"]
-    assert vs["d_auroc"] <= 1e-4 and vs["d_aupr"] <= 1e-4 and vs["d_fpr95"] <= 4e-4 + 1e-12, vs
+    assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
     b = d["arms"]["bf16"]["vs_external"]["hf"]
     assert b["d_auroc"] <= 3e-3 and b["d_fpr95"] <= 3e-3, b
+
+
+@pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
+def test_b32_parity_vs_fp32_arm(weights):
+    """ViT-B/32 at 50 000 + 10 000: round 3's recorded miss (fp16 dAUROC 1.5e-4 with fp32-valued weights rounded to one
+    operand, profiles/r03_parity_other_checkpoints_vs_hf.txt) — with the split form both regimes meet the bar.  Against
+    the exact-fp32 arm (it equals HF to 2.7e-6 at this geometry, same file)."""
+    from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
+
+    d = measure_drift("ViT-B/32", K=1000, n_id=50000, n_ood=10000, batch=512, arms=("fp16",),
+                      amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights)
+    print(f"B/32 parity ({weights} weights):", json.dumps(d))
+    assert d["weight_operands"]["fp16"]["split"] == (weights == "fp32")
+    vs = d["arms"]["fp16"]
+    assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
+
+
+def test_outlier_channel_stress_checkpoint():
+    """a checkpoint with massive-activation channels (mcm_amd.weights.inject_outlier_channels: six
+    residual channels whose `out_proj` / `fc2` rows are 100 x the rest, as real CLIP ViTs carry) — what seeded weights at
+    HF init scales never exercise.  The fp16 arm must hold the bar against the exact-fp32 arm with NO activation leaving
+    the fp16 range; and a checkpoint that does drive an activation past 65504 must not pass silently."""
+    import warnings
+
+    import numpy as np
+    import torch
+
+    from mcm_amd.config import geometry
+    from mcm_amd.engine import NativeCLIP
+    from mcm_amd.parity import measure_drift
+    from mcm_amd.weights import inject_outlier_channels, synth_state_dict
+
+    geo = geometry("ViT-B/16")
+    base = synth_state_dict(geo, 0, "fp16-exact")
+    sd, ch = inject_outlier_channels(base, geo, channels=6, scale=100.0, gamma_scale=1.0)
+    d = measure_drift("ViT-B/16", K=1000, n_id=20000, n_ood=10000, batch=500, arms=("fp16",), state_dict=sd)
+    print("outlier-channel stress:", json.dumps({k: d[k] for k in ("reference", "arms", "fp16_saturation_events", "weight_operands")}))
+    assert d["fp16_saturation_events"] == {"fp16": 0}
+    a = d["arms"]["fp16"]
+    assert a["d_auroc"] <= BAR and a["d_aupr"] <= BAR and a["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, a
+    # the other side of the watch: fc1 rows scaled until QuickGELU outputs leave the fp16 range -> counted, warned about
+    hot = {k: v.copy() for k, v in base.items()}
+    hot["vision_model.encoder.layers.3.mlp.fc1.weight"][:64, :] *= np.float32(40000.0)
+    net = NativeCLIP(geo, hot, precision="fp16", max_batch=64, max_prompt_tokens=77)
+    try:
+        px = torch.randn((64, 3, 224, 224), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        f = net.get_image_features(px)
+        assert torch.isfinite(f).all()          # saturated, not inf / NaN (MODE.FP16_OVFL)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            n = net.warn_if_saturated("the stress batch")
+        assert n > 0 and any("saturated" in str(x.message) for x in w)
+    finally:
+        net.close()

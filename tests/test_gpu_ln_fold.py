@@ -56,7 +56,7 @@ def test_folded_tower_vs_unfolded_and_fp32(prec, affine):
         want = ref.get_image_features(pixel_values=px, normalize=True).clone()
     finally:
         ref.close()
-    net = NativeCLIP(geo, sd, device=0, precision=prec, max_batch=128, max_prompt_tokens=77, harness=True)
+    net = NativeCLIP(geo, sd, device=0, precision=prec, max_batch=128, max_prompt_tokens=77, harness=True, weight_operands="single")
     try:
         on = _features(net, px, fold=True)     # 128 images: 99 M tiles x 3 > half a round -> ping-pong kernel, fused epilogues
         off = _features(net, px, fold=False)
@@ -84,7 +84,7 @@ def test_fold_batch_invariance_through_the_score_call():
     geo = geometry("ViT-B/16")
     sd = _state(geo, True)
     ids, _ = make_token_ids(50, seed=2)
-    net = NativeCLIP(geo, sd, device=0, precision="fp16", max_batch=160, max_prompt_tokens=50 * 20, harness=True)
+    net = NativeCLIP(geo, sd, device=0, precision="fp16", max_batch=160, max_prompt_tokens=50 * 20, harness=True, weight_operands="single")
     try:
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         g = torch.Generator(device="cuda").manual_seed(6)

@@ -38,7 +38,7 @@ def test_ln_tail_is_bit_identical_to_the_layernorm_launches(ckpt, precision, bat
     geo = geometry(ckpt)
     sd = _affine_state(geo)
     ids, _ = make_token_ids(40, seed=2)
-    net = NativeCLIP(geo, sd, device=0, precision=precision, max_batch=batch, max_prompt_tokens=40 * 20, harness=True)
+    net = NativeCLIP(geo, sd, device=0, precision=precision, max_batch=batch, max_prompt_tokens=40 * 20, harness=True, weight_operands="single")
     try:
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         g = torch.Generator(device="cuda").manual_seed(13)
@@ -66,7 +66,7 @@ def test_ln_tail_in_a_long_run_against_the_fp32_arm():
     geo = geometry("ViT-B/16")
     sd = _affine_state(geo)
     ids, _ = make_token_ids(40, seed=2)
-    net = NativeCLIP(geo, sd, device=0, precision="fp16", max_batch=512, max_prompt_tokens=40 * 20, harness=True)
+    net = NativeCLIP(geo, sd, device=0, precision="fp16", max_batch=512, max_prompt_tokens=40 * 20, harness=True, weight_operands="single")
     try:
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         assert net._lib.mcm_debug_ln_tail(1) == 0

@@ -25,11 +25,13 @@ from mcm_amd.synth import (SyntheticImageSet, SyntheticLoader, class_names, make
 from mcm_amd.weights import synth_state_dict  # noqa: E402
 
 
-def _net(name, precision, **kw):
+def _net(name, precision, regime="fp32", **kw):
+    """regime "fp32": the seeded weights as drawn (a 16-bit arm runs the split-weight GEMMs); "fp16-exact": rounded to
+    fp16 values like the reference's checkpoints (one operand per weight)."""
     from mcm_amd.engine import NativeCLIP
 
     geo = geometry(name)
-    return NativeCLIP(geo, synth_state_dict(geo, 0), precision=precision, **kw)
+    return NativeCLIP(geo, synth_state_dict(geo, 0, regime), precision=precision, **kw)
 
 
 def _unit(a):
@@ -207,10 +209,15 @@ def test_auroc_parity_vs_oracle_b16_2l():
     assert rep["bf16"]["d_auroc_aupr_fpr"][0] <= 5e-3, rep
 
 
-@pytest.fixture(scope="module", params=["fp16", "bf16"])
+@pytest.fixture(scope="module", params=[("fp16", "fp16-exact"), ("fp16", "fp32"), ("bf16", "fp16-exact")],
+                ids=["fp16-single-operand", "fp16-split-weights", "bf16"])
 def b16(request):
-    """Full-size B/16 handle in the default dtype (fp16) and in BASELINE's bf16."""
-    net = _net("ViT-B/16", request.param, max_batch=512, max_prompt_tokens=1000 * 20)
+    """Full-size B/16 handle: the default dtype (fp16) in both weight forms — one operand per weight on fp16-exact
+    weights (the headline path), W_hi + W_lo on fp32-valued ones — and BASELINE's bf16."""
+    prec, regime = request.param
+    net = _net("ViT-B/16", prec, regime, max_batch=512, max_prompt_tokens=1000 * 20)
+    net._regime = regime
+    assert net.split_weights == (regime == "fp32" or prec == "bf16")  # (fp16 values are not bf16 numbers)
     yield net
     net.close()
 
@@ -251,7 +258,7 @@ def test_full_size_bf16_vs_oracle_small_sample(b16):
     from oracle import oracle as orc
 
     geo = geometry("ViT-B/16")
-    o = orc.OracleCLIP(geo, synth_state_dict(geo, 0))
+    o = orc.OracleCLIP(geo, synth_state_dict(geo, 0, b16._regime))
     px, _ = make_pixels(4, 224, 10, ood=False, seed=9)
     want = o.encode_image(px)
     got = b16.get_image_features(pixel_values=torch.from_numpy(px).cuda(), normalize=True).cpu().numpy()

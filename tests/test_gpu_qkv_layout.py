@@ -19,7 +19,7 @@ def test_head_major_qkv_is_bit_identical(ckpt, precision, batch):
     geo = geometry(ckpt)
     sd = synth_state_dict(geo, 0)
     ids, _ = make_token_ids(40, seed=2)
-    net = NativeCLIP(geo, sd, device=0, precision=precision, max_batch=batch, max_prompt_tokens=40 * 20, harness=True)
+    net = NativeCLIP(geo, sd, device=0, precision=precision, max_batch=batch, max_prompt_tokens=40 * 20, harness=True, weight_operands="single")
     try:
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         g = torch.Generator(device="cuda").manual_seed(11)

@@ -21,11 +21,11 @@ from mcm_amd.synth import class_names, make_pixels, make_token_ids  # noqa: E402
 from mcm_amd.weights import synth_state_dict  # noqa: E402
 
 
-def _net(name, precision, **kw):
+def _net(name, precision, regime="fp32", **kw):
     from mcm_amd.engine import NativeCLIP
 
     geo = geometry(name)
-    return NativeCLIP(geo, synth_state_dict(geo, 0), precision=precision, **kw)
+    return NativeCLIP(geo, synth_state_dict(geo, 0, regime), precision=precision, **kw)
 
 
 def test_prompt_ensemble_80_templates_at_size_vs_oracle():
@@ -67,8 +67,9 @@ def test_l14_fp16_batch256_properties():
     """BASELINE config 4's geometry and dtype at its batch: ViT-L/14 (257 tokens, width 1024, 24 layers),
     fp16 operands, 256 images, K = 1000."""
     K, B = 1000, 256
-    net = _net("ViT-L/14", "fp16", max_batch=B, max_prompt_tokens=K * 16)
+    net = _net("ViT-L/14", "fp16", "fp16-exact", max_batch=B, max_prompt_tokens=K * 16)  # config 4's regime: one operand per weight
     try:
+        assert not net.split_weights
         ids, _ = make_token_ids(K, seed=2)
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         assert txt.shape == (K, 768)

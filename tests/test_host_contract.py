@@ -158,14 +158,10 @@ def test_image_folder_decode_pool_keeps_order(tmp_path):
             p.parent.mkdir(parents=True, exist_ok=True)
             Image.fromarray(rng.integers(0, 256, (8 + i, 9, 3), dtype=np.uint8)).save(p)
 
-    class Net:  # resize_crop stand-in: hand the decoded images back
-        def resize_crop(self, imgs):
-            return [im.clone() for im in imgs]
-
-    def walk(workers):
+    def walk(workers):  # the host half of the loader (the device half — packed upload + resize/crop — is GPU-tested)
         out = []
-        for imgs, labels in ImageFolderU8(str(tmp_path), Net(), 3, workers=workers):
-            out.append(([im.numpy() for im in imgs], labels.tolist()))
+        for imgs, labels in ImageFolderU8(str(tmp_path), None, 3, workers=workers).decoded_batches():
+            out.append((imgs, labels.tolist()))
         return out
 
     serial, pooled = walk(1), walk(4)

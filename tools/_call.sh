@@ -1,7 +1,6 @@
 #!/bin/bash
-# scratch driver (round 4, call 1): split-weight arm — new tests, model tests, bench in both weight regimes
-mkdir -p gpurun_out/r4c01
-O=$PWD/gpurun_out/r4c01
-timeout 900 python -m pytest tests/test_gpu_split_weights.py tests/test_gpu_c_abi.py tests/test_gpu_model.py -m gpu -x -q > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt
-timeout 300 python bench.py --no-drift --cpu-seconds 0 > $O/bench_fp16exact.json 2> $O/bench_fp16exact.err; tail -c 600 $O/bench_fp16exact.json
-timeout 300 python bench.py --no-drift --cpu-seconds 0 --weights-regime fp32 > $O/bench_fp32w_split.json 2> $O/bench_fp32w_split.err; tail -c 600 $O/bench_fp32w_split.json
+# scratch driver (round 4, call 3): whole GPU suite on the ABI-v2 tree, then the default bench line
+mkdir -p gpurun_out/r4c03
+O=$PWD/gpurun_out/r4c03
+timeout 1800 python -m pytest tests -m gpu -q -x --durations=25 > $O/pytest.txt 2>&1; tail -45 $O/pytest.txt
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json; tail -5 $O/bench_default.err
