@@ -384,6 +384,7 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
     ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
     ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
+    ap.add_argument("--nsplit", type=int, default=1, help="A/B hook (harness library): QKV / fc1 as n column-block launches")
     ap.add_argument("--idle-ms", type=float, default=-1.0,
                     help="measurement hook (DESIGN.md 5.5, the energy reading of the step): >= 0 = synchronise after every "
                          "timed step and leave the device idle for this long; the line is then NOT a throughput figure")
@@ -420,7 +421,7 @@ def main():
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
@@ -429,6 +430,8 @@ def main():
         net._lib.mcm_debug_ln_fold(args.ln_fold)
     if args.ln_tail >= 0:
         net._lib.mcm_debug_ln_tail(args.ln_tail)
+    if args.nsplit > 1 and net._lib.mcm_debug_nsplit(args.nsplit) != 0:
+        raise SystemExit("bad --nsplit")
     txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
                                 normalize=True)
     if args.qkv_chunks > 1 and net._lib.mcm_debug_qkv_chunks(args.qkv_chunks) != 0:
@@ -537,6 +540,8 @@ def main():
             line["harness_ln_fold"] = args.ln_fold
         if args.ln_tail >= 0:
             line["harness_ln_tail"] = args.ln_tail
+        if args.nsplit > 1:
+            line["harness_nsplit"] = args.nsplit
         if args.idle_ms >= 0:
             line["idle_ms_between_steps"] = args.idle_ms
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"

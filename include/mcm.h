@@ -341,6 +341,9 @@ int mcm_debug_attention_variant(int32_t variant);
 int mcm_debug_gemm_dbg(int32_t bits);
 /* A/B: run the QKV projection + attention of every layer per chunk of the batch (n chunks; 1 = shipped). */
 int mcm_debug_qkv_chunks(int32_t n);
+/* A/B: the wide store GEMMs (QKV projection, fc1) as n launches over column blocks of N / n (1 = shipped: one launch).
+ * The W re-fetch experiment of DESIGN.md / EXPERIMENTS.md: only N / n of W is live in an XCD's L2 per launch. */
+int mcm_debug_nsplit(int32_t n);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */

@@ -23,10 +23,12 @@
 // MFMA operand order is swapped (W fragment as A, X fragment as B) so each lane ends up
 // with 4 consecutive output columns of one row: 16-B fp32 / 8-B bf16 epilogue accesses.
 //
-// The shipped library holds three kernels that share the fragment/epilogue arithmetic and are bit-identical
+// The shipped library holds four kernels that share the fragment/epilogue arithmetic and are bit-identical
 // on the same inputs (which one runs is a size decision, launch_one):
 //   gemm_tile_kernel     128x128 tile, 4 waves, 2 LDS stages, one workgroup per tile,
 //                        2 workgroups/CU.  Small problems (text tower, CLS-only last layer, tests).
+//   gemm_tile64_kernel   the same with 64x128 tiles: problems that give the 128x128 kernel fewer than two workgroups
+//                        per CU (batch <= 32, B/32's short sequences).
 //   gemm_p256_kernel     256x256 tile, 8 waves (2x4, 128x64 wave tiles), two 64-KiB stages + a
 //                        4-KiB epilogue window per wave (160 KiB), persistent (one workgroup per CU).
 //                        Tiles are dealt XCD-first (an XCD's 32 CUs share X row panels in their
@@ -40,11 +42,10 @@
 // (twice the steps; X is re-staged from L2 for the lo step: no third LDS stage, no extra registers).
 // A whole-tile problem whose tile count ends in a thin last round of the persistent grid is cut in two launches
 // (launch_gemm, "Sliver round"): ping-pong kernel for the rows of the whole rounds, tile kernel for the rest.
-// Harness build only (-DMCM_HARNESS: tools/gemm_bench.hip and libmcm_hip_harness.so, which the A/B tests
-// load): gemm_persist_kernel (256x128, 3 stages: bound by the L1->LDS DMA path), the counted-store wait
-// forms, gemm_pp32_kernel (the ping-pong loop on 32x32x16 MFMAs: same cycles, more power, lower clock —
-// DESIGN.md 5.5), the LayerNorm fold (FOLD) and the LayerNorm tail (LNT) forms of gemm_pp_kernel, head-major 16-bit
-// outputs (GemmArgs::hm), the ablation bits and the variant switch — each measured, none faster in the model.
+// Every arm that was built, measured and not shipped — the 256x128 persistent kernel, the ping-pong loop on 32x32x16
+// MFMAs, balanced DMA, staggered epilogues, the LayerNorm fold and the LayerNorm tail, the ablation bits — lives in
+// gemm_arms.hpp, which this file includes only in the A/B builds (-DMCM_HARNESS: libmcm_hip_harness.so and
+// tools/gemm_bench; -DMCM_LN_FOLD / -DMCM_LN_TAIL): the shipped library holds the four kernels below and nothing else.
 #include <type_traits>
 
 #include "common.hpp"
@@ -54,20 +55,8 @@ namespace {
 
 constexpr int ROWB = 128;  // bytes of K per row per K-step
 
-// Ablation bits (GemmArgs::dbg: 1 no refill, 2 no MFMA, 4 no epilogue, 8 folded stores) exist only in
-// the bench harness build (tools/gemm_bench.hip, -DMCM_HARNESS); the shipped library compiles them out.
-#ifdef MCM_HARNESS
-#define DBG(bit) (a.dbg & (bit))
-#else
-#define DBG(bit) false
-#endif
-// Ablation bits INSIDE the ping-pong K-loop (1 no LDS-DMA, 2 no MFMA, 32 X panels with the nt hint) cost the loop
-// registers and branches even when they are off (-2 ... -10 % on the harness kernel, measured), so they exist only
-// in a dedicated build of tools/gemm_bench (-DMCM_HARNESS -DMCM_GEMM_ABLATE), not in libmcm_hip_harness.so.
-#if defined(MCM_HARNESS) && defined(MCM_GEMM_ABLATE)
-#define ABL(bit) (a.dbg & (bit))
-#else
-#define ABL(bit) false
+#if defined(MCM_HARNESS) || defined(MCM_LN_FOLD) || defined(MCM_LN_TAIL)
+#define MCM_ARMS 1  // A/B builds: gemm_arms.hpp is compiled in (below, in front of the launch section)
 #endif
 
 __device__ __forceinline__ int frag_off(int fr, int g, int kk) {
@@ -121,33 +110,19 @@ __device__ __forceinline__ int perm_n(int lr) {
 }
 
 // epilogue of a (MF*16)x64 wave tile at (mw, nw)
-// FOLD: consumer side of the LayerNorm fold (see wave_epilogue_lds); bv then holds b', c and the row statistics are
-// read here.  Same arithmetic (fold_apply) as the ping-pong kernel's form: a score does not depend on the kernel.
-template <int PREC, int EPI, int MF, bool FOLD = false>
+template <int PREC, int EPI, int MF>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                               const f32x4_t (&bv)[4], int mw, int nw, int fr, int g, float& amax) {
   const int n = nw + g * 16;
   if (n >= a.N) return;
-  f32x4_t cv[4];
-  if constexpr (FOLD) {
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) cv[fj] = *(const f32x4_t*)(a.fold_c + min(n, a.N - 16) + fj * 4);
-  }
 #pragma unroll
   for (int fi = 0; fi < MF; ++fi) {
     const int m = mw + fi * 16 + fr;
     if (m >= a.M) continue;
     f32x4_t v[4];
-    float2 rs = make_float2(1.f, 0.f);
-    if constexpr (FOLD) rs = a.fold_rs[m];
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
-      if constexpr (FOLD) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[fj][t] = fold_apply(acc[fj][fi][t], rs.x, rs.y, cv[fj][t], bv[fj][t]);
-      } else {
-        v[fj] = acc[fj][fi] + bv[fj];
-      }
+      v[fj] = acc[fj][fi] + bv[fj];
       if constexpr (EPI == EPI_GELU) {  // same form in every kernel variant: results must not
 #pragma unroll                          // depend on which variant the size heuristic picks
         for (int t = 0; t < 4; ++t)
@@ -217,19 +192,10 @@ __device__ __forceinline__ void store16_stream_s(const void* sbase, uint32_t vof
 
 // INTERIOR (16-bit outputs only; the ping-pong kernel): the caller guarantees a full tile and uniform mw / nw;
 // rows are then addressed as a uniform base plus one 32-bit lane offset, without bounds checks.
-// LayerNorm fold, consumer side (FOLD; ping-pong kernel, 16-bit outputs): the A operand was z = gamma o x instead of
-// LayerNorm(x), so the row's normalisation is applied here: out = (acc - mean c_n) rstd + b'_n with c = W gamma and
-// b' = b + W beta (both prepared once per weight, launch_fold_prep) and (rstd, mean rstd) per row from the producer's
-// moments (launch_fold_stats).  `bv` holds b' and fo.cv holds c for the lane's 16 columns; a lane of the wave keeps
-// (rstd, mean rstd) of rows lane and 64 + lane of the wave's 128 and the unit's row is fetched by ds_bpermute.
-struct FoldRegs {
-  f32x4_t cv[4];
-  float rstd[2], mrstd[2];
-};
-template <int PREC, int EPI, int MF, bool INTERIOR = false, bool FOLD = false>
+template <int PREC, int EPI, int MF, bool INTERIOR = false>
 __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
-                                                  char* scratch, float& amax, const FoldRegs* fo = nullptr) {
+                                                  char* scratch, float& amax) {
   const int fr = lane & 15, g = lane >> 4;
   if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
@@ -239,20 +205,9 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
     const int n = nw + c8 * 8;
     auto write_unit = [&](int u) {
       f32x4_t v[4];
-      float rstd = 1.f, mr = 0.f;
-      if constexpr (FOLD) {  // row u*16 + fr of the wave's 128: held by lane (u & 3) * 16 + fr, slot u >> 2
-        const int src = (((u & 3) << 4) | fr) << 2;
-        rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fo->rstd[u >> 2])));
-        mr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fo->mrstd[u >> 2])));
-      }
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) {
-        if constexpr (FOLD) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[fj][t] = fold_apply(acc[fj][u][t], rstd, mr, fo->cv[fj][t], bv[fj][t]);
-        } else {
-          v[fj] = acc[fj][u] + bv[fj];
-        }
+        v[fj] = acc[fj][u] + bv[fj];
         if constexpr (EPI == EPI_GELU) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[fj][t] = quick_gelu_fast(v[fj][t]);
@@ -287,11 +242,11 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if constexpr (INTERIOR) {
-          if (!DBG(16)) store16_stream_s(sp, (uint32_t)lane_off * 2u, r[t]);
+          store16_stream_s(sp, (uint32_t)lane_off * 2u, r[t]);
           sp += sp_step;
         } else {
           const int m = mw + u * 16 + t * 8 + rrow;
-          if (m < a.M && n < a.N && !DBG(16)) store16_stream((uint16_t*)a.out + out16_off(a, m, n), r[t]);
+          if (m < a.M && n < a.N) store16_stream((uint16_t*)a.out + out16_off(a, m, n), r[t]);
         }
       }
     };
@@ -415,7 +370,7 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 }  // namespace tile
 
-template <int PREC, int EPI, bool FOLD = false>
+template <int PREC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   using namespace tile;
   enter_precision_mode<PREC>();
@@ -483,13 +438,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   f32x4_t bv[4];
   load_bias(a, n0 + wc * 64 + g * 16, bv);
   float amax = 0.f;
-  wave_epilogue<PREC, EPI, 4, FOLD>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
+  wave_epilogue<PREC, EPI, 4>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
   sat_report<PREC>(amax, a.sat);
 }
 
-#ifdef MCM_HARNESS
 // =========================================================================================
-// 64x128 tile kernel (harness variant 11; DESIGN.md 7 "what is left outside the headline batch").  gemm_tile_kernel
+// 64x128 tile kernel (shipped since round 4; round 3 measured it as harness variant 11: batch 8 +7.5 %, batch 16 +4.5 %,
+// profiles/r03_z_tile64_small_batches.txt).  gemm_tile_kernel
 // with half the rows per workgroup — 2 x 2 waves of 32 x 64, the same staging, fragment and epilogue code (MF = 2) —
 // for problems that give the 128x128 kernel fewer workgroups than the chip has CUs (batch <= 32): twice the
 // workgroups, each with half the MFMA work per K-step and the same latency chain.  Same bits (a row's K is summed
@@ -587,20 +542,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tile64_kernel(const GemmArgs a) {
   sat_report<PREC>(amax, a.sat);
 }
 
-// =========================================================================================
-// persistent 256x128 kernel, 3-stage LDS-DMA pipeline running across tile boundaries
-// =========================================================================================
-namespace persist {
-constexpr int BM = 256, BN = 128;
-constexpr int A_BYTES = BM * ROWB;           // 32 KiB
-constexpr int W_BYTES = BN * ROWB;           // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-constexpr int NSTAGE = 3;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB
-constexpr int LOADS_PER_STAGE = 6;               // LDS-DMA instructions per wave per stage
-}  // namespace persist
-
-#endif
 // XCD-local tile enumeration: N-tiles are walked in groups of `gn` (the group's W panel
 // stays L2-resident while the XCD sweeps its M-tiles); inside a group the order is
 // (mtl, nt) n-fastest, so the 32 CUs of an XCD hold ~32/gn X row panels x gn W panels.
@@ -624,143 +565,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-#ifdef MCM_HARNESS
-template <int PREC, int EPI, bool COUNT_STORES>
-__global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) {
-  using namespace persist;
-  enter_precision_mode<PREC>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = prec_esize(PREC);
-  // store instructions per wave per full tile: 4 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 8 : 16;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
-
-  // ---- tile schedule: M-tiles are striped over the 8 XCDs (mt = mtl*8 + xcd); the G/8
-  // workgroups of an XCD walk that XCD's (mtl, nt) list n-fastest, so concurrently running
-  // CUs of one XCD share X row panels through their L2.
-  const int nbn = (a.N + BN - 1) / BN;
-  const int nbm = (a.M + BM - 1) / BM;
-  const int G8 = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int nmt_x = (nbm - xcd + 7) >> 3;
-  const int ntl_x = nmt_x * nbn;
-  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
-  const int total = ntl * nk;
-
-  // ---- LDS-DMA source geometry of this lane (constant): piece i covers tile rows
-  // i*64 + r0, 16-B chunk `chunk` (swizzled)
-  const int r0 = wave * 8 + (lane >> 4) * 2 + ((lane & 15) >> 3);
-  const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
-  const char* gx[4];
-  const char* gw[2];
-  int ji = 0, kti = 0;  // issue cursor: tile index (of this workgroup) and K-step
-  auto set_issue_tile = [&](int i) {
-    int mtl, nt;
-    tile_of(jx + i * G8, nmt_x, nbn, a.gn, mtl, nt);
-    const int m0 = (mtl * 8 + xcd) * BM, n0 = nt * BN;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * a.K) * ES + chunk * 16;
-  };
-  const uint32_t lds0 = lds_addr(smem);
-  auto issue = [&](int st) {
-    const uint32_t base = lds0 + st * STAGE_BYTES;
-    const size_t ko = (size_t)kti * ROWB;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      glds16(gx[p] + ko, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
-    if (++kti == nk) {
-      kti = 0;
-      if (++ji < ntl) set_issue_tile(ji);
-    }
-  };
-
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, g = lane >> 4;
-  const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
-  const int xbase = wr * 64 * ROWB;
-  const int wbase = A_BYTES + wc * 64 * ROWB;
-
-  f32x4_t acc[4][4];
-  zero_acc(acc);
-  float amax = 0.f;
-
-  set_issue_tile(0);
-  int issued = 0;
-  for (; issued < 2 && issued < total; ++issued) issue(issued);
-  int st = 0;          // LDS stage of step s
-  int ist = 2;         // LDS stage the next issue goes to
-  int jc = 0, ktc = 0; // compute cursor
-  int since_epi = 1000;
-  int cm0, cn0;        // origin of the tile being computed
-  {
-    int mtl, nt;
-    tile_of(jx, nmt_x, nbn, a.gn, mtl, nt);
-    cm0 = (mtl * 8 + xcd) * BM;
-    cn0 = nt * BN;
-  }
-  f32x4_t bv[4];
-#pragma unroll
-  for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const bool counted = nk >= 3;  // short K: every wait is vmcnt(0)
-  for (int s = 0; s < total; ++s) {
-    // Stage s must have landed; everything issued after it may stay in flight.  VMEM issue
-    // order around a tile boundary (tile ends at step e):
-    //   step e  : [DMA stage e+2] ........ [epilogue stores, E per wave]
-    //   step e+1: [bias loads, 4] [DMA stage e+3]
-    //   step e+2: [DMA stage e+4]
-    // so the ops younger than the awaited stage are 6+E at e+1, 10+E at e+2, else 6.
-    if (counted && issued > s + 1) {
-      if (COUNT_STORES && since_epi == 1) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI>();
-      else if (COUNT_STORES && since_epi == 2) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI + 4>();
-      else wait_vmcnt<LOADS_PER_STAGE>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
-    if (issued < total) {  // refill the stage that step s-1 just finished reading
-      if (!ABL(1)) issue(ist);
-      ist = ist == NSTAGE - 1 ? 0 : ist + 1;
-      ++issued;
-    }
-    const char* sb = smem + st * STAGE_BYTES;
-    if (!ABL(2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
-    st = st == NSTAGE - 1 ? 0 : st + 1;
-    ++since_epi;
-    if (++ktc == nk) {
-      if (!counted) wait_vmcnt<0>();  // bias was issued in this very tile's first step
-#pragma unroll
-      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!DBG(4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g, amax);
-      zero_acc(acc);
-      // only a full tile issues exactly STORES_PER_EPI stores per wave; ragged tiles fall back
-      // to waiting for the stores as well
-      since_epi = (cm0 + BM <= a.M && cn0 + BN <= a.N) ? 0 : 1000;
-      ktc = 0;
-      if (++jc < ntl) {
-        int mtl, nt;
-        tile_of(jx + jc * G8, nmt_x, nbn, a.gn, mtl, nt);
-        cm0 = (mtl * 8 + xcd) * BM;
-        cn0 = nt * BN;
-      }
-    }
-  }
-  sat_report<PREC>(amax, a.sat);
-}
-
-#endif  // MCM_HARNESS
-
 // =========================================================================================
 // persistent 256x256 kernel: 8 waves as 2(M) x 4(N), wave tile 128x64 (acc = 128 VGPRs),
 // two 64-KiB LDS stages.  One K-step = 64 MFMAs per wave = 2048 MFMA-cycles per SIMD, and
@@ -775,18 +579,6 @@ constexpr int W_BYTES = BN * ROWB;  // 32 KiB
 constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 KiB epilogue window per wave
 }  // namespace p256
-
-#ifdef MCM_GEMM_TRACE  // harness-only cycle stamps (tools/gemm_bench.hip): a.pos = uint64 buffer
-#define TRACE(k)                                                                                   \
-  do {                                                                                             \
-    if (DBG(128) && s < 64 && lane == 0) {                                                    \
-      const uint64_t t = __builtin_amdgcn_s_memtime();                                             \
-      ((uint64_t*)a.pos)[(((size_t)blockIdx.x * 8 + wave) * 64 + s) * 8 + (k)] = t;               \
-    }                                                                                              \
-  } while (0)
-#else
-#define TRACE(k)
-#endif
 
 template <int PREC, int EPI, bool COUNT_STORES>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
@@ -904,14 +696,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     // VMEM issue order: step e (tile end): [DMA stage e+1] ... [stores E]; step e+1:
     // [bias 4] [DMA stage e+2].  Stage s is the youngest DMA at this point, so only the
     // previous tile's stores may stay in flight.
-    TRACE(0);
     if (COUNT_STORES && stores_pending) wait_vmcnt<STORES_PER_EPI>();
     else wait_vmcnt<0>();
-    TRACE(1);
     stores_pending = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    TRACE(2);
     if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
     // The two waves of a SIMD (w and w+4) take turns: an LDS-DMA instruction blocks its wave for
     // 70-155 cycles while the TA takes the 64 addresses (cycle stamps, MCM_GEMM_TRACE), so if both
@@ -919,27 +708,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
     // priority 1) compute the first K half, refill, compute the second.
     const bool refill = issued < total;
-    if (refill && !late && !ABL(1)) issue(issued & 1);
-    TRACE(3);
+    if (refill && !late) issue(issued & 1);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
-    if (!ABL(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
-    TRACE(4);
-    if (refill && late && !ABL(1)) issue(issued & 1);
+    wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
+    if (refill && late) issue(issued & 1);
     if (refill) ++issued;
-    TRACE(5);
-    if (!ABL(2)) wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
-    TRACE(6);
+    wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
     if (++ktc == nk) {
       if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!DBG(4)) {
-        // dbg 8 (harness only): fold every tile's stores onto a 64-tile region that stays in L2
-        const int em0 = DBG(8) ? (int)(blockIdx.x & 63) * BM : cm0;
-        const int en0 = DBG(8) ? 0 : cn0;
-        wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, lane,
-                                        smem + 2 * STAGE_BYTES + wave * 4096, amax);
-      }
+      wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, lane,
+                                      smem + 2 * STAGE_BYTES + wave * 4096, amax);
       zero_acc<8>(acc);
       stores_pending = (cm0 + BM <= a.M && cn0 + BN <= a.N);
       ktc = 0;
@@ -965,14 +745,6 @@ __device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_
 __device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
-#ifdef MCM_HARNESS  // streamed forms (A/B bit 64: the fold producer's residual rows bypass the caches)
-__device__ __forceinline__ void gload16_nt(f32x4_t& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void gstore16_nt(const void* sbase, uint32_t voff, const f32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-#endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_pin(f32x4_t (&b)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
@@ -1045,101 +817,6 @@ __device__ __forceinline__ void wave_epilogue_f32_interior(const GemmArgs& a, co
   }
 }
 
-// LayerNorm fold, producer side (EPI_RESID in the ping-pong kernel): wave_epilogue_f32_interior<EPI_RESID> plus, for
-// every new residual row segment, (1) z = gamma o x in the operand dtype to fold_z (what the next GEMM multiplies) and
-// (2) the segment's moments — its sum and its sum of squares about its own mean, 64 columns per wave — to
-// fold_part[column / 64][row].  After the LDS bounce the 16 lanes of a DPP row hold the 64 columns of one row, so a
-// moment is 4 DPP adds; the 16 (chunk, row-group) results of 64 rows are parked in the lane whose index equals their
-// number and leave as ONE 512-byte store.  All global accesses from asm, counted like the plain form: at the wait of
-// chunk c the queue holds [loads c] [stores c-1: 4 x + 4 z (+ 1 moments)] [loads c+1].
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gstore8(const void* sbase, uint32_t voff, const u32x2_t& v) {
-  asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-template <int PREC, int MF>
-__device__ __forceinline__ void wave_epilogue_resid_fold(const GemmArgs& a, const f32x4_t (&acc)[4][MF],
-                                                         int mw, int nw, int lane, char* scratch, float& amax) {
-  static_assert(MF == 8, "the wait counts below are written out for 8 chunks");
-  const int fr = lane & 15, g = lane >> 4;
-  const int rrow = lane >> 4, c16 = lane & 15;
-  const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes, fp32 rows
-  const uint32_t zoff = voff >> 1;                                 // bytes, 16-bit rows of the same stride
-  const char* base = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
-  const char* zbase = (const char*)a.fold_z + ((size_t)mw * a.ldo + nw) * 2;
-  auto rowbase = [&](int c, int t) { return base + (size_t)(c * 16 + t * 4) * a.ldo * 4; };
-  auto zrowbase = [&](int c, int t) { return zbase + (size_t)(c * 16 + t * 4) * a.ldo * 2; };
-  const char* pbase = (const char*)(a.fold_part + (size_t)(nw >> 6) * a.M + mw);
-  const uint32_t poff = (uint32_t)(((c16 >> 2) * 16 + (c16 & 3) * 4 + rrow) * 8);
-  // gamma and the bias of the lane's 4 columns AFTER the bounce (4 + 4 registers, loaded here: nothing of this
-  // epilogue is live across the K loop); (acc + b) + resid as in every other form
-  auto xload = [&](f32x4_t& dst, const char* rb) {
-#ifdef MCM_HARNESS
-    if (DBG(64)) return gload16_nt(dst, rb, voff);
-#endif
-    gload16(dst, rb, voff);
-  };
-  auto xstore = [&](const char* rb, const f32x4_t& val) {
-#ifdef MCM_HARNESS
-    if (DBG(64)) return gstore16_nt(rb, voff, val);
-#endif
-    gstore16(rb, voff, val);
-  };
-  f32x4_t gam, bia;
-  gload16(gam, a.fold_g + nw, (uint32_t)c16 * 16u);
-  gload16(bia, a.bias + nw, (uint32_t)c16 * 16u);
-  f32x4_t buf[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) xload(buf[0][t], rowbase(0, t));
-  float ms = 0.f, mq = 0.f;
-#pragma unroll
-  for (int c = 0; c < MF; ++c) {
-    if (c + 1 < MF) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) xload(buf[(c + 1) & 1][t], rowbase(c + 1, t));
-    }
-#pragma unroll
-    for (int fj = 0; fj < 4; ++fj) *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ fr) << 4)) = acc[fj][c];
-    f32x4_t v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = t * 4 + rrow;
-      v[t] = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
-    }
-    if (c == 0) {
-      wait_vmcnt_pin<4>(buf[0]);
-      asm volatile("" : "+v"(gam), "+v"(bia));
-    } else if (c + 1 == MF) {
-      wait_vmcnt_pin<8>(buf[c & 1]);
-    } else if (c == 4) {
-      wait_vmcnt_pin<13>(buf[c & 1]);  // stores of chunk 3 include the first moments store
-    } else {
-      wait_vmcnt_pin<12>(buf[c & 1]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = (v[t] + bia) + buf[c & 1][t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) xstore(rowbase(c, t), v[t]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4_t z = fold_scale(v[t], gam);
-      sat_track<PREC>(amax, z[0], z[1]);
-      sat_track<PREC>(amax, z[2], z[3]);
-      if constexpr (PREC == MCM_PREC_F16) asm volatile("" : "+v"(amax));  // here, not 128 live values later
-      const u32x2_t zz = {pack2<PREC>(z[0], z[1]), pack2<PREC>(z[2], z[3])};
-      gstore8(zrowbase(c, t), zoff, zz);
-      float sm, sq;
-      slot_moments(v[t], sm, sq);
-      const bool mine = c16 == (c & 3) * 4 + t;
-      ms = mine ? sm : ms;
-      mq = mine ? sq : mq;
-    }
-    if ((c & 3) == 3) {
-      const u32x2_t pm = {__builtin_bit_cast(uint32_t, ms), __builtin_bit_cast(uint32_t, mq)};
-      gstore8(pbase + (size_t)(c >> 2) * 64 * 8, poff, pm);
-    }
-  }
-}
-
 // =========================================================================================
 // persistent 256x256 "ping-pong" kernel.  Same tile, wave tiles, LDS image and epilogue as
 // gemm_p256_kernel, but the two waves of a SIMD (w and w+4) run half a K-step apart: while one
@@ -1159,173 +836,8 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
       : "memory");
 }
 
-#ifdef MCM_HARNESS
-// the same with the non-temporal hint (harness A/B, dbg bit 32: X pieces streamed so that W stays L2-resident)
-__device__ __forceinline__ void glds16s_nt(const void* sbase, uint32_t voff, uint32_t lds_base) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_base)
-      : "memory");
-}
-#endif
-
-// harness-only phase timing of the ping-pong kernel: s_memtime deltas accumulated in scalar registers (stamps
-// only where the wave has to drain lgkmcnt anyway), split into mid-tile steps and steps that carry an epilogue;
-// written out once at the end (a.pos = uint32 buffer [block][wave][2][5]: 4 sums + step count)
-#ifdef MCM_GEMM_TRACE
-#define PPT_INIT()                                  \
-  uint32_t ppt_sum[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; \
-  uint64_t ppt_prev = __builtin_amdgcn_s_memtime(); \
-  int ppt_set = 0
-#define PPT(k)                                                    \
-  do {                                                            \
-    if (DBG(128)) {                                               \
-      if ((k) == 0) ppt_set = pend ? 1 : 0;                       \
-      const uint64_t t = __builtin_amdgcn_s_memtime();            \
-      ppt_sum[ppt_set][k] += (uint32_t)(t - ppt_prev);            \
-      ppt_prev = t;                                               \
-      if ((k) == 3) ppt_sum[ppt_set][4] += 1;                     \
-    }                                                             \
-  } while (0)
-#define PPT_DUMP()                                                                                      \
-  do {                                                                                                  \
-    if (DBG(128) && lane == 0) {                                                                        \
-      uint32_t* o = (uint32_t*)a.pos + ((size_t)blockIdx.x * 8 + wave) * 10;                            \
-      for (int i = 0; i < 2; ++i)                                                                       \
-        for (int j = 0; j < 5; ++j) o[i * 5 + j] = ppt_sum[i][j];                                       \
-    }                                                                                                   \
-  } while (0)
-#else
-#define PPT_INIT()
-#define PPT(k)
-#define PPT_DUMP()
-#endif
-
-// =========================================================================================
-// LayerNorm in the tail (LNT; EPI_RESID, 16-bit operand modes).  A residual GEMM (out-proj, fc2) is always followed by
-// the LayerNorm of the rows it has just updated, and its persistent grid always ends ragged: 1 182 tiles on 256
-// workgroups are 4.6 rounds, so in the last round 38 % of the CUs have nothing left to do for a whole tile time.
-// With LNT the kernel does not end there: a wave that has run out of tiles draws tickets — 32 rows each, in the order
-// the row tiles were walked — waits until every tile of the ticket's row tile has been PUBLISHED, and normalises those
-// rows (ln_row.hpp: the LayerNorm kernel's arithmetic, bit for bit) into the next GEMM's operand buffer.  The separate
-// LayerNorm launch, its 310-MB read in a low-occupancy-free interval of its own, and the ragged tail disappear together.
-//
-// Coherence.  Everything a ticket touches lives in ONE XCD's L2: row tiles are dealt to XCDs (row tile = mt * 8 + xcd,
-// xcd = blockIdx & 7 — all workgroups with the same blockIdx & 7 share an XCD; mcm_api.hip verifies that on the device
-// before it ever sets ln_y), a row tile's counters sit in that XCD's region of ln_state, and only waves of that XCD
-// normalise its rows.  Publication: a wave's epilogue stores are complete when the vmcnt(0) that ends its next compute
-// phase (or follows the last epilogue) has passed; then lane 0 adds 1 to the row tile's counter with an L2 atomic.
-// A counter reaches N/256 x 8 (tiles x waves) when the whole 256 x N block is in L2.  The consumer polls with a
-// returning L2 atomic (add 0), drops its CU's L1 (buffer_inv sc1) and reads the rows.  All atomics are inline asm
-// without scope bits: performed in the XCD's own L2, invisible to hipcc's waitcnt pass.
-// Deadlock-free: every workgroup of the grid is resident (one per CU) and a tile's producers never wait for anybody.
-// ln_state (per XCD region of ln_rs words): [ln_cap8] counters, tickets drawn, workgroups finished, timeouts.  The
-// last workgroup of an XCD to finish zeroes the region's first three parts: the state is all zero between launches
-// (no memset launch, no launch parity: a captured graph replays it unchanged).
-// =========================================================================================
-__device__ __forceinline__ void l2_atomic_add(const void* sbase, uint32_t voff, uint32_t val) {
-  asm volatile("global_atomic_add %0, %1, %2" ::"v"(voff), "v"(val), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ uint32_t l2_atomic_add_ret(const void* sbase, uint32_t voff, uint32_t val) {
-  uint32_t r;
-  asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(r)
-               : "v"(voff), "v"(val), "s"(sbase)
-               : "memory");
-  return r;
-}
-// one lane of the wave performs the atomic; every lane gets the value
-__device__ __forceinline__ uint32_t wave_l2_add_ret(const void* sbase, uint32_t off, uint32_t val, int lane) {
-  uint32_t r = 0;
-  if (lane == 0) r = l2_atomic_add_ret(sbase, off, val);
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-}
-template <int PREC, int NVU>
-__device__ __forceinline__ void ln_tail_nv(const GemmArgs& a, int xcd, int nmt_x, int lane, float& amax) {
-  const unsigned int* reg = a.ln_state + (size_t)xcd * a.ln_rs;  // this XCD's region
-  const uint32_t need = (uint32_t)(a.N / 256) * 8u;
-  const uint32_t ntick = (uint32_t)nmt_x * 8u;
-  constexpr int D = NVU * 256;
-  for (;;) {
-    const uint32_t t = wave_l2_add_ret(reg, (uint32_t)a.ln_cap8 * 4u, 1u, lane);
-    if (t >= ntick) break;
-    const int mtl = (int)(t >> 3), sub = (int)(t & 7);
-    const int mt = a.rev ? nmt_x - 1 - mtl : mtl;
-    int spins = 0;
-    while (wave_l2_add_ret(reg, (uint32_t)mt * 4u, 0u, lane) < need) {
-      __builtin_amdgcn_s_sleep(32);
-      if (++spins > (1 << 20)) {  // never in a correct run: count it and go on (wrong rows beat a hung box)
-        if (lane == 0) l2_atomic_add(reg, (uint32_t)(a.ln_cap8 + 2) * 4u, 1u);
-        break;
-      }
-    }
-    asm volatile("buffer_inv sc1" ::: "memory");
-    const size_t row0 = ((size_t)mt * 8 + xcd) * 256 + (size_t)sub * 32;
-#pragma unroll 1
-    for (int r0 = 0; r0 < 32; r0 += 8) {  // 8 rows side by side: 24 - 32 loads in flight, 8 reductions per exchange
-      float4 v[8][LN_MAXV];
-      float acc[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float* xr = a.resid + (row0 + r0 + r) * (size_t)D;
-#pragma unroll
-        for (int i = 0; i < NVU; ++i) {
-          typedef float f4_t __attribute__((ext_vector_type(4)));
-          const f4_t q = __builtin_nontemporal_load((const f4_t*)(xr + (i * 64 + lane) * 4));
-          v[r][i] = make_float4(q.x, q.y, q.z, q.w);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = ln_part_sum<NVU>(v[r], D, lane);
-      wave_sum_n<8>(acc);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = ln_center_sq<NVU>(v[r], ln_mean(acc[r], D), D, lane);
-      wave_sum_n<8>(acc);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        ln_scale<NVU>(v[r], ln_rstd(acc[r], D, a.ln_eps), a.ln_g, a.ln_b, D, lane);
-        ln_row_store<PREC, NVU>(v[r], (uint16_t*)a.ln_y + (row0 + r0 + r) * (size_t)D, D, lane, amax);
-      }
-    }
-  }
-}
-template <int PREC>
-__device__ __forceinline__ void ln_tail(const GemmArgs& a, int xcd, int nmt_x, int lane, float& amax) {
-  if (a.N == 768) ln_tail_nv<PREC, 3>(a, xcd, nmt_x, lane, amax);  // the widths of the CLIP vision towers
-  else ln_tail_nv<PREC, 4>(a, xcd, nmt_x, lane, amax);             // (launch_one admits 768 and 1024 only)
-}
-// end of an LNT kernel: the last workgroup of this XCD to get here zeroes the XCD's counters, tickets and finish count
-__device__ __forceinline__ void ln_finish(const GemmArgs& a, int xcd, char* smem) {
-  const unsigned int* reg = a.ln_state + (size_t)xcd * a.ln_rs;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* flag = (int*)smem;
-  if (threadIdx.x == 0) *flag = l2_atomic_add_ret(reg, (uint32_t)(a.ln_cap8 + 1) * 4u, 1u) == (gridDim.x >> 3) - 1;
-  __syncthreads();
-  if (*flag) {
-    const uint32_t zero = 0u;
-    for (int i = threadIdx.x; i < a.ln_cap8 + 2; i += blockDim.x)
-      asm volatile("global_store_dword %0, %1, %2" ::"v"((uint32_t)i * 4u), "v"(zero), "s"(reg) : "memory");
-  }
-}
-
-// BAL (balanced DMA): waves 0-3 stage their X half and W rows 0-127, waves 4-7 their X half and W rows 128-255 —
-// 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
-// waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
-// was last read (W fragments, by these very waves) a whole step earlier, so no ring of three is needed.
-// STAG (staggered epilogues): waves 0-3 run the epilogue of a finished tile BEFORE the barrier that ends the phase
-// in which waves 4-7 still compute that tile's last K-step, waves 4-7 theirs one phase later, under the first compute
-// phase of waves 0-3 on the next tile: each group's stores and conversions run beside the other group's MFMAs.
-// FOLD (LayerNorm fold, 16-bit modes): EPI_RESID runs the producer epilogue (wave_epilogue_resid_fold), EPI_STORE /
-// EPI_GELU the consumer form of wave_epilogue_lds; a wave then carries 6 registers of row / column data across its last
-// compute phase instead of 16 bias registers.
-// LNT: LayerNorm in the tail (above)
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
+template <int PREC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
-  static_assert(!LNT || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG), "LNT: plain residual form");
   using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1340,15 +852,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const int nmt_x = (nbm - xcd + 7) >> 3;
   const int ntl_x = nmt_x * nbn;
   const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) {  // no tile for this workgroup (small problems): it still takes LayerNorm tickets
-    if constexpr (LNT) {
-      float am = 0.f;
-      ln_tail<PREC>(a, xcd, nmt_x, lane, am);
-      sat_report<PREC>(am, a.sat);
-      ln_finish(a, xcd, smem);
-    }
-    return;
-  }
+  if (ntl == 0) return;
   const int nk = (a.K * ES) / ROWB;
   const int total = ntl * nk;
 
@@ -1394,22 +898,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
     const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
     const size_t ko = (size_t)kti * ROWB;
-    if (ABL(1)) return;  // ablation build: no LDS-DMA
     if (i < 4) {
       const size_t kox = (size_t)(kti >> a.ksplit) * ROWB;  // split weights: X K-step s / 2 meets W' K-steps s (hi), s + 1 (lo)
-#if defined(MCM_HARNESS) && defined(MCM_GEMM_ABLATE)
-      if (ABL(32)) {
-        glds16s_nt(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
-        return;
-      }
-#endif
       glds16s(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
-      const int q = BAL ? grp * 4 + (i - 4) : i - 4;
+      const int q = i - 4;
       glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
     }
   };
-  constexpr int NP0 = BAL ? 8 : 12;  // pieces per step of waves 0-3
+  constexpr int NP0 = 12;  // pieces per step of waves 0-3
   auto issue_done = [&]() {
     if (++kti == nk) {
       kti = 0;
@@ -1474,69 +971,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 
   Cursor cc{jx / nbn, jx % nbn};
   int em0 = 0, en0 = 0;  // tile whose epilogue is pending
-  constexpr bool FOLD_OUT = FOLD && EPI <= EPI_GELU;  // consumer side of the LayerNorm fold
-  static_assert(!FOLD || (PREC != MCM_PREC_F32 && EPI != EPI_PATCH), "LayerNorm fold: 16-bit operand modes");
   f32x4_t bv[4];  // bias of the pending tile: asm loads issued at the top of its last compute phase
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // consumer fold: b'[n] and c[n] of column n0 + wc*64 + lane, (rstd, mean rstd) of rows m0 + wr*128 + lane and + 64
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  float fold_b = 0.f, fold_c = 0.f;
-  f32x2_t fold_r0 = {0.f, 0.f}, fold_r1 = {0.f, 0.f};
   auto epilogue = [&]() {
     // every lane-derived address of the epilogue is recomputed from an opaque copy of the lane id: hoisted out
     // of the K loop they would occupy ~20 registers that the loop (128 accumulators + 64 fragments) does not have
     int le = lane;
     asm volatile("" : "+v"(le));
-    if constexpr (FOLD_OUT) {
-      asm volatile("" : "+v"(fold_b), "+v"(fold_c), "+v"(fold_r0), "+v"(fold_r1));
-      if (!DBG(4)) {
-        char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-        FoldRegs fo;
-        f32x4_t bx[4];
-        const int gl = le >> 4;
+    if constexpr (EPI != EPI_RESID) {  // (the residual form loads its bias inside the epilogue: a pin would keep 16 zeros
+                                       // live across the K loop)
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {  // the lane's 16 columns: gl*16 + fj*4 + t of the wave's 64
-            const int src = (gl * 16 + fj * 4 + t) << 2;
-            bx[fj][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fold_b)));
-            fo.cv[fj][t] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, fold_c)));
-          }
-        fo.rstd[0] = fold_r0[0]; fo.mrstd[0] = fold_r0[1];
-        fo.rstd[1] = fold_r1[0]; fo.mrstd[1] = fold_r1[1];
-        wave_epilogue_lds<PREC, EPI, 8, true, true>(a, acc, bx, em0 + wr * 128, en0 + wc * 64, le, win, amax, &fo);
-      }
-    } else {
-      if constexpr (!FOLD && EPI != EPI_RESID) {  // (the residual forms load their bias inside the epilogue: a pin
-                                                   // would keep 16 zeros live across the K loop)
-#pragma unroll
-        for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      }
-      if (!DBG(4)) {
-        char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-        if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
-          wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
-        else if constexpr (FOLD)
-          wave_epilogue_resid_fold<PREC, 8>(a, acc, em0 + wr * 128, en0 + wc * 64, le, win, amax);
-        else
-          wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
-      }
+      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
     }
+    char* win = smem + 2 * STAGE_BYTES + wave * 4096;
+    if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
+      wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
+    else
+      wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
     zero_acc<8>(acc);
   };
-#ifdef MCM_HARNESS
-  if (a.dbg >> 8) {  // harness: de-phase the workgroups of an XCD, (dbg >> 8) x 1024 cycles per step of jx & 3
-    const uint64_t until = __builtin_amdgcn_s_memtime() + (uint64_t)((jx >> 3) & 3) * (uint64_t)(a.dbg >> 8) * 1024u;
-    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   set_issue_tile();
   {
     const LaneK lk = lane_consts();
 #pragma unroll
     for (int i = 0; i < NP0; ++i)
-      if (BAL || i < 4 || !grp) piece(lk, 0, i);
+      if (i < 4 || !grp) piece(lk, 0, i);
   }
   issue_done();
   wait_vmcnt<0>();
@@ -1548,14 +1008,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   }
   int ktc = 0;
   bool pend = false;
-  int pub = -1;  // LNT: row tile (index within this XCD) whose epilogue this wave has issued but not yet published
   auto phase_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  PPT_INIT();
   for (int s = 0; s < total; ++s) {
     // ---- memory phase of step s: the step's fragments into registers, interleaved with the DMA issues for
     // step s+1 (a DMA issue blocks the wave on the TA, a ds_read on the LDS queue: alternating them lets the two
@@ -1574,10 +1032,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NP0; ++i) piece(lk, si, i);
         issue_done();
-        if constexpr (!STAG) phase_barrier();
+        phase_barrier();
       }
       epilogue();
-      if constexpr (LNT) pub = (em0 / BM) >> 3;
       if (!grp) {
         const LaneK lk = lane_consts();
         fo1 = lk.fo1;
@@ -1598,475 +1055,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
           piece(lk, si, i);
         }
       } else {
-        if constexpr (BAL) {  // W first: it has to land within this phase
-#pragma unroll
-          for (int i = 4; i < 8; ++i) {
-            readf(lk, sr, 2 * (i - 4));
-            readf(lk, sr, 2 * (i - 4) + 1);
-            piece(lk, si, i);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            readf(lk, sr, 8 + 2 * i);
-            readf(lk, sr, 8 + 2 * i + 1);
-            piece(lk, si, i);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
-            piece(lk, si, i);
-          }
-        }
-      }
-      issue_done();
-    }
-    pin_frags();
-    if constexpr (BAL) {
-      if (grp) wait_vmcnt<4>();  // everything older than this phase's 4 X pieces: the W pieces waves 0-3 read next
-    }
-    PPT(0);
-    if (!split || STAG) phase_barrier();
-    PPT(1);
-    // ---- compute phase of step s
-    if constexpr (FOLD_OUT) {
-      if (ktc == nk - 1) {  // 4 asm loads, covered by the wait that ends this phase
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        const int pn = cc.nt * BN + wc * 64, pm = (mt_of(cc.mtl) * 8 + xcd) * BM + wr * 128;
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(fold_b) : "v"(le * 4), "s"(a.bias + pn) : "memory");
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(fold_c) : "v"(le * 4), "s"(a.fold_c + pn) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fold_r0) : "v"(le * 8), "s"(a.fold_rs + pm) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fold_r1) : "v"(le * 8), "s"(a.fold_rs + pm + 64) : "memory");
-      }
-    } else if (FOLD || EPI == EPI_RESID) {  // residual forms: the bias (and gamma) are loaded inside the epilogue
-    } else if (ktc == nk - 1 && a.bias) {
-      int le = lane;
-      asm volatile("" : "+v"(le));
-      load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
-    }
-    __builtin_amdgcn_s_setprio(1);
-    if (!ABL(2)) compute(fo1, sr);  // ablation build: no MFMAs (and none of the compute phase's fragment reads)
-    __builtin_amdgcn_s_setprio(0);
-    PPT(2);
-    wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
-    if constexpr (LNT) {  // ... and, in the first phase after an epilogue, its stores: the tile is published
-      if (pub >= 0) {
-        if (lane == 0) l2_atomic_add(a.ln_state + (size_t)xcd * a.ln_rs, (uint32_t)pub * 4u, 1u);
-        pub = -1;
-      }
-    }
-    phase_barrier();
-    PPT(3);
-    pend = false;
-    if (++ktc == nk) {
-      ktc = 0;
-      pend = true;
-      em0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
-      en0 = cc.nt * BN;
-      cursor_next(cc);
-    }
-  }
-  if (!grp) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  if (pend) epilogue();
-  if constexpr (LNT) {
-    if (pend) pub = (em0 / BM) >> 3;
-    wait_vmcnt<0>();
-    if (pub >= 0 && lane == 0) l2_atomic_add(a.ln_state + (size_t)xcd * a.ln_rs, (uint32_t)pub * 4u, 1u);
-    ln_tail<PREC>(a, xcd, nmt_x, lane, amax);
-  }
-  if constexpr (EPI <= EPI_GELU || FOLD || LNT) sat_report<PREC>(amax, a.sat);
-  if constexpr (LNT) ln_finish(a, xcd, smem);
-  PPT_DUMP();
-}
-
-#ifdef MCM_HARNESS
-// =========================================================================================
-// ping-pong kernel on v_mfma_f32_32x32x16_{f16,bf16} (16-bit operand modes only).  Same tile (256x256),
-// wave tiles (128x64), LDS image, DMA schedule and phase structure as gemm_pp_kernel; the compute phase
-// issues 32 MFMAs of 32 cycles instead of 64 of 16.  Why it pays here and did not in the barrier-locked
-// kernel: in the compute phase the MFMAs run back to back from registers, and a
-// 16x16x32 issues every ~19 cycles instead of 16 (the per-instruction issue overhead is paid per MFMA),
-// a 32x32x16 every ~32-33 instead of 32; it also reads its A/B operands from the register file half as
-// often per FLOP, which is energy on a part that sits at its power limit.
-//
-// Fragment maps (guide section 3): A = W block (32 tile columns x 16 k), B = X block (32 rows x 16 k),
-// lane l supplies row (l & 31), 16-B chunk (2 ks + (l >> 5)) of the 128-B K-step row — the existing
-// pair/XOR LDS image serves 32-row fragments conflict-free as well (the four 16-lane groups of a
-// ds_read_b128 touch 8 distinct row pairs).  D: lane (j = l & 31, h = l >> 5), register r holds
-// (X row j, W-block row 4h + 8(r >> 2) + (r & 3)); W rows are staged in the order perm_n32 so that this
-// is tile column h*16 + r: a lane owns 16 consecutive columns of its row in each of the two 32-column
-// blocks of the wave tile.
-// =========================================================================================
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-__device__ __forceinline__ int perm_n32(int i) {  // LDS row i (0..31) of a 32-row W block holds this block column
-  return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3);
-}
-template <int PREC>
-__device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {  // 32x32x16, fp32 acc
-  if constexpr (PREC == MCM_PREC_F16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4_t quad(const f32x16_t& v, int q) {
-  return (f32x4_t){v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-}
-
-// 16-bit epilogue of a full 128x64 wave tile held as acc[xb][wb] (32x32 blocks).  Unit = one block
-// (32 rows x 32 columns = 2 KiB of 16-bit), units in wb-major order ping-ponging between the two halves
-// of the wave's 4-KiB window like wave_epilogue_lds; a lane writes its 32 B of row j, the read-back puts
-// four lanes on a 64-B row, so one store instruction writes 16 rows x 64 B.  bv[wb][q]: bias of columns
-// nw + wb*32 + h*16 + q*4 .. +3; bv[1] is loaded here (asm, counted) and first used by unit 4.
-template <int PREC, int EPI>
-__device__ __forceinline__ void wave_epilogue16_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2], f32x4_t (&bv0)[4],
-                                                    int mw, int nw, int lane, char* scratch, float& amax) {
-  const int j = lane & 31, h = lane >> 5;
-  f32x4_t bv1[4];
-  if (a.bias) {
-    const float* p = a.bias + nw + 32 + h * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv1[q]) : "v"(p + q * 4) : "memory");
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bv1[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
-  const int rrow = lane >> 2, c4 = lane & 3;  // read-back: 4 lanes per 64-B row
-  auto write_unit = [&](int u, const f32x4_t (&bv)[4]) {
-    const int wb = u >> 2, xb = u & 3;
-    f32x4_t v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = quad(acc[xb][wb], q) + bv[q];
-      if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[q][t] = quick_gelu_fast(v[q][t]);
-      }
-      sat_track<PREC>(amax, v[q][0], v[q][1]);
-      sat_track<PREC>(amax, v[q][2], v[q][3]);
-    }
-    char* w = scratch + (u & 1) * 2048 + j * 64;
-    const int sw = (j >> 1) & 3;
-    *(uint4*)(w + (((h * 2) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
-                                                      pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
-    *(uint4*)(w + (((h * 2 + 1) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
-                                                          pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
-  };
-  auto read_unit = [&](int u, uint4 (&r)[2]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 16 + rrow;
-      r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 64 + ((c4 ^ ((row >> 1) & 3)) << 4));
-    }
-  };
-  const int lane_off = rrow * a.ldo + c4 * 8;  // elements
-  auto store_unit = [&](int u, const uint4 (&r)[2]) {
-    const int wb = u >> 2, xb = u & 3;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint16_t* rowbase = (uint16_t*)a.out + (size_t)(mw + xb * 32 + t * 16) * a.ldo + nw + wb * 32;
-      if (!DBG(16)) store16_stream(rowbase + lane_off, r[t]);
-    }
-  };
-  write_unit(0, bv0);
-#pragma unroll
-  for (int u = 1; u < 8; ++u) {
-    uint4 r[2];
-    read_unit(u - 1, r);
-    if (u == 4) {
-      // VMEM queue behind the four bv1 loads: the stores of units 0..2 (2 each)
-      asm volatile("s_waitcnt vmcnt(6)" : "+v"(bv1[0]), "+v"(bv1[1]), "+v"(bv1[2]), "+v"(bv1[3])::"memory");
-    }
-    if (u < 4) write_unit(u, bv0);
-    else write_unit(u, bv1);
-    store_unit(u - 1, r);
-  }
-  {
-    uint4 r[2];
-    read_unit(7, r);
-    store_unit(7, r);
-  }
-}
-
-// fp32-row epilogue (residual read-modify-write) of the same wave tile.  Unit = one 32x32 block = 32 rows x
-// 128 B = the whole 4-KiB window; eight lanes read a row back, so every global access instruction moves
-// 8 rows x 128 B.  The bias (of the four columns a lane owns AFTER the bounce) is added after the bounce:
-// (acc + b) + resid, the order of every other GEMM kernel here.  All global accesses are asm, counted:
-// queue at the wait of unit u, oldest first: [loads u] [stores u-1] [loads u+1]  =>  vmcnt <= 8.
-__device__ __forceinline__ void wave_epilogue_resid_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2],
-                                                        const f32x4_t (&bvf)[2], int mw, int nw, int lane, char* scratch) {
-  const int j = lane & 31, h = lane >> 5;
-  const int rrow = lane >> 3, c8 = lane & 7;
-  const uint32_t voff = (uint32_t)(rrow * a.ldo + c8 * 4) * 4u;  // bytes
-  const char* base = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
-  auto rowbase = [&](int u, int t) {
-    const int wb = u >> 2, xb = u & 3;
-    return base + ((size_t)(xb * 32 + t * 8) * a.ldo + wb * 32) * 4;
-  };
-  f32x4_t buf[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int wb = u >> 2, xb = u & 3;
-    if (u + 1 < 8) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) gload16(buf[(u + 1) & 1][t], rowbase(u + 1, t), voff);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *(f32x4_t*)(scratch + j * 128 + (((h * 4 + q) ^ (j & 7)) << 4)) = quad(acc[xb][wb], q);
-    f32x4_t v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = t * 8 + rrow;
-      v[t] = *(const f32x4_t*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4)) + bvf[wb];
-    }
-    if (u == 0 || u + 1 == 8) wait_vmcnt_pin<4>(buf[u & 1]);
-    else wait_vmcnt_pin<8>(buf[u & 1]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] += buf[u & 1][t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gstore16(rowbase(u, t), voff, v[t]);
-  }
-}
-
-template <int PREC, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
-  using namespace p256;
-  static_assert(PREC != MCM_PREC_F32 && EPI != EPI_PATCH, "16-bit operand modes, interior tiles");
-  enter_precision_mode<PREC>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
-  const int grp = wave >> 2, w4 = wave & 3;
-
-  const int nbn = a.N / BN, nbm = a.M / BM;
-  const int G8 = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int nmt_x = (nbm - xcd + 7) >> 3;
-  const int ntl_x = nmt_x * nbn;
-  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
-  const int total = ntl * nk;
-
-  const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
-  struct Cursor { int mtl, nt; };
-  auto cursor_next = [&](Cursor& c) {
-    c.mtl += dmt;
-    c.nt += dnt;
-    if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
-  };
-  auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
-  const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
-
-  // ---- LDS-DMA side: exactly gemm_pp_kernel's (12 pieces per step from waves 0-3, 4 from waves 4-7), only the
-  // order of the W rows inside a 32-row block differs (perm_n32)
-  struct LaneK { uint32_t voff_x, voff_w; int fo0; };
-  auto lane_consts = [&]() {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    const int rr = (l >> 4) * 2 + ((l & 15) >> 3);
-    const int chunk = (l & 7) ^ (((w4 & 1) << 2) | (l >> 4));
-    LaneK c;
-    c.voff_x = (uint32_t)(rr * (uint32_t)sx + chunk * 16);
-    c.voff_w = (uint32_t)(perm_n32(w4 * 8 + rr) * (uint32_t)sw + chunk * 16);
-    const int j = l & 31, h = l >> 5;
-    c.fo0 = (j >> 1) * 256 + ((((j & 1) << 3) | ((h ^ (j >> 1)) & 7)) << 4);  // K16 sub-step ks: fo0 ^ (ks << 5)
-    return c;
-  };
-  Cursor ci{jx / nbn, jx % nbn};
-  int ji = 0, kti = 0;
-  const char *tx, *tw;
-  auto set_issue_tile = [&]() {
-    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
-    tx = (const char*)a.x + (size_t)(m0 + grp * 128 + w4 * 8) * sx;
-    tw = (const char*)a.w + (size_t)n0 * sw;
-  };
-  const uint32_t lds0 = lds_addr(smem);
-  auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
-    const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
-    const size_t ko = (size_t)kti * ROWB;
-    if (i < 4) {
-      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
-    } else {
-      const int q = i - 4;  // LDS rows q*32 + w4*8 + rr of the W panel = tile columns q*32 + perm_n32(w4*8 + rr)
-      glds16s(tw + ko + (size_t)(q * 32) * sw, lk.voff_w, base + A_BYTES + q * 4096);
-    }
-  };
-  auto issue_done = [&]() {
-    if (++kti == nk) {
-      kti = 0;
-      if (++ji < ntl) {
-        cursor_next(ci);
-        set_issue_tile();
-      }
-    }
-  };
-
-  // ---- MFMA side: wave tile 128 x 64 = 4 X blocks x 2 W blocks of 32x32, K-step = 4 sub-steps of 16
-  const int wr = wave >> 2, wc = wave & 3;
-  const int xbase = wr * 128 * ROWB;
-  const int wbase = A_BYTES + wc * 64 * ROWB;
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  // memory phase: all 8 W fragments and the X fragments of sub-steps 0 and 1 (64 registers); the X fragments of
-  // sub-steps 2 and 3 replace them during the compute phase, each after its last use
-  u32x4_t xf[2][4], wf[4][2];
-  auto readf = [&](const LaneK& lk, int st, int i) {  // memory-phase read i of 16, in order of first use
-    const char* sb = smem + st * STAGE_BYTES;
-    if (i < 2) wf[0][i] = *(const u32x4_t*)(sb + wbase + i * 4096 + lk.fo0);
-    else if (i < 6) xf[0][i - 2] = *(const u32x4_t*)(sb + xbase + (i - 2) * 4096 + lk.fo0);
-    else if (i < 8) wf[1][i - 6] = *(const u32x4_t*)(sb + wbase + (i - 6) * 4096 + (lk.fo0 ^ 32));
-    else if (i < 12) xf[1][i - 8] = *(const u32x4_t*)(sb + xbase + (i - 8) * 4096 + (lk.fo0 ^ 32));
-    else wf[2 + ((i - 12) >> 1)][(i - 12) & 1] =
-        *(const u32x4_t*)(sb + wbase + ((i - 12) & 1) * 4096 + (lk.fo0 ^ ((2 + ((i - 12) >> 1)) << 5)));
-  };
-  auto pin_frags = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) asm volatile("" : "+v"(wf[k][f]));
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(xf[k][f]));
-  };
-  f32x16_t acc[4][2];
-  float amax = 0.f;
-  auto zero = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][w][r] = 0.f;
-  };
-  zero();
-  auto compute = [&](int fo0, int st) {
-    const char* sb = smem + st * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int xb = 0; xb < 4; ++xb) {
-#pragma unroll
-        for (int wb = 0; wb < 2; ++wb)
-          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks][xb]), acc[xb][wb]);
-        xf[ks][xb] = *(const u32x4_t*)(sb + xbase + xb * 4096 + (fo0 ^ ((ks + 2) << 5)));
-      }
-#pragma unroll
-    for (int ks = 2; ks < 4; ++ks)
-#pragma unroll
-      for (int xb = 0; xb < 4; ++xb)
-#pragma unroll
-        for (int wb = 0; wb < 2; ++wb)
-          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks & 1][xb]), acc[xb][wb]);
-  };
-
-  Cursor cc{jx / nbn, jx % nbn};
-  int em0 = 0, en0 = 0;  // tile whose epilogue is pending
-  // bias registers of the pending tile, asm loads issued at the top of its last compute phase: 16-bit outputs
-  // need the 16 columns of the lane's first block (the second block's are loaded inside the epilogue), the
-  // fp32-row form the 4 + 4 columns the lane owns after the LDS bounce
-  constexpr bool RESID = (EPI == EPI_RESID);
-  f32x4_t bv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  auto bias_issue = [&](int n0) {
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    if constexpr (RESID) {
-      const float* p = a.bias + n0 + wc * 64 + (le & 7) * 4;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[0]) : "v"(p) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[1]) : "v"(p + 32) : "memory");
-    } else {
-      const float* p = a.bias + n0 + wc * 64 + (le >> 5) * 16;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(p + q * 4) : "memory");
-    }
-  };
-  auto epilogue = [&]() {
-    int le = lane;
-    asm volatile("" : "+v"(le));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
-    if (!DBG(4)) {
-      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-      if constexpr (RESID) {
-        const f32x4_t bvf[2] = {bv[0], bv[1]};
-        wave_epilogue_resid_b32(a, acc, bvf, em0 + wr * 128, en0 + wc * 64, le, win);
-      } else {
-        wave_epilogue16_b32<PREC, EPI>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
-      }
-    }
-    zero();
-  };
-  set_issue_tile();
-  {
-    const LaneK lk = lane_consts();
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-      if (i < 4 || !grp) piece(lk, 0, i);
-  }
-  issue_done();
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (grp) {  // waves 4-7 run one phase behind
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  int ktc = 0;
-  bool pend = false;
-  auto phase_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int s = 0; s < total; ++s) {
-    const int sr = s & 1, si = sr ^ 1;
-    const bool split = pend && !grp;
-    int fo0;
-    if (pend) {
-      if (!grp) {
-        const LaneK lk = lane_consts();
-#pragma unroll
-        for (int i = 0; i < 12; ++i) piece(lk, si, i);
-        issue_done();
-        phase_barrier();
-      }
-      epilogue();
-      if (!grp) {
-        const LaneK lk = lane_consts();
-        fo0 = lk.fo0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) readf(lk, sr, i);
-      }
-    }
-    if (!split) {
-      const LaneK lk = lane_consts();
-      fo0 = lk.fo0;
-      if (!grp) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          if (i < 8) {
-            readf(lk, sr, 2 * i);
-            readf(lk, sr, 2 * i + 1);
-          }
-          piece(lk, si, i);
-        }
-      } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) readf(lk, sr, 4 * i + jj);
+          for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
           piece(lk, si, i);
         }
       }
@@ -2075,9 +1067,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
     pin_frags();
     if (!split) phase_barrier();
     // ---- compute phase of step s
-    if (ktc == nk - 1 && a.bias) bias_issue(cc.nt * BN);  // covered by the wait that ends this phase
+    if (EPI == EPI_RESID) {  // residual form: the bias is loaded inside the epilogue
+    } else if (ktc == nk - 1 && a.bias) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      load_bias_async(a, cc.nt * BN + wc * 64 + (le >> 4) * 16, bv);  // covered by the wait that ends this phase
+    }
     __builtin_amdgcn_s_setprio(1);
-    compute(fo0, sr);
+    compute(fo1, sr);
     __builtin_amdgcn_s_setprio(0);
     wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
     phase_barrier();
@@ -2095,17 +1092,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
-  if constexpr (!RESID) sat_report<PREC>(amax, a.sat);
+  if constexpr (EPI <= EPI_GELU) sat_report<PREC>(amax, a.sat);
 }
 
-#endif  // MCM_HARNESS
+#ifdef MCM_ARMS
+// the launch helpers the arms need are declared before the include, the arms' own launchers and routing come with it
+int persistent_grid();
+#include "gemm_arms.hpp"
+#endif
 
 // ---- launch ------------------------------------------------------------------------------
 
 #ifdef MCM_HARNESS
-int g_variant = -1;  // -1 auto, 0 tile, 1/2 persistent 256x128 (2: counted stores), 3/4 persistent 256x256 (4: counted stores),
-                     // 5 ping-pong 256x256 (interior tiles only, else 3), 6 ping-pong on 32x32x16 MFMAs (else 5),
-                     // 7 ping-pong with balanced DMA, 8 ping-pong with staggered epilogues (else 5)
+int g_variant = -1;  // -1 auto (the shipped size policy), 0 the 128x128 tile kernel always, 3/4 persistent 256x256 (4: counted
+                     // stores), 5 ping-pong 256x256 (whole tiles only, else 3), 11 the 64x128 tile kernel always; arms
+                     // (gemm_arms.hpp): 1/2 persistent 256x128, 6 ping-pong on 32x32x16 MFMAs, 7 balanced DMA, 8 staggered
+                     // epilogues, 9 the flagged ping-pong text with every flag off (all: whole tiles, else as 5)
 int variant() { return g_variant; }
 #else
 constexpr int variant() { return -1; }  // the shipped library has the size policy of launch_one only
@@ -2125,21 +1127,20 @@ int persistent_grid() {
   return n;
 }
 
-template <int PREC, int EPI, bool FOLD = false>
+template <int PREC, int EPI>
 hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI, FOLD>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, tile::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int nbn = (a.N + tile::BN - 1) / tile::BN, nbm = (a.M + tile::BM - 1) / tile::BM;
-  hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI, FOLD>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
-#ifdef MCM_HARNESS
 template <int PREC, int EPI>
 hipError_t launch_tile64(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -2153,20 +1154,6 @@ hipError_t launch_tile64(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_tile64_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile64::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-template <int PREC, int EPI, bool CS>
-hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<PREC, EPI, CS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, persist::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
-  return hipGetLastError();
-}
-
-#endif
 
 template <int PREC, int EPI, bool CS>
 hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
@@ -2181,39 +1168,23 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
+template <int PREC, int EPI>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-
-#ifdef MCM_HARNESS
-template <int PREC, int EPI>
-hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp32_kernel<PREC, EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_pp32_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
-  return hipGetLastError();
-}
-
-#endif
 
 // the kernel family launch_one picks for a problem: 0 tile kernel, 5 ping-pong (whole tiles) or plain persistent
 int size_policy(int M, int N) {
   int v = variant();
-  if (v < 0 || v == 11) {  // auto (11: harness arm that only swaps the tile kernel, launch_one): the persistent 256x256 kernel once its tiles cover most of the CUs, else the
+  if (v < 0) {  // auto: the persistent 256x256 kernel once its tiles cover most of the CUs, else the
                 // one-workgroup-per-tile kernel (text tower, CLS-only last layer).  Round 1, bench.py --batch
                 // 128 / 256 / 384: p256 wins from ~300 tiles on (+3 / +6 / +7 % end to end against the old >= 1024 rule).
     const long tiles = (long)((M + p256::BM - 1) / p256::BM) * ((N + p256::BN - 1) / p256::BN);
@@ -2224,69 +1195,30 @@ int size_policy(int M, int N) {
     // and up unchanged (profiles/r03_x_kernel_choice_small_batches.txt).
     v = 2 * tiles > persistent_grid() ? 5 : 0;  // 5 falls back to 3 when the problem has edge tiles
   }
-  if (v != 0 && persistent_grid() < 8) v = 0;
+  if (v != 0 && v != 11 && persistent_grid() < 8) v = 0;
   return v;
 }
 
 template <int PREC, int EPI>
 hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   int v = size_policy(a.M, a.N);
-  const bool fold = a.fold_z != nullptr || a.fold_rs != nullptr;
-  if (fold) {  // LayerNorm fold (harness / -DMCM_LN_FOLD builds only: measured slower than the LayerNorm launches)
-#if defined(MCM_HARNESS) || defined(MCM_LN_FOLD)
-    if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
-      const bool sides = EPI == EPI_RESID ? (a.fold_z && a.fold_g && a.fold_part && a.bias && !a.fold_rs)
-                                          : (a.fold_rs && a.fold_c && a.bias && !a.fold_z);
-      if (v == 5 && sides && a.M % p256::BM == 0 && a.N % p256::BN == 0 && a.ldo == a.N)
-        return launch_pp<PREC, EPI, false, false, true>(a, s);
-      if constexpr (EPI <= EPI_GELU) {
-        if (v == 0 && sides) return launch_tile<PREC, EPI, true>(a, s);
-      }
-    }
-#endif
-    return hipErrorInvalidValue;
+#ifdef MCM_ARMS
+  {  // A/B builds: the LayerNorm fold / tail forms and the forced arm variants (gemm_arms.hpp)
+    hipError_t e;
+    if (arms::route<PREC, EPI>(v, a, s, &e)) return e;
   }
-  if (a.ln_y) {  // LayerNorm in the tail: the ping-pong kernel's residual form only (the caller asked gemm_ln_tail_ok).
-                 // An A/B arm (harness / -DMCM_LN_TAIL builds): measured equal at ViT-B/16 batch 512 and slower on smaller
-                 // problems, so the shipped library launches its LayerNorms and does not carry the kernel.
-#if defined(MCM_HARNESS) || defined(MCM_LN_TAIL)
-    if constexpr (EPI == EPI_RESID && PREC != MCM_PREC_F32) {
-      if (v == 5 && a.M % p256::BM == 0 && a.N % p256::BN == 0 && (a.N == 768 || a.N == 1024) && a.ldo == a.N && a.ln_g &&
-          a.ln_b && a.ln_state && a.ln_cap8 * 8 >= a.M / p256::BM && persistent_grid() % 8 == 0)
-        return launch_pp<PREC, EPI, false, false, false, true>(a, s);
-    }
+#else
+  if (a.fold_z || a.fold_rs || a.ln_y) return hipErrorInvalidValue;  // A/B arms: not in the shipped library
 #endif
-    return hipErrorInvalidValue;
+  if (v == 0 || v == 11) {
+    // 64x128 tiles when the 128x128 kernel would get fewer than two workgroups per CU (batch <= 32 at B/16, the text
+    // tower's short prompts banks, B/32): twice the workgroups, the same bits (round 3: batch 8 +7.5 %, batch 16 +4.5 %)
+    const bool few = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 2L * persistent_grid();
+    if (v == 11 || (variant() < 0 && few && !MCM_HM(a.hm))) return launch_tile64<PREC, EPI>(a, s);
+    return launch_tile<PREC, EPI>(a, s);
   }
 #ifdef MCM_HARNESS
-  // variant 11: the shipped size policy, with the 64x128 tile kernel wherever the 128x128 one would be short of workgroups
-  if (v == 0 && variant() == 11 && !a.hm &&
-      (long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 2L * persistent_grid())
-    return launch_tile64<PREC, EPI>(a, s);
-#endif
-  if (v == 0) return launch_tile<PREC, EPI>(a, s);
-#ifdef MCM_HARNESS
-  if (v == 1) return launch_persist<PREC, EPI, false>(a, s);
-  if (v == 2) return launch_persist<PREC, EPI, true>(a, s);
   if (v == 4) return launch_p256<PREC, EPI, true>(a, s);
-  if (v == 7) {  // ping-pong with balanced DMA (8 + 8 pieces); else as 5
-    if constexpr (EPI != EPI_PATCH) {
-      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI, true>(a, s);
-    }
-    v = 5;
-  }
-  if (v == 8) {  // ping-pong with staggered epilogues; else as 5
-    if constexpr (EPI != EPI_PATCH) {
-      if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI, false, true>(a, s);
-    }
-    v = 5;
-  }
-  if (v == 6) {  // ping-pong on 32x32x16 MFMAs: 16-bit operand modes, whole tiles; else as 5
-    if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
-      if (a.M % p256::BM == 0 && a.N % p256::BN == 0 && !a.hm) return launch_pp32<PREC, EPI>(a, s);
-    }
-    v = 5;
-  }
 #endif
   if (v == 5) {
     if constexpr (EPI != EPI_PATCH) {  // the patch epilogue remaps rows: stays with the plain kernel
@@ -2324,7 +1256,7 @@ constexpr int g_group_n = 0, g_dbg = 0;
 int gemm_persistent_grid() { return persistent_grid(); }  // workgroups of the persistent kernels (one per CU, multiple of 8)
 bool gemm_ln_tail_ok(int prec, int M, int N) {
 #if !defined(MCM_HARNESS) && !defined(MCM_LN_TAIL)
-  return false;
+  return false;  // the arm is not in this build
 #endif
   if (prec == MCM_PREC_F32 || M <= 0 || M % p256::BM || (N != 768 && N != 1024)) return false;
   return size_policy(M, N) == 5 && persistent_grid() >= 8;
@@ -2366,7 +1298,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   if (a.ksplit && (a.ksplit != 1 || prec == MCM_PREC_F32 || ((a.K * es) / ROWB) % 2 || a.fold_z || a.fold_rs || a.ln_y))
     return hipErrorInvalidValue;
 #ifdef MCM_HARNESS
-  if (a.ksplit && (variant() == 1 || variant() == 2 || variant() == 6)) return hipErrorInvalidValue;
+  if (a.ksplit && (variant() == 1 || variant() == 2 || variant() == 6)) return hipErrorInvalidValue;  // (arms without the split staging)
 #endif
   // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
   if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
@@ -2411,3 +1343,4 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
 #endif
   return launch_gemm_one(prec, epi, a, s);
 }
+

@@ -177,8 +177,32 @@ bool next_dir(mcm_handle* h) {
   h->flip = !h->flip;
   return h->flip;
 }
+#ifdef MCM_HARNESS
+int g_nsplit = 1;  // A/B (mcm_debug_nsplit): the wide store GEMMs (QKV, fc1) as n launches over column blocks of N / n
+#endif
 hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs& a_in) {
   GemmArgs a = a_in;
+#ifdef MCM_HARNESS
+  if (g_nsplit > 1 && epi <= EPI_GELU && a.N >= 2048 && a.N % (256 * g_nsplit) == 0 && !a.fold_rs && !a.hm && a.M > 4096) {
+    // W re-fetch experiment: the XCD's L2 (4 MiB) cannot hold all of W (fc1: 4.7 MB) beside the X
+    // panels in flight, so W streams through it once per tile round; with the columns cut in n blocks only N / n of W
+    // is live per launch (X is then read n times).  Same bits (a column's K-sum does not depend on its neighbours).
+    const int n = g_nsplit, nb = a.N / n;
+    const size_t wrow = (size_t)a.K * prec_esize(prec) * (a.ksplit ? 2 : 1);
+    hipError_t e = hipSuccess;
+    g_nsplit = 1;
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+      GemmArgs p = a_in;
+      p.N = nb;
+      p.w = (const char*)a_in.w + (size_t)i * nb * wrow;
+      p.bias = a_in.bias ? a_in.bias + (size_t)i * nb : nullptr;
+      p.out = (char*)a_in.out + (size_t)i * nb * prec_esize(prec);
+      e = gemm(h, s, prec, epi, p);
+    }
+    g_nsplit = n;
+    return e;
+  }
+#endif
   a.rev = next_dir(h) ? 1 : 0;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
   Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);  // algorithmic FLOP: the logical K, split or not
@@ -1142,6 +1166,11 @@ int mcm_debug_qkv_head_major(int32_t on) {
   g_qkv_head_major = on ? 1 : 0;
   return MCM_OK;
 }
+int mcm_debug_nsplit(int32_t n) {  // 1 (shipped): one launch per GEMM; 2 / 3 / 4: QKV and fc1 as n column-block launches
+  if (n < 1 || n > 4) return MCM_EINVAL;
+  g_nsplit = n;
+  return MCM_OK;
+}
 int mcm_debug_qkv_chunks(int32_t n) {
   if (n < 1 || n > 16) return MCM_EINVAL;
   g_qkv_chunks = n;
@@ -1149,7 +1178,7 @@ int mcm_debug_qkv_chunks(int32_t n) {
 }
 
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || (variant > 8 && variant != 11)) return MCM_EINVAL;
+  if (variant < -1 || (variant > 9 && variant != 11)) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }

@@ -108,9 +108,9 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[-1, 0, 2, 4, 5, 6, 7, 8], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
-                                                   "pingpong256x256", "pingpong256x256-mfma32", "pingpong256x256-balanced",
-                                                   "pingpong256x256-staggered"])
+@pytest.fixture(params=[-1, 0, 2, 4, 5, 6, 7, 8, 9, 11], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
+                                                          "pingpong256x256", "pingpong256x256-mfma32", "pingpong256x256-balanced",
+                                                          "pingpong256x256-staggered", "pingpong256x256-arms-text", "tile64"])
 def gemm_net(request, tiny_net, harness_net):
     """Every GEMM kernel variant must pass the same parity cases (the shipped policy picks by problem size, so
     small test shapes would otherwise only exercise the tile kernel).  -1 = the shipped library as is; the
@@ -238,7 +238,7 @@ def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, pre
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (-1, 3, 4, 5, 6, 7, 8):
+        for variant in (-1, 3, 4, 5, 6, 7, 8, 9):
             for _ in range(3):
                 got = run(variant)
                 assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
@@ -288,9 +288,10 @@ def test_linear_sliver_split_bitwise(tiny_net, harness_net, M, N, K, epi, prec):
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("M,N,K,epi", [(3152, 768, 768, 2), (3152, 2304, 768, 0), (3152, 768, 3072, 2), (197, 768, 768, 2),
                                        (1000, 3072, 768, 1), (77, 512, 512, 0)])
-def test_linear_tile64_bitwise(harness_net, M, N, K, epi, prec):
-    """Harness variant 11: the 64x128 tile kernel (small batches: twice the workgroups of the 128x128 kernel) against the
-    128x128 tile kernel, bit for bit, ragged row counts included."""
+def test_linear_tile64_bitwise(tiny_net, harness_net, M, N, K, epi, prec):
+    """The 64x128 tile kernel (shipped since round 4 for problems that give the 128x128 kernel fewer than two workgroups per
+    CU; forced everywhere by harness variant 11) against the 128x128 tile kernel (variant 0), bit for bit, ragged row counts
+    included — and the shipped library's own choice on these shapes (which is the 64x128 kernel) against both."""
     dt = DTYPE[prec]
     g = torch.Generator(device="cuda").manual_seed(M + N + K + epi)
     x = torch.randn((M, K), generator=g, device="cuda").to(dt)
@@ -314,6 +315,12 @@ def test_linear_tile64_bitwise(harness_net, M, N, K, epi, prec):
         assert torch.isfinite(ref.float()).all()
         view = torch.int32 if ref.element_size() == 4 else torch.int16
         assert torch.equal(got.view(view), ref.view(view))
+        y = torch.zeros((M, N), device="cuda", dtype=dt)      # the shipped library, its own size policy
+        rd = resid0.clone() if epi == 2 else y
+        assert tiny_net._lib.mcm_op_linear(tiny_net._h, PREC[prec], _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(rd), M, N, K,
+                                           epi, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal((rd if epi == 2 else y).view(view), ref.view(view))
     finally:
         net._lib.mcm_debug_gemm_variant(-1)
 

@@ -46,11 +46,17 @@ def gemm_isa_harness(tmp_path_factory):
     return open(out / asm[0]).read()
 
 
-def _kernel(isa, prec, epi, fold=0):
-    """gemm_pp_kernel<PREC, EPI, BAL = false, STAG = false, FOLD = fold, LNT = false>"""
-    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi%dELb0ELb0ELb%dELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold), isa,
-                  re.S | re.M)
-    assert m, "gemm_pp_kernel<%d,%d,fold=%d> not found" % (prec, epi, fold)
+def _kernel(isa, prec, epi, fold=0, arms=None):
+    """The shipped gemm_pp_kernel<PREC, EPI> (gemm.hip) or — with `fold` / `arms` — the flagged text of gemm_arms.hpp:
+    arms::gemm_pp_kernel<PREC, EPI, BAL = false, STAG = false, FOLD = fold, LNT = false>."""
+    if arms is None:
+        arms = bool(fold)
+    if arms:
+        pat = r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi%dELb0ELb0ELb%dELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold)
+    else:
+        pat = r"^(_ZN\S*_114gemm_pp_kernelILi%dELi%dEEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi)
+    m = re.search(pat, isa, re.S | re.M)
+    assert m, "gemm_pp_kernel<%d,%d,fold=%d,arms=%s> not found" % (prec, epi, fold, arms)
     return m.group(0)
 
 
@@ -103,7 +109,7 @@ def test_pingpong_residual_kernel_with_the_layernorm_tail_keeps_the_k_loop_clean
     uniform branch and one asm atomic behind the wait that ends a compute phase, the tail itself sits behind the loop —
     the K loop must look exactly like the plain residual kernel's: no scratch, 64 MFMAs, no wait between the LDS-DMA
     issues and the MFMAs, and up to the last MFMA only the hand-written waits."""
-    m = re.search(r"^(_ZN\S*gemm_pp_kernelILi%dELi2ELb0ELb0ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
+    m = re.search(r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi2ELb0ELb0ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
                   re.S | re.M)
     assert m, "LNT kernel not found"
     lines = m.group(0).splitlines()
