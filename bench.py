@@ -187,7 +187,7 @@ def parity_leg(args, K, B, device):
             hf_note = f"HF reference scorer unavailable ({type(e).__name__}: {e}): vs_hf not measured"
     from mcm_amd.parity import REALISTIC_PIXELS, meets_bar
 
-    arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16")))
+    arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16", "fp16+refine")))
     c3 = tuple(args.drift_n) == (50000, 10000)  # default: BASELINE config 3 — ImageNet-1k vs the four OOD sets
     ood_sets = CONFIG3_OOD_SETS if c3 else None
     out = {"config": "BASELINE config 3: ImageNet-1k-sized ID set (50 000) vs iNaturalist / SUN / Places / Textures-sized "
@@ -212,7 +212,7 @@ def parity_leg(args, K, B, device):
         r = {"auroc_fp32_arm": d["reference"]["auroc"], "fpr95_fp32_arm": d["reference"]["fpr95"],
              "score_std_id": d["reference"]["score_std_id"], "seconds": time.perf_counter() - t0,
              "fp16_saturation_events": d["fp16_saturation_events"].get("fp16"),
-             "weight_operands": d["weight_operands"],
+             "weight_operands": d["weight_operands"], "refine": d.get("refine"),
              "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys + ("max_set",) + (("per_set",) if c3 else ())} for p in arms_w}}
         if "external" in d:
             r["auroc_hf"], r["fpr95_hf"] = d["external"]["hf"]["auroc"], d["external"]["hf"]["fpr95"]
@@ -384,6 +384,7 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
     ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
     ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
+    ap.add_argument("--group-n", type=int, default=0, help="A/B hook (harness library): N tiles of the persistent walk in groups of g")
     ap.add_argument("--nsplit", type=int, default=1, help="A/B hook (harness library): QKV / fc1 as n column-block launches")
     ap.add_argument("--idle-ms", type=float, default=-1.0,
                     help="measurement hook (DESIGN.md 5.5, the energy reading of the step): >= 0 = synchronise after every "
@@ -421,7 +422,7 @@ def main():
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1 or args.group_n > 0)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
@@ -430,6 +431,8 @@ def main():
         net._lib.mcm_debug_ln_fold(args.ln_fold)
     if args.ln_tail >= 0:
         net._lib.mcm_debug_ln_tail(args.ln_tail)
+    if args.group_n > 0 and net._lib.mcm_debug_gemm_group_n(args.group_n) != 0:
+        raise SystemExit("bad --group-n")
     if args.nsplit > 1 and net._lib.mcm_debug_nsplit(args.nsplit) != 0:
         raise SystemExit("bad --nsplit")
     txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
@@ -542,6 +545,8 @@ def main():
             line["harness_ln_tail"] = args.ln_tail
         if args.nsplit > 1:
             line["harness_nsplit"] = args.nsplit
+        if args.group_n > 0:
+            line["harness_group_n"] = args.group_n
         if args.idle_ms >= 0:
             line["idle_ms_between_steps"] = args.idle_ms
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"

@@ -67,6 +67,11 @@ def process_args(argv=None):
     p.add_argument("--weight-operands", default="auto", choices=["auto", "single", "split"],
                    help="16-bit modes: one operand per GEMM weight, or W_hi + W_lo (exact for fp32-valued weights, twice "
                         "the GEMM work); auto = split exactly when a weight is not a number of the operand dtype")
+    p.add_argument("--refine-threshold", default="auto", choices=["auto", "on", "off"],
+                   help="re-score the images whose 16-bit score lies within a few noise widths of the FPR95 threshold with the "
+                        "exact-fp32 arm (a few hundred images per run), so that FPR95 is the fp32 arm's number and not "
+                        "merely within 1 - 8 images of it (mcm_amd/refine.py); auto = on for --dtype fp16 / bf16 with the device "
+                        "metrics and an MCM-family --score")
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
@@ -185,27 +190,46 @@ def main(argv=None):
     test_labels = get_test_labels(args, test_loader)
     on_dev = not args.host_metrics and args.score != "maha"  # scores stay in HBM; three metrics come back
     if args.score == "maha":  # reference eval_ood_detection.py:72-79
-        if ws > 1:
-            raise SystemExit("--score maha runs on one GPU (the baseline's fit is a host-side step)")
         args.feat_dim = net.geo.proj_dim
         os.makedirs(args.template_dir, exist_ok=True)
-        if args.generate:
+        # world_size > 1: the fit (a host-side float64 step over the training features) runs on rank 0 only; the two
+        # statistics are broadcast (RCCL) and every rank scores its own shard of each test set (get_Mahalanobis_score)
+        if args.generate and rank == 0:
             n_train = min(N_ID[args.in_dataset], args.max_count * args.n_cls) if args.subset else N_ID[args.in_dataset]
             train_loader = _loader(args, net, "train", n_train, False, sources)
             get_mean_prec(args, net, train_loader)
         # like the reference (:77-78) the statistics are always read back from the files get_mean_prec wrote —
         # or that an earlier run wrote, which is what `--generate ""` (argparse's only falsy bool) is for
-        stats = {}
-        for what in ("classwise_mean", "precision"):
-            f = os.path.join(args.template_dir, maha_file_name(args, what))
-            if not os.path.exists(f):
-                raise SystemExit(f"--generate is off and {f} does not exist: run once with --generate True")
-            stats[what] = torch.load(f, map_location="cpu")
+        stats = {"classwise_mean": torch.empty((args.n_cls, args.feat_dim)), "precision": torch.empty((args.feat_dim, args.feat_dim))}
+        if rank == 0:
+            for what in ("classwise_mean", "precision"):
+                f = os.path.join(args.template_dir, maha_file_name(args, what))
+                if not os.path.exists(f):
+                    raise SystemExit(f"--generate is off and {f} does not exist: run once with --generate True")
+                stats[what] = torch.load(f, map_location="cpu").float().contiguous()
+        if ws > 1:
+            mdist.broadcast_tensors([stats["classwise_mean"], stats["precision"]], src=0)
         classwise_mean, precision = stats["classwise_mean"], stats["precision"]
         in_score = get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True)
     else:
         in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
     net.warn_if_saturated(f"the ID set {args.in_dataset}")
+    refiner, net32 = None, None
+    if args.refine_threshold != "off" and on_dev and args.dtype != "fp32":
+        from mcm_amd.detection import prompt_bank
+        from mcm_amd.refine import Rescorer, ThresholdRefiner
+
+        # the exact-fp32 arm over the same weights; the prompt bank is the 16-bit handle's (its text tower is exact fp32 too)
+        net32 = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision="fp32",
+                            max_batch=min(args.batch_size, 256), synthetic_regime=args.synthetic_weights)
+        set_loaders = {"id": test_loader}
+        refiner = ThresholdRefiner(Rescorer(net32, prompt_bank(args, net, test_labels), set_loaders, args.T, args.score))
+        refiner.fit_id(in_score)
+        log.debug("threshold refinement: 16-bit score noise (max over %d calibration images) %.2e, window +-%.2e around the "
+                  "FPR95 threshold, %d ID images re-scored in fp32" % (refiner.stats["calibration_images"],
+                  refiner.stats["noise_max_abs"], refiner.stats["delta"], refiner.stats["rescored"]["id"]))
+    elif args.refine_threshold == "on":
+        raise SystemExit("--refine-threshold on needs a 16-bit --dtype, the device metrics and an MCM-family --score")
     auroc_list, aupr_list, fpr_list = [], [], []
     result = {"in_score": in_score, "out_scores": {}, "rank": rank, "world_size": ws, "sources": sources,
               "log_directory": args.log_directory}
@@ -217,6 +241,10 @@ def main(argv=None):
             out_score = get_Mahalanobis_score(args, net, ood_loader, classwise_mean, precision, in_dist=False)
         else:
             out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
+            if refiner is not None:
+                set_loaders[out_dataset] = ood_loader
+                refiner.apply(out_dataset, out_score)
+                log.debug(f"threshold refinement: {refiner.stats['rescored'][out_dataset]} images of {out_dataset} re-scored in fp32")
         result["out_scores"][out_dataset] = out_score
         net.warn_if_saturated(out_dataset)
         if rank == 0:
@@ -238,6 +266,9 @@ def main(argv=None):
                       "checks, not the paper's accuracy")
         with open(os.path.join(args.log_directory, "data_sources.json"), "w") as f:
             json.dump({"weights": args.weights or "seeded synthetic", "sets": sources}, f, indent=1)
+    if refiner is not None:
+        result["refine"] = refiner.stats
+        net32.close()
     # programmatic callers (tests) get the scores back; as device tensors they outlive the handle (torch owns them)
     net.close()
     if ws > 1:

@@ -344,6 +344,10 @@ int mcm_debug_qkv_chunks(int32_t n);
 /* A/B: the wide store GEMMs (QKV projection, fc1) as n launches over column blocks of N / n (1 = shipped: one launch).
  * The W re-fetch experiment of DESIGN.md / EXPERIMENTS.md: only N / n of W is live in an XCD's L2 per launch. */
 int mcm_debug_nsplit(int32_t n);
+/* A/B: the persistent kernels walk their N tiles in groups of gn (0 = plain n-fastest walk, the shipped behaviour): only gn
+ * N-tiles of W are live in an XCD's L2 at a time.  Honoured by gemm_p256_kernel and by the arms text of the ping-pong kernel
+ * (variant 9); the shipped ping-pong kernel walks plainly. */
+int mcm_debug_gemm_group_n(int32_t gn);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */

@@ -764,8 +764,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const int total = ntl * nk;
 
   const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
-  struct Cursor { int mtl, nt; };
+  // GROUPED walk (A/B, mcm_debug_gemm_group_n / gemm_set_group_n): the N tiles of this XCD's list are walked in groups of
+  // a.gn — all row tiles against N tiles [0, gn), then [gn, 2 gn), ... — so only gn / nbn of W is live in the XCD's L2 at a
+  // time (fc1: 4 of 12 tiles = 1.6 of 4.7 MB), at the price of reading every X panel nbn / gn times.  Unlike cutting the
+  // GEMM into column-block launches (mcm_debug_nsplit) it adds no ragged round.  Tile ordinal -> (mtl, nt) by tile_of.
+  const bool grouped = a.gn > 0 && a.gn < nbn;
+  struct Cursor { int mtl, nt, q; };
   auto cursor_next = [&](Cursor& c) {
+    if (grouped) {
+      c.q += G8;
+      tile_of(c.q, nmt_x, nbn, a.gn, c.mtl, c.nt);
+      return;
+    }
     c.mtl += dmt;
     c.nt += dnt;
     if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
@@ -793,7 +803,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     c.fo1 = frag_off(l & 15, l >> 4, 1);
     return c;
   };
-  Cursor ci{jx / nbn, jx % nbn};
+  Cursor ci{jx / nbn, jx % nbn, jx};
+  if (grouped) tile_of(jx, nmt_x, nbn, a.gn, ci.mtl, ci.nt);
   int ji = 0, kti = 0;
   const char *tx, *tw;  // uniform: first byte of this wave's rows of the tile being staged
   auto set_issue_tile = [&]() {
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       for (int fj = 0; fj < 4; ++fj) mfma_pair(wf[1][fj], xf[fi], acc[fj][fi]);
   };
 
-  Cursor cc{jx / nbn, jx % nbn};
+  Cursor cc = ci;  // (the issue cursor has not moved yet)
   int em0 = 0, en0 = 0;  // tile whose epilogue is pending
   constexpr bool FOLD_OUT = FOLD && EPI <= EPI_GELU;  // consumer side of the LayerNorm fold
   static_assert(!FOLD || (PREC != MCM_PREC_F32 && EPI != EPI_PATCH), "LayerNorm fold: 16-bit operand modes");

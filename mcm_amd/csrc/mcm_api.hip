@@ -1166,6 +1166,11 @@ int mcm_debug_qkv_head_major(int32_t on) {
   g_qkv_head_major = on ? 1 : 0;
   return MCM_OK;
 }
+int mcm_debug_gemm_group_n(int32_t gn) {  // 0 (default): the plain n-fastest walk; g > 0: N tiles walked in groups of g (arms kernel, variant 9)
+  if (gn < 0 || gn > 64) return MCM_EINVAL;
+  gemm_set_group_n(gn);
+  return MCM_OK;
+}
 int mcm_debug_nsplit(int32_t n) {  // 1 (shipped): one launch per GEMM; 2 / 3 / 4: QKV and fc1 as n column-block launches
   if (n < 1 || n > 4) return MCM_EINVAL;
   g_nsplit = n;

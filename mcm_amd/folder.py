@@ -79,6 +79,10 @@ class ImageFolderU8:
     def shard(self, lo: int, hi: int) -> "ImageFolderU8":
         return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi, self.workers)
 
+    def gather(self, indices):
+        """uint8 [b,S,S,3] device batch of the named samples (threshold refinement, mcm_amd/refine.py)."""
+        return self.net.resize_crop([__import__("torch").from_numpy(_decode_rgb(self.dataset.samples[int(i)][0])) for i in indices])
+
     def decoded_batches(self) -> Iterator:
         """Host side only: `(list of decoded uint8 [H,W,3] arrays, labels int64 [b])` per batch, in dataset order; with
         `workers` > 1 batch i+1 is decoded by the pool while the consumer works on batch i."""

@@ -86,7 +86,12 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         raise ValueError(weights)
     ids, mask = make_token_ids(K, seed=2)
     dev = torch.device("cuda", device)
-    names = [ref] + [a for a in arms if a != ref]
+    derived = [a for a in arms if a.endswith("+refine")]  # "fp16+refine": arm "fp16" + threshold refinement (mcm_amd/refine.py)
+    base_arms = [a for a in arms if a not in derived]
+    for a in derived:
+        if a[: -len("+refine")] not in base_arms:
+            base_arms.append(a[: -len("+refine")])
+    names = [ref] + [a for a in base_arms if a != ref]
     nets, banks = {}, {}
     ext = {}
     try:
@@ -114,14 +119,29 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                     parts[e].append(fn(px).to(device=dev, dtype=torch.float32).reshape(-1))
             for p in parts:
                 scores[p][tag] = torch.cat(parts[p])
+        # derived arms: the base arm's scores with the images near the FPR95 threshold re-scored by the exact arm (here the
+        # exact arm has scored everything already, so the callback is a lookup)
+        refine_stats = {}
+        if derived:
+            from .refine import refine_threshold_scores
+
+            for a in derived:
+                b = a[: -len("+refine")]
+                scores[a] = {t: scores[b][t].clone() for t in tags}
+                _, _, st = refine_threshold_scores(scores[a]["id"], {n: scores[a][n] for n, _, _ in sets},
+                                                   lambda name, idx: scores[ref][name][idx])
+                refine_stats[a] = st
+            names = names + derived
         out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood if not ood_sets else {n: c for n, c, _ in sets},
                "batch": batch, "score": score, "T": T, "reference_arm": ref,
                "pixels": {"amp": amp, "tile": tile, "tile_ood": t_ood},
                "weights": weights if state_dict is None else "caller's state dict", "arms": {}}
         # fp16 activations that hit +-65504 anywhere in the run (sticky per-handle counters; 0 = none)
-        out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in names if _arm_spec(p)[0] == "fp16"}
+        out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in nets if _arm_spec(p)[0] == "fp16"}
         out["weight_operands"] = {p: {"split": nets[p].split_weights, "inexact_elements": nets[p].weights_inexact}
-                                  for p in names}
+                                  for p in nets}
+        if refine_stats:
+            out["refine"] = refine_stats
 
         def measures(p):  # per OOD set, and the AVG row (mean over the sets) — what the metrics are quoted on
             per = {n: nets[ref].measures(scores[p]["id"], scores[p][n], negate=True) for n, _, _ in sets}
@@ -196,6 +216,17 @@ def _operating_point(net, pool: Dict, ref: str, target: float, ext: Sequence[str
     a = 0.5 * (lo + hi)
     m = split(a)
     n_id, n_ood = int(m.sum()), int((~m).sum())
+    refine_stats = {}
+    for p in [p for p in pool if p.endswith("+refine")]:  # threshold refinement on THIS split (mcm_amd/refine.py)
+        from .refine import refine_threshold_scores
+
+        b = p[: -len("+refine")]
+        sid, sood = pool[b][m].clone(), pool[b][~m].clone()
+        rid, rood = pool[ref][m], pool[ref][~m]
+        _, _, refine_stats[p] = refine_threshold_scores(sid, {"ood": sood}, lambda name, idx: (rid if name == "id" else rood)[idx])
+        patched = pool[b].clone()
+        patched[m], patched[~m] = sid, sood
+        pool[p] = patched
     meas = {p: net.measures(pool[p][m], pool[p][~m], negate=True) for p in pool}
     r = meas[ref]
     out = {"target_auroc": target, "a": a, "n_id": n_id, "n_ood": n_ood,
@@ -215,6 +246,8 @@ def _operating_point(net, pool: Dict, ref: str, target: float, ext: Sequence[str
             out["arms"][p]["vs_external"] = {e: delta(p, e) for e in ext}
     if ext:
         out["reference"]["vs_external"] = {e: delta(ref, e) for e in ext}
+    if refine_stats:
+        out["refine"] = refine_stats
     return out
 
 

@@ -99,6 +99,14 @@ class SyntheticLoader:
         """Loader over the sub-range [lo, hi) of the same dataset (per-rank shard)."""
         return SyntheticLoader(self.dataset, self.batch_size, lo, hi)
 
+    def gather(self, indices):
+        """Pixels of the named samples (threshold refinement, mcm_amd/refine.py)."""
+        import torch
+
+        d = self.dataset
+        return torch.from_numpy(np.concatenate([make_pixels(1, d.size, d.n_classes, ood=d.ood, seed=d.seed, start=int(i))[0]
+                                                for i in indices]))
+
     def __iter__(self) -> Iterator:
         import torch
 
@@ -165,7 +173,30 @@ class DevicePatternLoader:
         return DevicePatternLoader(d.n, d.size, d.n_classes, self.batch_size, self.device, ood=d.ood,
                                    seed=d.seed, amp=self.amp, noise=self.noise, tile=self.tile, lo=lo, hi=hi)
 
+    def gather(self, indices):
+        """Pixels of the named samples (any order) — the same values iteration yields for them (threshold refinement,
+        mcm_amd/refine.py).  Generated block by block: every aligned 64-image block that holds a wanted sample once."""
+        import torch
+
+        idx = [int(i) for i in indices]
+        if not idx:
+            return torch.empty((0, 3, self.dataset.size, self.dataset.size), device=self.device)
+        out = [None] * len(idx)
+        by_block = {}
+        for pos, i in enumerate(idx):
+            by_block.setdefault(i // self.BLOCK, []).append((pos, i))
+        for b, items in sorted(by_block.items()):
+            lo = b * self.BLOCK
+            hi = min(lo + self.BLOCK, len(self.dataset))
+            blk = next(iter(self.shard(lo, hi)._range_batches(self.BLOCK)))[0]
+            for pos, i in items:
+                out[pos] = blk[i - lo]
+        return torch.stack(out)
+
     def __iter__(self) -> Iterator:
+        return self._range_batches(self.batch_size)
+
+    def _range_batches(self, batch_size) -> Iterator:
         import torch
 
         d, dev = self.dataset, self.device
@@ -176,8 +207,8 @@ class DevicePatternLoader:
         ch = torch.arange(3, device=dev, dtype=torch.float32).view(1, 3, 1, 1)
         w = 2 * math.pi / S
         B = self.BLOCK
-        for s in range(self.lo, self.hi, self.batch_size):
-            n = min(self.batch_size, self.hi - s)
+        for s in range(self.lo, self.hi, batch_size):
+            n = min(batch_size, self.hi - s)
             parts = []
             for b in range(s // B, (s + n - 1) // B + 1):
                 g.manual_seed(((d.seed << 24) ^ (fam << 23)) + b)

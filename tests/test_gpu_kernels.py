@@ -243,7 +243,16 @@ def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, pre
                 got = run(variant)
                 assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
                     f"variant {variant}"
+        # the grouped tile walk (N tiles in groups of g: the W re-fetch A/B of EXPERIMENTS.md) visits the same tiles in
+        # another order: same bits, in the arms text of the ping-pong kernel (9) and in the plain persistent kernel (3)
+        for gn in (1, 2, 4):
+            assert harness_net._lib.mcm_debug_gemm_group_n(gn) == 0
+            for variant in (9, 3):
+                got = run(variant)
+                assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
+                    f"group_n {gn} variant {variant}"
     finally:
+        harness_net._lib.mcm_debug_gemm_group_n(0)
         harness_net._lib.mcm_debug_gemm_variant(-1)
 
 
