@@ -285,7 +285,7 @@ def ingest_legs(net, txt, B, steps, which):
         base = {hw: rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8) for hw in sizes}
         batch = [base[sizes[i % len(sizes)]] for i in range(B)]
         nbytes = PackedImagePipe.packed_bytes(batch)
-        pipe = PackedImagePipe(net, B, nbytes + (1 << 20), pack_threads=min(16, os.cpu_count() or 1))
+        pipe = PackedImagePipe(net, B, nbytes + (1 << 20), pack_threads=int(os.environ.get("MCM_PACK_THREADS", min(16, os.cpu_count() or 1))))
         for px in pipe.stream([batch, batch]):
             net.score_images(px, txt, 1.0, "MCM", out=sc)
         torch.cuda.synchronize()

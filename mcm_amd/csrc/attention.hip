@@ -281,6 +281,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     seq = sj * 8 + (bid & 7);
     h = j - sj * heads;
   }
+  // Which wave takes which q-blocks.  The q-blocks are dealt round-robin to the waves (13 blocks on 8 waves: 2-2-2-2-2-1-1-1),
+  // and waves w and w + 4 share a SIMD, so SIMD 0 always carried 4 blocks and the others 3 — and the kernel is bound by
+  // the VALU / transcendental issue of its softmax (exp2 runs at quarter rate), i.e. by the busiest SIMD.  With rev & 4
+  // the deal is rotated by the workgroup's index (bits 3-4: workgroups of one XCD share bid & 7), so the 2.5 workgroups
+  // resident on a CU load different SIMDs most: 3.25 blocks per SIMD on average instead of 4 on one.  Same bits (a
+  // q-block's arithmetic does not depend on the wave that runs it).
+  const int wq = (rev & 4) ? (wave + NW - ((bid >> 3) & 3) % NW) % NW : wave;
   const int D = heads * 64;
   // qkv layout.  Row-major (hm = 0): [rows][3 D], a head's q / k / v are 128-B segments of 4.6-KB rows.  Head-major
   // (hm = rows of the array, what the QKV projection writes in the model): [3 heads][hm][64] — this workgroup's Q, K
@@ -295,10 +302,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   uint4 qf[MAXQB][2];
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
-    const int qr = min((wave + NW * i) * 16 + fr, L - 1);
+    const int qr = min((wq + NW * i) * 16 + fr, L - 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      qf[i][kk] = (wave + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
+      qf[i][kk] = (wq + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
                                        : make_uint4(0, 0, 0, 0);
   }
   for (int blk = wave; blk < LP / 8; blk += NW) {  // 1-KiB pieces: 8 key rows each
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
 
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
-    const int qb = wave + NW * i;
+    const int qb = wq + NW * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
     const uint4 q0 = qf[i][0], q1 = qf[i][1];
@@ -616,6 +623,7 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   const int nt = (L + 15) / 16;
 #ifdef MCM_HARNESS
   if (g_attn_variant == 10 && nseq % 8 == 0) rev |= 2;  // XCD-aware deal of the (sequence, head) workgroups
+  if (g_attn_variant == 11) rev |= 4;                   // q-blocks dealt to the waves rotated per workgroup (SIMD balance)
 #endif
 #ifdef MCM_HARNESS  // priority A/B arms, B/16 shape only (13 key tiles)
   if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);

@@ -1131,7 +1131,7 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
 
 #ifdef MCM_HARNESS  // libmcm_hip_harness.so only: process-wide A/B switches for tests and tools
 int mcm_debug_attention_variant(int32_t variant) {
-  if (variant < 0 || variant > 10) return MCM_EINVAL;
+  if (variant < 0 || variant > 11) return MCM_EINVAL;
   attention_set_variant(variant);
   return MCM_OK;
 }

@@ -469,7 +469,7 @@ def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causa
     try:
         # -1: the shipped library; 1 / 0: both kernels forced in the harness library; 10: the XCD-aware deal of the
         # workgroups (sequence counts that are multiples of 8; the plain deal otherwise)
-        for variant in (-1, 1, 0, 10):
+        for variant in (-1, 1, 0, 10, 11):  # 11: the rotated deal of the q-blocks to the waves (SIMD balance)
             net = tiny_net if variant < 0 else harness_net
             if variant >= 0:
                 assert net._lib.mcm_debug_attention_variant(variant) == 0
@@ -480,7 +480,7 @@ def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causa
             np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=tol, atol=tol,
                                        err_msg=f"variant {variant}")
             outs[variant] = out
-        assert torch.equal(outs[1], outs[10]) and torch.equal(outs[1], outs[-1])
+        assert torch.equal(outs[1], outs[10]) and torch.equal(outs[1], outs[-1]) and torch.equal(outs[1], outs[11])
     finally:
         harness_net._lib.mcm_debug_attention_variant(1)
 
