@@ -384,6 +384,7 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
     ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
     ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
+    ap.add_argument("--patch-fold", type=int, default=-1, help="A/B hook (harness library): 0 = patchify + plain patch GEMM (rounds 1 - 3)")
     ap.add_argument("--group-n", type=int, default=0, help="A/B hook (harness library): N tiles of the persistent walk in groups of g")
     ap.add_argument("--nsplit", type=int, default=1, help="A/B hook (harness library): QKV / fc1 as n column-block launches")
     ap.add_argument("--idle-ms", type=float, default=-1.0,
@@ -422,7 +423,7 @@ def main():
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
     net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1 or args.group_n > 0)
+                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1 or args.group_n > 0 or args.patch_fold >= 0)
     if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
         raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
     if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
@@ -431,6 +432,8 @@ def main():
         net._lib.mcm_debug_ln_fold(args.ln_fold)
     if args.ln_tail >= 0:
         net._lib.mcm_debug_ln_tail(args.ln_tail)
+    if args.patch_fold >= 0:
+        net._lib.mcm_debug_patch_fold(args.patch_fold)
     if args.group_n > 0 and net._lib.mcm_debug_gemm_group_n(args.group_n) != 0:
         raise SystemExit("bad --group-n")
     if args.nsplit > 1 and net._lib.mcm_debug_nsplit(args.nsplit) != 0:
@@ -547,6 +550,8 @@ def main():
             line["harness_nsplit"] = args.nsplit
         if args.group_n > 0:
             line["harness_group_n"] = args.group_n
+        if args.patch_fold >= 0:
+            line["harness_patch_fold"] = args.patch_fold
         if args.idle_ms >= 0:
             line["idle_ms_between_steps"] = args.idle_ms
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"

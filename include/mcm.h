@@ -191,6 +191,13 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
 int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const int32_t* heights,
                        const int32_t* widths, int32_t B, uint8_t* dst_dev, void* stream);
 
+/* Host side of the raw-image ingest: copies n images (host pointers srcs[i], sizes[i] bytes) to dst + offsets[i] — the ONE
+ * pinned buffer a batch is uploaded from with a single asynchronous copy (replaces the loader's per-batch `.cuda()` of
+ * reference utils/detection_util.py:222-223) — with `threads` native threads, the work cut by bytes.  Pure host code;
+ * MCM_ERANGE when an image does not fit dst_bytes. */
+int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, const int64_t* offsets, int32_t n, uint8_t* dst,
+                int64_t dst_bytes, int32_t threads);
+
 /* Prompt-ensemble bank (BASELINE config 5): feats_dev = unit-norm text
  * features [K*T, proj_dim], class-major (row k*T + t = template t of class k), as written by
  * mcm_encode_text; bank_dev [K, proj_dim] = normalise(mean over the T templates).  The reference
@@ -348,6 +355,9 @@ int mcm_debug_nsplit(int32_t n);
  * N-tiles of W are live in an XCD's L2 at a time.  Honoured by gemm_p256_kernel and by the arms text of the ping-pong kernel
  * (variant 9); the shipped ping-pong kernel walks plainly. */
 int mcm_debug_gemm_group_n(int32_t gn);
+/* A/B: 1 (default, shipped) = the patch-embedding GEMM gathers its A operand from the fp32 NCHW pixels itself; 0 = the
+ * rounds 1 - 3 route (patchify writes a patch matrix, the GEMM reads it back).  Bit-identical. */
+int mcm_debug_patch_fold(int32_t on);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */

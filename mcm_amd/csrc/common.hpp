@@ -189,6 +189,8 @@ struct GemmArgs {
   int ldx;            // elements
   int ldo;            // elements (row stride of out / resid)
   int np;             // EPI_PATCH: patches per image
+  const float* px;    // EPI_PATCH: NCHW fp32 pixels [B,3,img,img] to gather the A operand from (nullptr: read `x`, the patch
+  int img, patch;     //   matrix patchify wrote); image and patch size.  See gemm_patch_takes_pixels / gemm_p256_kernel
   int gn;             // persistent kernel: N-tiles per L2 group (0 = default)
   int rev;            // persistent kernel: walk the M tiles from the last to the first
   int dbg;            // ablation bits, read only in -DMCM_HARNESS builds: 1 no refill, 2 no MFMA, 4 no epilogue
@@ -234,6 +236,7 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a, hipStream_t s);
 // which LayerNorm-fold form launch_gemm has for this problem: 1 = ping-pong kernel (producer and consumer epilogues),
 // 2 = tile kernel (consumer epilogue only; its producer is launch_fold_rows after the plain residual GEMM), 0 = none
 int gemm_fold_kind(int epi, int M, int N);
+bool gemm_patch_takes_pixels(int prec, int M, int N, int kpad, int patch, int image);
 bool gemm_ln_tail_ok(int prec, int M, int N);
 int gemm_persistent_grid();
 // LayerNorm fold, weight side: c[n] = sum_k gamma[k] W[n,k], bfold[n] = bias[n] + sum_k beta[k] W[n,k]  (W: operand dtype)

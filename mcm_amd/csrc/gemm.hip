@@ -580,8 +580,27 @@ constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 4096;  // 128 KiB of stages + 4 KiB epilogue window per wave
 }  // namespace p256
 
-template <int PREC, int EPI, bool COUNT_STORES>
+// 16-byte global load / store from inline asm with a scalar base and a 32-bit lane offset: invisible to hipcc's waitcnt
+// pass, counted by the caller (used by the fp32 interior epilogue below and by the pixel-gathering A operand of the patch GEMM)
+__device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+// EPI_PATCH with GemmArgs::px — the im2col-free patch embedding (HF modeling_clip.py:148-154,209-210: a
+// Conv2d with kernel = stride = P is a GEMM over gathered pixels).  The A operand is not read from a patch matrix: each
+// lane fetches the 8 (fp32 mode: 4) consecutive pixels behind its 16-byte LDS chunk straight from the NCHW fp32 image —
+// k = (c, py, px) is the [D,3,P,P] weight flattening, so a chunk is 32 contiguous bytes of one image row — converts them
+// (the same single-instruction packs patchify used: same bits) and writes them to the slot the LDS-DMA would have
+// filled.  Loads are issued where the DMA for the next K-step is issued and committed to LDS at the end of the current
+// step, a whole K-step of MFMAs later.  The 154-MB patch matrix (written by one kernel, read back by this one) is gone.
+// PXF is its own instantiation (not a run-time branch): without the X row pointers and the bias registers of the plain form
+// the 32 registers of pixel loads in flight fit the 256-register budget; with both forms in one kernel hipcc spilled 13.
+template <int PREC, int EPI, bool COUNT_STORES, bool PXF = false>
 __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
+  static_assert(!PXF || EPI == EPI_PATCH, "pixel gathering: the patch embedding only");
   using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -607,6 +626,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   const char* gx[4];
   const char* gw[4];
   int ji = 0, kti = 0;
+  constexpr int EC = 16 / ES, KS = ROWB / ES;  // elements per 16-B chunk / per K-step
+  uint32_t pxoff[4] = {0u, 0u, 0u, 0u};  // PXF: byte offset of this lane's pixels at (c, py) = (0, 0), per piece
+  f32x4_t xr[4][2];                        // PXF: the pixel loads in flight
+  int xst = 0;                             // ... and the LDS stage they belong to
   // Tile walk.  With the default plain n-fastest order (gn >= nbn) the next tile of this workgroup
   // is G8 tiles further on, so (m-tile, n-tile) advance by a fixed (G8 / nbn, G8 % nbn) with one
   // carry: no division on the tile switch, which sits on the refill path of waves 0-3.  Interior
@@ -639,25 +662,57 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
       const char* wb = wlane + (size_t)n0 * sw;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        gx[p] = xb + (size_t)(p * 64) * sx;
+        if constexpr (!PXF) gx[p] = xb + (size_t)(p * 64) * sx;
         gw[p] = wb + (size_t)(p * 64) * sw;
       }
     } else {  // edge tile: rows past the end re-read the last row (their results are never stored)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        gx[p] = (const char*)a.x + (size_t)min(m0 + p * 64 + r0, a.M - 1) * sx + chunk * 16;
+        if constexpr (!PXF) gx[p] = (const char*)a.x + (size_t)min(m0 + p * 64 + r0, a.M - 1) * sx + chunk * 16;
         gw[p] = (const char*)a.w + (size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * sw + chunk * 16;
+      }
+    }
+    if constexpr (PXF) {
+      {  // row m = (image b, patch gy * g + gx); this lane's chunk starts at element e of the K-step
+        const int P = a.patch, S = a.img, gsz = S / P;
+        const int e = chunk * EC, dpy = e / P, pxl = e - dpy * P;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = min(m0 + p * 64 + r0, a.M - 1);
+          const int b = m / a.np, pp = m - b * a.np, gy = pp / gsz, gxx = pp - gy * gsz;
+          pxoff[p] = (uint32_t)((((size_t)b * 3 * S + (size_t)gy * P + dpy) * S + (size_t)gxx * P + pxl) * 4);
+        }
       }
     }
   };
   const uint32_t lds0 = lds_addr(smem);
+  // PXF: request the pixels of the K-step the issue cursor points at (the cursor is advanced by issue(), called after).
+  // Every wave does this at the TOP of a step — also waves 4-7, whose DMA issue sits in the middle of it — so that the
+  // loads have the whole step's MFMAs to land in.
+  auto issue_px = [&](int st) {
+    // K-step -> (channel c, first patch row py0): KS / P patch rows per step
+    const int r = (kti >> a.ksplit) * (KS / a.patch), c = r / a.patch, py0 = r - c * a.patch;
+    const char* kb = (const char*)a.px + ((size_t)c * a.img + py0) * a.img * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      gload16(xr[p][0], kb, pxoff[p]);
+      if constexpr (ES == 2) gload16(xr[p][1], kb, pxoff[p] + 16u);
+    }
+    xst = st;
+  };
   auto issue = [&](int st) {
     const uint32_t base = lds0 + st * STAGE_BYTES;
     const size_t ko = (size_t)kti * ROWB, kox = (size_t)(kti >> a.ksplit) * ROWB;
+    if constexpr (PXF) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      glds16(gx[p] + kox, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
-      glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
+      for (int p = 0; p < 4; ++p)
+        glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        glds16(gx[p] + kox, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
+        glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
+      }
     }
     if (++kti == nk) {
       kti = 0;
@@ -682,9 +737,33 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 #pragma unroll
   for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // PXF: the pixels requested by the last issue() -> operand dtype -> the LDS slots the DMA would have filled.  Called
+  // where the issuing wave has a whole K-step of MFMAs (waves 4-7: half of one) between the request and this wait.
+  auto commit_x = [&]() {
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      asm volatile("" : "+v"(xr[p][0]));
+      if constexpr (ES == 2) asm volatile("" : "+v"(xr[p][1]));
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      char* dst = smem + xst * STAGE_BYTES + (p * 8 + wave) * 1024 + lane * 16;
+      if constexpr (PREC != MCM_PREC_F32) {
+        *(uint4*)dst = make_uint4(pack2<PREC>(xr[p][0][0], xr[p][0][1]), pack2<PREC>(xr[p][0][2], xr[p][0][3]),
+                                  pack2<PREC>(xr[p][1][0], xr[p][1][1]), pack2<PREC>(xr[p][1][2], xr[p][1][3]));
+      } else {
+        *(f32x4_t*)dst = xr[p][0];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
   cursor_init(ci);
   set_issue_tile();
+  if constexpr (PXF) issue_px(0);
   issue(0);
+  if constexpr (PXF) commit_x();
   int issued = 1;
   int jc = 0, ktc = 0;
   Cursor cc;
@@ -701,13 +780,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     stores_pending = false;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
+    if constexpr (!PXF) {  // (the patch embedding has no bias: bv stays the constant zero it was initialised to)
+      if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
+    }
     // The two waves of a SIMD (w and w+4) take turns: an LDS-DMA instruction blocks its wave for
     // 70-155 cycles while the TA takes the 64 addresses (cycle stamps, MCM_GEMM_TRACE), so if both
     // waves refill at the top of the step the matrix pipe idles through 8 of them and then both
     // waves want it at once.  Waves 0-3 refill first and compute after; waves 4-7 (static
     // priority 1) compute the first K half, refill, compute the second.
     const bool refill = issued < total;
+    if constexpr (PXF) {
+      if (refill) issue_px(issued & 1);
+    }
     if (refill && !late) issue(issued & 1);
     const char* sb = smem + (s & 1) * STAGE_BYTES;
     wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[0], acc);
@@ -715,9 +799,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
     if (refill) ++issued;
     wave_khalf<PREC, 8>(sb + xbase, sb + wbase, foff[1], acc);
     if (++ktc == nk) {
-      if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
+      if constexpr (!PXF) {
+        if (nk < 2) wait_vmcnt<0>();  // bias issued in this very step
 #pragma unroll
-      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+        for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
+      }
       wave_epilogue_lds<PREC, EPI, 8>(a, acc, bv, cm0 + wr * 128, cn0 + wc * 64, lane,
                                       smem + 2 * STAGE_BYTES + wave * 4096, amax);
       zero_acc<8>(acc);
@@ -729,6 +815,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
         cn0 = cc.nt * BN;
       }
     }
+    if constexpr (PXF) {
+      if (refill) commit_x();  // the next step's X pixels, before the barrier that opens it
+    }
   }
   sat_report<PREC>(amax, a.sat);
 }
@@ -739,12 +828,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
 // vmcnt(0) in front of the fragment reads or the MFMAs of the K loop (it did, once the epilogue's plain
 // stores were inlined into the loop: the wait drains the LDS-DMA stream, -20 % on fc2).  The queue at the wait
 // of chunk c, oldest first: [older] [loads c] [stores c-1] [loads c+1]  =>  vmcnt <= 8 (<= 4 at both ends).
-__device__ __forceinline__ void gload16(f32x4_t& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void gstore16(const void* sbase, uint32_t voff, const f32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_pin(f32x4_t (&b)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
@@ -1155,16 +1238,16 @@ hipError_t launch_tile64(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, int EPI, bool CS>
+template <int PREC, int EPI, bool CS, bool PXF = false>
 hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS, PXF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS, PXF>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
@@ -1210,6 +1293,9 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
 #else
   if (a.fold_z || a.fold_rs || a.ln_y) return hipErrorInvalidValue;  // A/B arms: not in the shipped library
 #endif
+  if constexpr (EPI == EPI_PATCH) {
+    if (a.px) return launch_p256<PREC, EPI, false, true>(a, s);  // the pixel-gathering form of the persistent kernel
+  }
   if (v == 0 || v == 11) {
     // 64x128 tiles when the 128x128 kernel would get fewer than two workgroups per CU (batch <= 32 at B/16, the text
     // tower's short prompts banks, B/32): twice the workgroups, the same bits (round 3: batch 8 +7.5 %, batch 16 +4.5 %)
@@ -1260,6 +1346,15 @@ bool gemm_ln_tail_ok(int prec, int M, int N) {
 #endif
   if (prec == MCM_PREC_F32 || M <= 0 || M % p256::BM || (N != 768 && N != 1024)) return false;
   return size_policy(M, N) == 5 && persistent_grid() >= 8;
+}
+
+// The patch GEMM can gather its A operand from the NCHW fp32 pixels (GemmArgs::px) when the problem is one the persistent
+// kernel takes anyway and the patch geometry fits a K-step: P | K-step elements, P a multiple of the chunk, no K padding.
+bool gemm_patch_takes_pixels(int prec, int M, int N, int kpad, int patch, int image) {
+  const int es = prec_esize(prec), ks = ROWB / es, ec = 16 / es;
+  if (patch <= 0 || image % patch || patch % ec || ks % patch || kpad != 3 * patch * patch) return false;
+  if ((size_t)M / ((size_t)(image / patch) * (image / patch)) * 3 * image * image * 4 >= (1ull << 32)) return false;  // 32-bit lane offsets
+  return size_policy(M, N) != 0 && persistent_grid() >= 8;
 }
 
 int gemm_fold_kind(int epi, int M, int N) {

@@ -178,6 +178,11 @@ bool next_dir(mcm_handle* h) {
   return h->flip;
 }
 #ifdef MCM_HARNESS
+int g_patch_fold = 1;  // A/B (mcm_debug_patch_fold): 0 = patchify + plain patch GEMM (rounds 1 - 3), 1 = pixel-gathering patch GEMM
+#else
+constexpr int g_patch_fold = 1;
+#endif
+#ifdef MCM_HARNESS
 int g_nsplit = 1;  // A/B (mcm_debug_nsplit): the wide store GEMMs (QKV, fc1) as n launches over column blocks of N / n
 #endif
 hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs& a_in) {
@@ -760,7 +765,12 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
   hipStream_t s = (hipStream_t)stream;
   const mcm_config& c = h->cfg;
   const int D = c.v_width;
-  {
+  // fp32 NCHW pixels: the patch GEMM gathers its A operand from the image itself (gemm_p256_kernel, GemmArgs::px) when the
+  // geometry allows (B/16, B/32 at batches the persistent kernel takes); otherwise — uint8 ingest, L/14's padded K, small
+  // batches — patchify writes the patch matrix first
+  const bool from_px = !u8 && g_patch_fold &&
+                       gemm_patch_takes_pixels(c.precision, B * h->np, D, h->kpad, c.patch_size, c.image_size);
+  if (!from_px) {
     Scope sc(h, s, MCM_KC_PATCHIFY, 0.0);
     if (u8)
       HIP_TRY(h, launch_patchify_u8(c.precision, (const uint8_t*)pixels_dev, h->patches, B, c.image_size,
@@ -770,6 +780,7 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
                                  c.patch_size, h->kpad, s));
   }
   GemmArgs a{};
+  a.px = from_px ? (const float*)pixels_dev : nullptr; a.img = c.image_size; a.patch = c.patch_size;
   a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
   a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
   a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np; a.ksplit = h->vis.split ? 1 : 0;
@@ -1164,6 +1175,10 @@ int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host) {  // ticket
 }
 int mcm_debug_qkv_head_major(int32_t on) {
   g_qkv_head_major = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_patch_fold(int32_t on) {  // 1 (shipped): the patch GEMM gathers pixels itself; 0: patchify + plain GEMM
+  g_patch_fold = on ? 1 : 0;
   return MCM_OK;
 }
 int mcm_debug_gemm_group_n(int32_t gn) {  // 0 (default): the plain n-fastest walk; g > 0: N tiles walked in groups of g (arms kernel, variant 9)

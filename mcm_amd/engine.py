@@ -84,10 +84,13 @@ def load_library(harness: bool = False):
         L.mcm_debug_gemm_dbg.argtypes = [i32]
         L.mcm_debug_nsplit.argtypes = [i32]
         L.mcm_debug_gemm_group_n.argtypes = [i32]
+        L.mcm_debug_patch_fold.argtypes = [i32]
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mcm_resize_crop_u8.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), i32, vp, vp]
+    L.mcm_pack_u8.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), i32, vp,
+                              ctypes.c_int64, i32]
     L.mcm_tokenizer_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp)]
     L.mcm_tokenizer_destroy.argtypes = [vp]
     L.mcm_tokenizer_destroy.restype = None
@@ -122,12 +125,12 @@ EXPORTED_SYMBOLS = [
     "mcm_encode_image_raw", "mcm_maha_prepare", "mcm_maha_score_features",
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
     "mcm_saturation_check", "mcm_saturation_count",
-    "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight",
+    "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight", "mcm_pack_u8",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
                         "mcm_debug_ln_tail", "mcm_debug_ln_tail_timeouts", "mcm_debug_nsplit",
-                        "mcm_debug_gemm_group_n"]
+                        "mcm_debug_gemm_group_n", "mcm_debug_patch_fold"]
 
 
 def _stream_ptr():

@@ -145,14 +145,10 @@ class PackedImagePipe(_Pipe):
         super().__init__(net, int(max_bytes_per_batch), depth)
         import torch
 
-        # packing a batch is a host memcpy of every image into the pinned buffer (~0.3 GB per 512 raw images): numpy
-        # releases the GIL for it, so a few threads share it
+        # packing a batch is a host memcpy of every image into the pinned buffer (~0.3 GB per 512 raw images): done by
+        # `pack_threads` native threads, the work cut by bytes (mcm_pack_u8, csrc/ingest.cpp)
         self.pack_threads = max(1, int(pack_threads))
-        self._pool = None
-        if self.pack_threads > 1:
-            from concurrent.futures import ThreadPoolExecutor
-
-            self._pool = ThreadPoolExecutor(self.pack_threads)
+        self._lib = net._lib
 
         S = net.geo.image_size
         self.out = [torch.empty((self.max_batch, S, S, 3), dtype=torch.uint8, device=self.device) for _ in self.slots]
@@ -180,22 +176,22 @@ class PackedImagePipe(_Pipe):
             self.slots[self.slots.index(s)] = grown
             s = grown
         offs, hs, ws, o = [], [], [], 0
-        hv = s.host.numpy()
         for a in arrs:
             offs.append(o)
             hs.append(a.shape[0])
             ws.append(a.shape[1])
             o += (a.size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
 
-        def put(lo, hi):
-            for a, off in zip(arrs[lo:hi], offs[lo:hi]):
-                hv[off:off + a.size] = a.reshape(-1)
+        import ctypes
 
-        if self._pool is None or len(arrs) < 2 * self.pack_threads:
-            put(0, len(arrs))
-        else:
-            step = -(-len(arrs) // self.pack_threads)
-            list(self._pool.map(lambda lo: put(lo, min(lo + step, len(arrs))), range(0, len(arrs), step)))
+        arrs = [np.ascontiguousarray(a) for a in arrs]
+        n = len(arrs)
+        srcs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (ctypes.c_int64 * n)(*[a.size for a in arrs])
+        offsets = (ctypes.c_int64 * n)(*offs)
+        rc = self._lib.mcm_pack_u8(srcs, sizes, offsets, n, ctypes.c_void_p(s.host.data_ptr()), s.host.numel(), self.pack_threads)
+        if rc:
+            raise RuntimeError(f"mcm_pack_u8 rc={rc}")
         return s, offs, hs, ws, o
 
     def stream(self, batches: Iterable[Sequence]) -> Iterator:

@@ -169,3 +169,37 @@ def test_get_ood_scores_clip_contract_with_stub_net():
     args.score = "maha"
     with pytest.raises(ValueError):
         get_ood_scores_clip(args, Stub(), SyntheticLoader(ds, 8), class_names(6))
+
+
+def test_native_image_packing_equals_a_python_copy():
+    """mcm_pack_u8 (csrc/ingest.cpp, host code: runs without a GPU): n images of their own sizes into one buffer at given
+    offsets, the work cut by bytes over native threads — same bytes as a Python loop, untouched gaps, range errors."""
+    import ctypes
+
+    import numpy as np
+
+    from mcm_amd.engine import LIB_PATH
+
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    L.mcm_pack_u8.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.c_int32, vp, i64, ctypes.c_int32]
+    rng = np.random.default_rng(3)
+    shapes = [(int(rng.integers(1, 400)), int(rng.integers(1, 500)), 3) for _ in range(97)] + [(1200, 1600, 3), (1, 1, 3)]
+    imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in shapes]
+    offs, o = [], 0
+    for a in imgs:
+        offs.append(o)
+        o += (a.size + 15) // 16 * 16
+    for threads in (1, 3, 16, 64):
+        dst = np.full(o + 32, 0xAB, dtype=np.uint8)
+        want = dst.copy()
+        for a, off in zip(imgs, offs):
+            want[off:off + a.size] = a.reshape(-1)
+        n = len(imgs)
+        srcs = (vp * n)(*[a.ctypes.data for a in imgs])
+        sizes = (i64 * n)(*[a.size for a in imgs])
+        offsets = (i64 * n)(*offs)
+        assert L.mcm_pack_u8(srcs, sizes, offsets, n, dst.ctypes.data_as(vp), dst.size, threads) == 0
+        assert np.array_equal(dst, want), threads
+    assert L.mcm_pack_u8(srcs, sizes, offsets, n, dst.ctypes.data_as(vp), o - 64, 4) == -7     # MCM_ERANGE: last image does not fit
+    assert L.mcm_pack_u8(srcs, sizes, offsets, 0, dst.ctypes.data_as(vp), dst.size, 4) == 0

@@ -344,3 +344,31 @@ def test_prompt_ensemble_bank():
     want /= np.linalg.norm(want, axis=1, keepdims=True)
     assert bank.shape == (7, 64)
     np.testing.assert_allclose(bank, want, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,batches", [("ViT-B/16", (512, 100, 57)), ("ViT-B/32", (512, 300)), ("ViT-L/14", (64,))])
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp32"])
+def test_patch_gemm_gathering_pixels_equals_the_patchify_route(name, batches, precision):
+    """SURVEY.md K1, the im2col-free patch embedding: since round 4 the patch GEMM reads its A operand from the fp32 NCHW
+    pixels itself (gemm_p256_kernel<..., PXF>) wherever the persistent kernel takes the problem and the patch size divides
+    a K-step (B/16, B/32 from batch 56 / 223 on).  Against the rounds 1 - 3 route (patchify writes a patch matrix, the GEMM
+    reads it back; harness switch mcm_debug_patch_fold(0)): the same bits, whole and ragged batches, every dtype; and
+    ViT-L/14 (P = 14, padded K) and small batches keep the old route."""
+    from mcm_amd.engine import NativeCLIP
+
+    geo = geometry(name)
+    B = max(batches)
+    net = NativeCLIP(geo, synth_state_dict(geo, 0, "fp16-exact"), precision=precision, max_batch=B, max_prompt_tokens=77,
+                     harness=True)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(17)
+        px = torch.randn((B, 3, geo.image_size, geo.image_size), generator=g, device="cuda")
+        for b in batches:
+            assert net._lib.mcm_debug_patch_fold(1) == 0
+            got = net.get_image_features(px[:b])
+            assert net._lib.mcm_debug_patch_fold(0) == 0
+            want = net.get_image_features(px[:b])
+            assert torch.isfinite(got).all() and torch.equal(got, want), (name, precision, b)
+    finally:
+        net._lib.mcm_debug_patch_fold(1)
+        net.close()

@@ -123,3 +123,17 @@ def test_pingpong_residual_kernel_with_the_layernorm_tail_keeps_the_k_loop_clean
     plain_mfma = [i for i, l in enumerate(plain) if "v_mfma_f32_16x16x32" in l]
     waits = lambda ls, end: [l.strip() for l in ls[:end] if "s_waitcnt vmcnt" in l]  # noqa: E731
     assert waits(lines, mfma[-1]) == waits(plain, plain_mfma[-1])
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2], ids=["bf16", "fp32", "fp16"])
+def test_pixel_gathering_patch_gemm_does_not_spill(gemm_isa, prec):
+    """gemm_p256_kernel<PREC, EPI_PATCH, false, PXF = true> (the im2col-free patch embedding): 32 registers of pixel loads
+    are in flight across a K-step of MFMAs next to 128 accumulators.  As a run-time branch of the plain kernel it spilled
+    13 registers; as its own instantiation (no X row pointers, no bias registers) it must not touch scratch, must keep the
+    W operand on the LDS-DMA path and fetch pixels with plain 16-byte loads."""
+    m = re.search(r"^(_ZN\S*_116gemm_p256_kernelILi%dELi3ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa, re.S | re.M)
+    assert m, "pixel-gathering patch GEMM not found"
+    body = m.group(0)
+    assert "scratch_" not in body
+    assert "global_load_lds_dwordx4" in body and len(re.findall(r"global_load_dwordx4 v", body)) >= 4
+    assert len(re.findall(r"v_mfma_f32_16x16x(32|4)", body)) in (64, 256)
