@@ -277,7 +277,7 @@ def ingest_legs(net, txt, B, steps, which):
         out["host_u8"] = {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
                           "pcie_gb_per_sec": (pipe.bytes_copied - b0) / dt / 1e9, "bytes_per_image": S * S * 3,
                           "source": "uint8 [B,224,224,3] crops in pinned host memory, one async copy per batch on a copy "
-                                    "stream, 2 device buffers"}
+                                    "stream, 3 device buffers"}
         del pipe, host
     if "host-raw" in which:
         rng = np.random.default_rng(11)

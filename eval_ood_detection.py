@@ -70,8 +70,8 @@ def process_args(argv=None):
     p.add_argument("--refine-threshold", default="auto", choices=["auto", "on", "off"],
                    help="re-score the images whose 16-bit score lies within a few noise widths of the FPR95 threshold with the "
                         "exact-fp32 arm (a few hundred images per run), so that FPR95 is the fp32 arm's number and not "
-                        "merely within 1 - 8 images of it (mcm_amd/refine.py); auto = on for --dtype fp16 / bf16 with the device "
-                        "metrics and an MCM-family --score")
+                        "merely within 1 - 8 images of it (mcm_amd/refine.py); auto = on for --dtype fp16 / bf16 with an "
+                        "MCM-family --score")
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
@@ -215,7 +215,8 @@ def main(argv=None):
         in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
     net.warn_if_saturated(f"the ID set {args.in_dataset}")
     refiner, net32 = None, None
-    if args.refine_threshold != "off" and on_dev and args.dtype != "fp32":
+    refinable = args.score != "maha" and args.dtype != "fp32"  # (with --host-metrics the scores are host arrays: refined in place too)
+    if args.refine_threshold != "off" and refinable:
         from mcm_amd.detection import prompt_bank
         from mcm_amd.refine import Rescorer, ThresholdRefiner
 
@@ -224,12 +225,12 @@ def main(argv=None):
                             max_batch=min(args.batch_size, 256), synthetic_regime=args.synthetic_weights)
         set_loaders = {"id": test_loader}
         refiner = ThresholdRefiner(Rescorer(net32, prompt_bank(args, net, test_labels), set_loaders, args.T, args.score))
-        refiner.fit_id(in_score)
+        refiner.fit_id(in_score if on_dev else torch.from_numpy(in_score))
         log.debug("threshold refinement: 16-bit score noise (max over %d calibration images) %.2e, window +-%.2e around the "
                   "FPR95 threshold, %d ID images re-scored in fp32" % (refiner.stats["calibration_images"],
                   refiner.stats["noise_max_abs"], refiner.stats["delta"], refiner.stats["rescored"]["id"]))
     elif args.refine_threshold == "on":
-        raise SystemExit("--refine-threshold on needs a 16-bit --dtype, the device metrics and an MCM-family --score")
+        raise SystemExit("--refine-threshold on needs a 16-bit --dtype and an MCM-family --score")
     auroc_list, aupr_list, fpr_list = [], [], []
     result = {"in_score": in_score, "out_scores": {}, "rank": rank, "world_size": ws, "sources": sources,
               "log_directory": args.log_directory}
@@ -243,7 +244,7 @@ def main(argv=None):
             out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
             if refiner is not None:
                 set_loaders[out_dataset] = ood_loader
-                refiner.apply(out_dataset, out_score)
+                refiner.apply(out_dataset, out_score if on_dev else torch.from_numpy(out_score))
                 log.debug(f"threshold refinement: {refiner.stats['rescored'][out_dataset]} images of {out_dataset} re-scored in fp32")
         result["out_scores"][out_dataset] = out_score
         net.warn_if_saturated(out_dataset)

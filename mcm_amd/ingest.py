@@ -32,16 +32,18 @@ class _Slot:
 
 
 class _Pipe:
-    """Two (or more) pinned-host / device buffer pairs and a copy stream.  `stage(i)` hands out slot i's pinned host
+    """`depth` pinned-host / device buffer pairs and a copy stream.  THREE by default: the host fills slot k while the GPU
+    scores batch k - 2 and batch k - 1 waits in the queue behind it; with two, filling slot k had to wait for batch k - 2's
+    scoring to finish and the GPU idled through every fill (measured: 26.3 instead of 20.4 ms per 512 raw images).  `stage(i)` hands out slot i's pinned host
     view once the compute stream has finished with the slot's previous contents; `push(slot, nbytes)` issues the
     asynchronous copy; `ready(slot)` makes the current (compute) stream wait for it."""
 
-    def __init__(self, net, slot_bytes: int, depth: int = 2):
+    def __init__(self, net, slot_bytes: int, depth: int = 3):
         import torch
 
         self.net, self.device = net, net.device
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.slots = [_Slot(int(slot_bytes), self.device) for _ in range(max(2, depth))]
+        self.slots = [_Slot(int(slot_bytes), self.device) for _ in range(max(2, depth))]  # (depth 2 still works, slower)
         self.bytes_copied = 0
 
     def stage(self, i: int) -> "_Slot":
@@ -81,7 +83,7 @@ class PinnedBatchPipe(_Pipe):
             scores = net.score_images(dev_batch, bank)  # on the current stream
     """
 
-    def __init__(self, net, max_batch: int, depth: int = 2):
+    def __init__(self, net, max_batch: int, depth: int = 3):
         S = net.geo.image_size
         self.S, self.max_batch = S, int(max_batch)
         super().__init__(net, self.max_batch * S * S * 3, depth)
@@ -140,7 +142,7 @@ class PackedImagePipe(_Pipe):
 
     ALIGN = 16  # every image starts on a 16-byte boundary of the packed buffer
 
-    def __init__(self, net, max_batch: int, max_bytes_per_batch: int, depth: int = 2, pack_threads: int = 1):
+    def __init__(self, net, max_batch: int, max_bytes_per_batch: int, depth: int = 3, pack_threads: int = 1):
         self.max_batch = int(max_batch)
         super().__init__(net, int(max_bytes_per_batch), depth)
         import torch
