@@ -1,17 +1,22 @@
 #!/bin/bash
-# scratch driver (round 4, call 11): 3-deep ingest pipes, ingest tests, metrics test, then the final records of the round
-mkdir -p gpurun_out/r4c11
-O=$PWD/gpurun_out/r4c11
-timeout 900 python -m pytest tests/test_gpu_ingest.py tests/test_gpu_metrics.py tests/test_gpu_round2.py -m gpu -q > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt | cut -c1-200
-B="--no-drift --cpu-seconds 0 --no-arms --sustain-seconds 0"
-for t in 16 16; do
-MCM_PACK_THREADS=$t timeout 300 python bench.py $B --ingest host-raw,host-u8 > $O/bench_ingest$t.json 2> $O/bench_ingest$t.err
+# scratch driver (round 4, call 12): parity of every --score kind; batch sweep and other checkpoints on the shipped tree
+mkdir -p gpurun_out/r4c12
+O=$PWD/gpurun_out/r4c12
+timeout 900 python tools/score_kinds_probe.py 10000 10000 > $O/score_kinds.txt 2> $O/score_kinds.err; cat $O/score_kinds.txt | cut -c1-600
+B="--no-drift --cpu-seconds 0 --no-arms --sustain-seconds 0 --ingest none"
+for b in 8 16 32 64 128 256 768; do
+timeout 300 python bench.py $B --batch $b > $O/bench_b$b.json 2> $O/bench_b$b.err
 python - <<PY
 import json
-d=json.loads(open("$O/bench_ingest$t.json").read().strip().splitlines()[-1])
-print("pack threads $t", round(d["value"]), {k:(round(v["images_per_sec"]), round(v["pcie_gb_per_sec"],1)) for k,v in d["ingest"].items()})
+d=json.loads(open("$O/bench_b$b.json").read().strip().splitlines()[-1])
+print("batch $b", round(d["value"]), round(d["ms_per_step"],3), round(d["roofline"]["frac"],3), d["kernel_ms_per_step"])
 PY
 done
-# logic check of the N = 2 path on the one GPU (gloo) and smoke()
-timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 > $O/bench_2ranks.json 2> $O/bench_2ranks.err; tail -c 400 $O/bench_2ranks.json
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt
+for c in "ViT-B/32 512 fp16" "ViT-L/14 256 fp16" "ViT-B/16 512 bf16"; do set -- $c
+timeout 300 python bench.py $B --ckpt $1 --batch $2 --precision $3 --weight-operands single > $O/bench_$(echo $1 | tr / _)_$3.json 2> $O/bench_other.err
+python - <<PY
+import json
+d=json.loads(open("$O/bench_$(echo $1 | tr / _)_$3.json").read().strip().splitlines()[-1])
+print("$1 batch $2 $3", round(d["value"]), round(d["ms_per_step"],3), round(d["roofline"]["frac"],3), d["kernel_ms_per_step"])
+PY
+done
