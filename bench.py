@@ -66,6 +66,60 @@ def pmc_traffic(family="gemm"):
         return None, None, None
 
 
+def live_pmc_traffic(args):
+    """L2<->fabric bytes per GEMM launch measured IN THIS RUN: two short child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, /opt/skills/guides/MI355X_MICROARCH.md
+    HBM section; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 half-count correction of FETCH_SIZE), summarised by
+    tools/traffic_json.py.  Returns (family bytes per launch, per-shape dict, note) — (None, None, why) when rocprofv3 is not
+    there or a pass fails (the committed profiles/*_traffic.json is then used and labelled as such)."""
+    import importlib.util
+    import shutil
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, None, "rocprofv3 not found"
+    spec = importlib.util.spec_from_file_location("traffic_json", os.path.join(ROOT, "tools", "traffic_json.py"))
+    tj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tj)
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-drift", "--cpu-seconds", "0",
+             "--sustain-seconds", "0", "--no-profile", "--ingest", "none", "--no-arms", "--no-live-traffic", "--ckpt", args.ckpt,
+             "--batch", str(args.batch), "--prompts", str(args.prompts), "--precision", args.precision,
+             "--weights-regime", args.weights_regime, "--weight-operands", args.weight_operands]
+    env = dict(os.environ, TMPDIR="/tmp")
+    found = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, counter)
+            try:
+                r = subprocess.run([rp, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=240)
+            except Exception as e:
+                return None, None, f"rocprofv3 {counter} pass: {type(e).__name__}"
+            hits = [os.path.join(dp, f) for dp, _d, fs in os.walk(out) for f in fs
+                    if f.endswith("_results.db") or f.endswith("counter_collection.csv")]
+            if r.returncode or not hits:
+                return None, None, f"rocprofv3 {counter} pass failed (rc {r.returncode})"
+            try:
+                found[counter] = tj.mean_by_family(hits[0], counter)
+            except Exception as e:
+                return None, None, f"parsing the {counter} pass: {type(e).__name__}: {e}"
+    fetch, write = found["FETCH_SIZE"], found["WRITE_SIZE"]
+    if "gemm" not in fetch:
+        return None, None, "no GEMM dispatches in the counter pass"
+    per = {}
+    for f, (fb, n) in fetch.items():
+        if f == "gemm" or f.startswith("gemm_"):
+            wb = write.get(f, (0.0, 0))[0]
+            per[f] = {"l2_fabric_bytes": (2 * fb + wb) * 1024, "launches_sampled": n}
+            if f in tj.ALGO and args.batch == 512 and args.ckpt == "ViT-B/16":
+                per[f]["algorithmic_bytes"] = tj.ALGO[f]
+                per[f]["ratio"] = per[f]["l2_fabric_bytes"] / tj.ALGO[f]
+    fam = per.pop("gemm")["l2_fabric_bytes"]
+    per.pop("gemm_fp32_text_tower", None)
+    return fam, per, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 3 steps each"
+
+
 class SmiSampler(threading.Thread):
     """sclk (MHz) and package power (W) of device 0 every `period` s through rocm-smi."""
 
@@ -368,6 +422,12 @@ def main():
                     help="comma list of ingest legs reported next to the device-resident number (N = 1): host-u8 (pinned "
                          "224x224 uint8 crops -> copy stream -> mcm_score_u8), host-raw (variable-size decoded images -> one "
                          "packed copy -> resize/crop on the device -> mcm_score_u8); 'none' skips them")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured hipGraph (mcm_amd.engine.GraphedScorer) instead of launching its "
+                         "~110 kernels: what a small-batch caller would do (launch-bound below batch ~64); per-kernel events off")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~40 s); the committed "
+                         "profiles/*_traffic.json is reported instead")
     ap.add_argument("--no-arms", action="store_true", help="skip the 3-step runs of the other precision arms (N = 1)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group even for one rank, so that the score all-gather really runs "
@@ -455,10 +515,26 @@ def main():
         if coll:
             torch.distributed.barrier()
 
+    graphs = None
+    if args.graph:  # one graph per input buffer (a graph replays the pointers it captured): no copy in the timed loop
+        from mcm_amd.engine import GraphedScorer
+
+        args.no_profile = True
+        graphs = []
+        graphs = [GraphedScorer(net, B, txt, 1.0, "MCM", input=b) for b in bufs]
+
+    def step(i, out):
+        if graphs is None:
+            net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=out)
+        else:
+            g = graphs[i % nbuf]
+            g.graph.replay()
+            out.copy_(g.output, non_blocking=True)
+
     for i in range(args.warmup):
         if not args.no_profile and i == args.warmup - 1:
             net.profile(True)  # creates the event pool outside the timed region
-        net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[0])
+        step(i, scores[0])
     if coll:  # warm the collective too (RCCL builds its rings on first use)
         mdist.all_gather_scores(scores[0], ws * B)
     torch.cuda.synchronize()
@@ -473,7 +549,7 @@ def main():
     for i in range(args.steps):
         if n_prof:
             net.profile(i % pe == 0)  # a host-side flag: events are recorded on profiled steps only
-        net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[i])
+        step(i, scores[i])
         if args.idle_ms >= 0:  # measurement hook: an idle device between steps (kernel times come from the HIP events)
             torch.cuda.synchronize()
             time.sleep(args.idle_ms * 1e-3)
@@ -505,7 +581,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(n_sus):
-            net.score_images(bufs[i % nbuf], txt, 1.0, "MCM", out=scores[i % args.steps])
+            step(i, scores[i % args.steps])
         torch.cuda.synchronize()
         barrier()
         dts = time.perf_counter() - t1
@@ -552,6 +628,8 @@ def main():
             line["harness_group_n"] = args.group_n
         if args.patch_fold >= 0:
             line["harness_patch_fold"] = args.patch_fold
+        if args.graph:
+            line["hip_graph"] = "every step is one replay of a captured hipGraph (mcm_amd.engine.GraphedScorer)"
         if args.idle_ms >= 0:
             line["idle_ms_between_steps"] = args.idle_ms
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"
@@ -621,6 +699,14 @@ def main():
             native = first_scores.cpu().numpy() if args.steps >= 1 else None
             line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
     net.close()
+    if rank == 0 and ws == 1 and line.get("roofline") and not args.no_live_traffic and not args.no_profile:
+        # roofline.traffic witnessed by this very run (the handle is closed: the children have the device to themselves)
+        torch.cuda.empty_cache()
+        fam, per, note = live_pmc_traffic(args)
+        if fam is not None:
+            line["roofline"].update(traffic=fam, traffic_source=note, traffic_per_shape=per)
+        else:
+            line["roofline"]["traffic_source"] = f"{line['roofline'].get('traffic_source')} (committed record; live PMC pass unavailable: {note})"
     px0 = bufs[0]
     del bufs, scores
     if rank == 0 and ws == 1 and not args.no_arms:

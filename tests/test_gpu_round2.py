@@ -280,3 +280,37 @@ def test_hot_loop_call_is_hip_graph_capturable():
         assert torch.equal(out, net.score_images(px, txt, 1.0, "MCM"))
     finally:
         net.close()
+
+
+@pytest.mark.parametrize("uint8", [False, True])
+def test_graphed_scorer_replays_the_eager_bits(uint8):
+    """mcm_amd.engine.GraphedScorer: the step as one hipGraph replay (small batches are launch-bound) — same bits as the
+    eager call, on its own static input and on a caller-provided one, fp32 NCHW and uint8 NHWC pixels."""
+    from mcm_amd.engine import GraphedScorer
+
+    net = _net("B16-2L", "fp16", "fp16-exact", max_batch=8, max_prompt_tokens=1024)
+    try:
+        ids, _ = make_token_ids(11, seed=4)
+        txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+        g_ = torch.Generator(device="cuda").manual_seed(21)
+
+        def pixels():
+            if uint8:
+                return torch.randint(0, 256, (8, 224, 224, 3), dtype=torch.uint8, generator=g_, device="cuda")
+            return torch.randn((8, 3, 224, 224), generator=g_, device="cuda")
+
+        scorer = GraphedScorer(net, 8, txt, uint8=uint8)
+        for _ in range(3):
+            px = pixels()
+            got = scorer(px).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(got, net.score_images(px, txt, 1.0, "MCM"))
+        own = pixels()
+        s2 = GraphedScorer(net, 8, txt, input=own)
+        assert torch.equal(s2().clone(), net.score_images(own, txt, 1.0, "MCM"))
+        own.copy_(pixels())
+        assert torch.equal(s2().clone(), net.score_images(own, txt, 1.0, "MCM"))
+        with pytest.raises(ValueError):
+            scorer(pixels()[:4])
+    finally:
+        net.close()
