@@ -44,7 +44,8 @@ ALGO = {"gemm_qkv": 100864 * 768 * 2 + 2304 * 768 * 2 + 100864 * 2304 * 2,
         "gemm_fc1": 100864 * 768 * 2 + 3072 * 768 * 2 + 100864 * 3072 * 2,
         "gemm_resid_outproj_fc2": ((100864 * 768 * 2 + 768 * 768 * 2 + 2 * 100864 * 768 * 4)
                                    + (100864 * 3072 * 2 + 768 * 3072 * 2 + 2 * 100864 * 768 * 4)) // 2,
-        "gemm_patch": 100352 * 768 * 2 + 768 * 768 * 2 + 100352 * 768 * 4}
+        # patch embedding, pixel-gathering form (round 4): fp32 NCHW pixels read once + W + the fp32 residual rows written
+        "gemm_patch": 512 * 3 * 224 * 224 * 4 + 768 * 768 * 2 + 100352 * 768 * 4}
 
 
 def gemm_shape(name):
