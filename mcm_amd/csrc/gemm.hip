@@ -1421,8 +1421,11 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
       const long rest_wgs = (rt - rt1) * 2 * (a.N / 128);
       // (a last round up to a quarter full; up to half full measured equal or slower at batches 64 ... 512:
       // profiles/r03_x_kernel_choice_small_batches.txt)
+      // ... and only when the left-over rows are a problem the size policy hands to the tile kernel (with a wide N the floor
+      // in rt1 can leave up to 8 nbn - 1 tiles, more than half a round: those would go back to a persistent kernel as a
+      // second ragged round — ADVICE r3)
       if (R >= 1 && left > 0 && left * 4 <= G && rt1 >= 1 && rt1 < rt && rest_wgs * 2 >= G &&
-          size_policy((int)(rt1 * p256::BM), a.N) == 5) {
+          size_policy((int)(rt1 * p256::BM), a.N) == 5 && size_policy((int)((rt - rt1) * p256::BM), a.N) == 0) {
         GemmArgs m = a, r = a;
         const size_t row0 = (size_t)rt1 * p256::BM;
         m.M = (int)row0;

@@ -1,7 +1,5 @@
 #!/bin/bash
-# scratch driver (round 4, call 14): the default bench line (live PMC traffic, arms, ingest, parity) and the rocprofv3 passes of the shipped tree
-mkdir -p gpurun_out/r4c14
-O=$PWD/gpurun_out/r4c14
-SECONDS=0
-timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench: $SECONDS s"; tail -c 600 $O/bench_default.json; tail -3 $O/bench_default.err
-bash tools/profile.sh r04_j > $O/profile.log 2>&1; tail -5 $O/profile.log
+# scratch driver (round 4, call 15): whole GPU suite on the final tree of this stage
+mkdir -p gpurun_out/r4c15
+O=$PWD/gpurun_out/r4c15
+timeout 2400 python -m pytest tests -m gpu -q --durations=8 > $O/pytest.txt 2>&1; tail -14 $O/pytest.txt | cut -c1-200
