@@ -331,18 +331,17 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
 #ifdef MCM_HARNESS
 /* libmcm_hip_harness.so only (built with -DMCM_HARNESS next to the shipped library; loaded by the A/B tests
  * and tools, never by the product path).  Process-wide switches.
- * GEMM variant: -1 the shipped size policy, 0 = 128x128 tile kernel, 1/2 = persistent 256x128 3-stage
- * (2: counted epilogue stores), 3/4 = persistent 256x256 2-stage (4: counted epilogue stores),
- * 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3),
- * 6 = the ping-pong loop on 32x32x16 MFMAs (16-bit modes; others run as 5),
- * 7 = ping-pong with balanced DMA (8 + 8 pieces per step), 8 = ping-pong with staggered epilogues (both: whole tiles,
- *     others run as 5),
- * 11 = the shipped size policy with a 64x128 tile kernel wherever the 128x128 one would get fewer workgroups than
- *     two per CU (small batches).
+ * GEMM variant: -1 the shipped size policy (64x128 / 128x128 tile kernels, persistent 256x256, ping-pong),
+ * 0 = the 128x128 tile kernel always, 11 = the 64x128 tile kernel always, 3/4 = persistent 256x256 2-stage (4: counted
+ * epilogue stores), 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3);
+ * arms of gemm_arms.hpp: 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 6 = the ping-pong loop on 32x32x16
+ * MFMAs (16-bit modes), 7 = ping-pong with balanced DMA (8 + 8 pieces per step), 8 = ping-pong with staggered epilogues,
+ * 9 = the flagged ping-pong text with every flag off (honours mcm_debug_gemm_group_n) — 6 ... 9: whole tiles, others run as 5.
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
 /* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel, 2 ... 9 = priority / wave-count /
- * two-pass arms of the shipped kernel at the B/16 shape, 10 = XCD-aware deal of the (sequence, head) workgroups. */
+ * two-pass arms of the shipped kernel at the B/16 shape, 10 = XCD-aware deal of the (sequence, head) workgroups,
+ * 11 = the q-blocks dealt to the waves rotated per workgroup (SIMD balance; bit-identical, no gain). */
 int mcm_debug_attention_variant(int32_t variant);
 /* A/B and ablation bits of the GEMM kernels (gemm.hip, GemmArgs::dbg; 0 = shipped behaviour). */
 int mcm_debug_gemm_dbg(int32_t bits);
