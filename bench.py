@@ -478,6 +478,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    legs, t_leg = {}, time.perf_counter()  # wall clock per leg of this run -> line["leg_seconds"]
+
+    def leg_done(name):
+        nonlocal t_leg
+        now = time.perf_counter()
+        legs[name] = round(legs.get(name, 0.0) + now - t_leg, 2)
+        t_leg = now
+
     geo = geometry(args.ckpt)
     sd = synth_state_dict(geo, 0, args.weights_regime)
     K, B = args.prompts, args.batch
@@ -543,6 +551,7 @@ def main():
         net.profile(False)
     pe = max(1, args.profile_every)
     n_prof = 0 if args.no_profile else len(range(0, args.steps, pe))
+    leg_done("setup_and_warmup")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -570,6 +579,7 @@ def main():
     assert torch.isfinite(scores).all()
     nb_cpu = min(args.cpu_batch, B)
     first_scores = scores[0][:nb_cpu].clone()  # step 0 scored bufs[0]; the sustained leg overwrites scores[]
+    leg_done("timed_steps")
 
     sustained = None
     if args.sustain_seconds > 0:  # every rank runs it (the chip-level power state is what is being measured)
@@ -589,9 +599,11 @@ def main():
         if sampler:
             sustained.update(sampler.stop())
 
+    leg_done("sustained")
     ingest = None
     if ws == 1 and args.ingest != "none":
         ingest = ingest_legs(net, txt, B, max(6, min(args.steps, 12)), set(args.ingest.split(",")))
+        leg_done("ingest")
 
     line = None
     if rank == 0:
@@ -697,7 +709,9 @@ def main():
         if ws == 1 and args.cpu_seconds > 0:
             pxs = [b[:nb_cpu].cpu() for b in bufs]  # the batches the native run scored (bufs[0] first)
             native = first_scores.cpu().numpy() if args.steps >= 1 else None
+            leg_done("line")
             line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
+            leg_done("cpu_baseline")
     net.close()
     if rank == 0 and ws == 1 and line.get("roofline") and not args.no_live_traffic and not args.no_profile:
         # roofline.traffic witnessed by this very run (the handle is closed: the children have the device to themselves)
@@ -707,6 +721,7 @@ def main():
             line["roofline"].update(traffic=fam, traffic_source=note, traffic_per_shape=per)
         else:
             line["roofline"]["traffic_source"] = f"{line['roofline'].get('traffic_source')} (committed record; live PMC pass unavailable: {note})"
+        leg_done("live_pmc_traffic")
     px0 = bufs[0]
     del bufs, scores
     if rank == 0 and ws == 1 and not args.no_arms:
@@ -725,11 +740,14 @@ def main():
                                  ids, px0, local)
             arms[name]["weights_regime"] = regime
         line["arms"] = arms
+        leg_done("arms")
     del px0
     torch.cuda.empty_cache()
     if rank == 0:
         if ws == 1 and not args.no_drift and args.precision != "fp32":
             line["parity"] = parity_leg(args, K, B, local)
+            leg_done("parity")
+        line["leg_seconds"] = legs
         print(json.dumps(line), flush=True)
     if coll:
         torch.distributed.barrier()

@@ -357,6 +357,9 @@ int mcm_debug_gemm_group_n(int32_t gn);
 /* A/B: 1 (default, shipped) = the patch-embedding GEMM gathers its A operand from the fp32 NCHW pixels itself; 0 = the
  * rounds 1 - 3 route (patchify writes a patch matrix, the GEMM reads it back).  Bit-identical. */
 int mcm_debug_patch_fold(int32_t on);
+/* 0 (shipped): mcm_resize_crop_u8 stages the source window in LDS where it fits; 1: the per-pixel fused form of
+   rounds 2 - 3 for every workgroup (A/B). */
+int mcm_debug_resize_fused_only(int32_t on);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */

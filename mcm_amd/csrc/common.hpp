@@ -324,4 +324,8 @@ struct PrepImage {
   int32_t top, left;   // CenterCrop origin inside the resized image
 };
 int prep_max_taps();
-hipError_t launch_resize_crop(const PrepImage* meta_dev, int B, int S, uint8_t* dst, hipStream_t s);
+// coef_dev: prep_coef_bytes(max_batch, S) of workspace for the per-image coefficient tables of the LDS form (nullptr: the
+// fused form everywhere); fused_only (A/B, harness builds): every workgroup takes the rounds-2/3 form
+size_t prep_coef_bytes(int max_batch, int S);
+hipError_t launch_resize_crop(const PrepImage* meta_dev, int32_t* coef_dev, int B, int S, uint8_t* dst, hipStream_t s,
+                              bool fused_only = false);

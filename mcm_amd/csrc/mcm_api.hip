@@ -71,6 +71,7 @@ struct mcm_handle {
   // has to drain the stream before it may write the next batch's geometry; prep_ev[k] = "the copy out of slot k is done"
   static constexpr int PREP_RING = 4;
   PrepImage *prep_pin = nullptr, *prep_dev = nullptr;
+  int32_t* prep_coef = nullptr;  // PREP_RING x prep_coef_bytes: the resize kernel's coefficient tables (allocated by the first call)
   hipEvent_t prep_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
   unsigned prep_next = 0;
   int64_t max_rows = 0;
@@ -181,6 +182,11 @@ bool next_dir(mcm_handle* h) {
 int g_patch_fold = 1;  // A/B (mcm_debug_patch_fold): 0 = patchify + plain patch GEMM (rounds 1 - 3), 1 = pixel-gathering patch GEMM
 #else
 constexpr int g_patch_fold = 1;
+#endif
+#ifdef MCM_HARNESS
+int g_resize_fused_only = 0;  // A/B (mcm_debug_resize_fused_only): 1 = the resize kernel's rounds-2/3 form everywhere
+#else
+constexpr int g_resize_fused_only = 0;
 #endif
 #ifdef MCM_HARNESS
 int g_nsplit = 1;  // A/B (mcm_debug_nsplit): the wide store GEMMs (QKV, fc1) as n launches over column blocks of N / n
@@ -923,7 +929,12 @@ int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const 
   }
   HIP_TRY(h, hipMemcpyAsync(dev, pin, (size_t)B * sizeof(PrepImage), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipEventRecord(h->prep_ev[slot], s));
-  HIP_TRY(h, launch_resize_crop(dev, B, S, dst_dev, s));
+  if (!h->prep_coef) {  // first call on this handle (one synchronous allocation; text-only / pre-cropped users never pay it)
+    rc = dev_alloc(h, (void**)&h->prep_coef, (size_t)mcm_handle::PREP_RING * prep_coef_bytes(h->cfg.max_batch, S));
+    if (rc) return rc;
+  }
+  int32_t* coef = (int32_t*)((char*)h->prep_coef + (size_t)slot * prep_coef_bytes(h->cfg.max_batch, S));
+  HIP_TRY(h, launch_resize_crop(dev, coef, B, S, dst_dev, s, g_resize_fused_only != 0));
   return MCM_OK;
 }
 
@@ -1179,6 +1190,10 @@ int mcm_debug_qkv_head_major(int32_t on) {
 }
 int mcm_debug_patch_fold(int32_t on) {  // 1 (shipped): the patch GEMM gathers pixels itself; 0: patchify + plain GEMM
   g_patch_fold = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_resize_fused_only(int32_t on) {  // 0 (shipped): LDS form where the window fits; 1: the fused form everywhere
+  g_resize_fused_only = on ? 1 : 0;
   return MCM_OK;
 }
 int mcm_debug_gemm_group_n(int32_t gn) {  // 0 (default): the plain n-fastest walk; g > 0: N tiles walked in groups of g (arms kernel, variant 9)

@@ -58,6 +58,31 @@ def test_random_sizes_match_oracle(net):
         np.testing.assert_array_equal(got, orc.resize_crop_u8(img, 224), err_msg=f"{h}x{w}")
 
 
+def test_packed_images_at_unaligned_offsets_match_oracle(net):
+    """The LDS form reads the source window in 16-byte chunks aligned to the ADDRESS: images packed back to back at
+    byte offsets of every residue mod 16, the first one at the start of the allocation + 1 and the last one ending at
+    its last byte, must come out bit-equal (chunks that stick out of an image are read byte by byte)."""
+    import torch
+
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(23)
+    sizes = [(int(rng.integers(225, 520)), int(rng.integers(225, 520))) for _ in range(17)] + [(224, 224), (40, 31)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    offsets, cur = [], 1
+    for i, im in enumerate(imgs):
+        offsets.append(cur)
+        cur += im.size + (i % 5)           # gaps of 0..4 bytes: every alignment shows up
+    host = np.zeros(cur - ((len(imgs) - 1) % 5), dtype=np.uint8)    # the last image ends the buffer
+    for o, im in zip(offsets, imgs):
+        host[o:o + im.size] = im.reshape(-1)
+    assert offsets[-1] + imgs[-1].size == host.size and len({o % 16 for o in offsets}) > 8
+    out = net.resize_crop_packed(torch.from_numpy(host).cuda(), offsets, [h for h, _ in sizes],
+                                 [w for _, w in sizes]).cpu().numpy()
+    for (h, w), img, got in zip(sizes, imgs, out):
+        np.testing.assert_array_equal(got, orc.resize_crop_u8(img, 224), err_msg=f"{h}x{w}")
+
+
 def test_feeds_the_scoring_path(net):
     """resize/crop on the device → uint8 scoring route == the same route fed with the oracle's crops."""
     import torch

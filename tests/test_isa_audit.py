@@ -137,3 +137,34 @@ def test_pixel_gathering_patch_gemm_does_not_spill(gemm_isa, prec):
     assert "scratch_" not in body
     assert "global_load_lds_dwordx4" in body and len(re.findall(r"global_load_dwordx4 v", body)) >= 4
     assert len(re.findall(r"v_mfma_f32_16x16x(32|4)", body)) in (64, 256)
+
+
+@pytest.fixture(scope="module")
+def preprocess_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_p")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "mcm_amd", "csrc"),
+           "-c", os.path.join(ROOT, "mcm_amd", "csrc", "preprocess.hip"), "-o", str(out / "preprocess.o"), "-save-temps=obj"]
+    subprocess.run(cmd, check=True, cwd=str(out), capture_output=True, timeout=600)
+    asm = [f for f in os.listdir(out) if f.endswith("gfx950.s")]
+    assert asm, os.listdir(out)
+    return open(out / asm[0]).read()
+
+
+def test_resize_kernel_keeps_lds_address_space_and_avoids_the_packed_shift(preprocess_isa):
+    """Two properties of mcm_resize_crop_u8's LDS form that only the generated code shows (both cost a wrong image on the
+    MI355X before the bit-exact tests caught them, preprocess.hip):
+    * its LDS traffic is ds_* — no flat store (an LDS pointer re-aligned through an integer cast turns the accesses into
+      flat ones, and hipcc then merges the horizontal pass's byte stores into 16-bit flat stores at odd addresses);
+    * no v_ashr_pk_u8_i32: hipcc fuses two neighbouring (>> 22, clamp to 0..255) into it and ORs the result into a packed
+      word as if the destination's upper half were zero, which it is not on this device."""
+    m = re.search(r"^(_ZN\S*18resize_crop_kernel\S*):\s.*?^\.Lfunc_end", preprocess_isa, re.S | re.M)
+    assert m, "resize_crop_kernel not found"
+    body = m.group(0)
+    assert "v_ashr_pk" not in preprocess_isa
+    assert "flat_store" not in body and "scratch_" not in body
+    assert body.count("ds_write_b8") >= 3 and "v_alignbyte_b32" in body and "v_mul_u32_u24" in body
+    # nothing in the LDS form multiplies on the quarter-rate 32-bit multiplier: the only v_mul_lo_u32 left are the fused
+    # form's taps and index arithmetic
+    assert body.count("v_mul_u32_u24") + body.count("v_mad_u32_u24") > 100
