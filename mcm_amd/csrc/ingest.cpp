@@ -10,12 +10,39 @@
 // images, so every thread moves the same amount — runs at the host's memory bandwidth.
 #include <stdint.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <thread>
 #include <vector>
 
 #include "../../include/mcm.h"
+
+namespace {
+// memcpy whose stores bypass the cache: the pinned buffer is written once and next read by the DMA engine, so pulling its
+// lines into the cache first (read-for-ownership) is a third of the memory traffic for nothing
+void copy_streaming(uint8_t* d, const uint8_t* s, size_t n) {
+#if defined(__SSE2__)
+  if (n >= 4096) {
+    const size_t head = (16 - ((uintptr_t)d & 15)) & 15;
+    memcpy(d, s, head);
+    d += head, s += head, n -= head;
+    for (; n >= 64; d += 64, s += 64, n -= 64) {
+      const __m128i a = _mm_loadu_si128((const __m128i*)s), b = _mm_loadu_si128((const __m128i*)(s + 16));
+      const __m128i c = _mm_loadu_si128((const __m128i*)(s + 32)), e = _mm_loadu_si128((const __m128i*)(s + 48));
+      _mm_stream_si128((__m128i*)d, a);
+      _mm_stream_si128((__m128i*)(d + 16), b);
+      _mm_stream_si128((__m128i*)(d + 32), c);
+      _mm_stream_si128((__m128i*)(d + 48), e);
+    }
+    _mm_sfence();
+  }
+#endif
+  memcpy(d, s, n);
+}
+}  // namespace
 
 extern "C" int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, const int64_t* offsets, int32_t n,
                            uint8_t* dst, int64_t dst_bytes, int32_t threads) {
@@ -32,7 +59,7 @@ extern "C" int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, con
     int64_t lo = total * t / nt, hi = total * (t + 1) / nt, pos = 0;
     for (int32_t i = 0; i < n && pos < hi; ++i) {
       const int64_t a = std::max(lo, pos), b = std::min(hi, pos + sizes[i]);
-      if (a < b) memcpy(dst + offsets[i] + (a - pos), srcs[i] + (a - pos), (size_t)(b - a));
+      if (a < b) copy_streaming(dst + offsets[i] + (a - pos), srcs[i] + (a - pos), (size_t)(b - a));
       pos += sizes[i];
     }
   };

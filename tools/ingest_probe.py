@@ -87,8 +87,40 @@ dt = time.perf_counter() - t0
 out(stage="h2d_copy_beside_scoring", copy_ms=round(e0.elapsed_time(e1) / 6, 2), GBps=round(nb * 6 / e0.elapsed_time(e1) / 1e6, 1),
     score_ms_meanwhile=round(dt * 1e3 / n, 2))
 del pipe
-for depth in (2, 3, 4):
-    for th in (8, 16, 32):
+
+
+class Ablated(PackedImagePipe):
+    """the pipeline with the host pack and / or the H2D copy left out (stale bytes: timing only)"""
+
+    def __init__(self, *a, pack=True, copy=True, **kw):
+        super().__init__(*a, **kw)
+        self.do_pack, self.do_copy, self._memo = pack, copy, {}
+
+    def _fill(self, s, images):
+        if self.do_pack or id(s) not in self._memo:
+            self._memo[id(s)] = super()._fill(s, images)
+        return self._memo[id(s)]
+
+    def push(self, s, nbytes):
+        if self.do_copy or not s.used:
+            super().push(s, nbytes)
+
+
+for pack, copy in ((True, True), (False, True), (True, False), (False, False)):
+    pipe = Ablated(net, B, nbytes + (1 << 20), depth=3, pack_threads=8, pack=pack, copy=copy)
+    for px in pipe.stream([batch] * 4):
+        net.score_images(px, txt, 1.0, "MCM", out=sc)
+    torch.cuda.synchronize()
+    steps = 16
+    t0 = time.perf_counter()
+    for px in pipe.stream(batch for _ in range(steps)):
+        net.score_images(px, txt, 1.0, "MCM", out=sc)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out(stage="pipeline_ablation", pack=pack, copy=copy, ms_per_batch=round(dt * 1e3 / steps, 2), images_per_s=round(steps * B / dt))
+    del pipe
+for depth in (3,):
+    for th in (8,):
         pipe = PackedImagePipe(net, B, nbytes + (1 << 20), depth=depth, pack_threads=th)
         for px in pipe.stream([batch, batch]):
             net.score_images(px, txt, 1.0, "MCM", out=sc)
