@@ -162,7 +162,14 @@ def cpu_baseline(geo, sd, ids, mask, K, px_batches, max_seconds, native_first):
     import numpy as np
     import torch
 
-    info = {"cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "unit": "images/sec"}
+    from mcm_amd.hostinfo import cpu_quota, effective_cpus
+
+    # torch defaults to one thread per visible core; a container is scheduled on its cgroup quota (the GPU boxes here: 256
+    # CPUs visible, 16 cores of quota), and threads beyond it only take turns.  `cores` = the threads used = that allocation.
+    threads_default = torch.get_num_threads()
+    torch.set_num_threads(min(threads_default, effective_cpus()))
+    info = {"cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "cpu_quota_cores": cpu_quota(),
+            "torch_default_threads": threads_default, "unit": "images/sec"}
     bs = px_batches[0].shape[0]
     try:
         from oracle.hf_reference import HFReference
@@ -217,6 +224,7 @@ def cpu_baseline(geo, sd, ids, mask, K, px_batches, max_seconds, native_first):
                        f"does, value_hoisted: bank encoded once) after a warm-up (bank + 8 images) of {warm:.1f} s; same seeded "
                        f"weights and pixels as the native run" + ("" if n >= target else
                                                                   f"; stopped at the {max_seconds:.0f} s cap"))
+    torch.set_num_threads(threads_default)
     if native_first is not None and first is not None:
         d = np.abs(first - native_first)
         info["parity_max_abs_dscore_vs_native"] = float(d.max())
@@ -357,6 +365,63 @@ def ingest_legs(net, txt, B, steps, which):
                            "source": "decoded RGB images of 8 sizes (256x341 ... 600x800) in pageable host memory, packed "
                                      "into one pinned buffer and copied once per batch, Resize + CenterCrop on the device"}
         del pipe
+    if "host-jpeg" in which:
+        # the CLI's own loader on an image folder of JPEG files: file read + Pillow decode in the loader's worker processes (host
+        # work, like the reference's DataLoader workers) -> packed copy -> Resize + CenterCrop + scoring on the device
+        try:
+            import shutil
+            import tempfile
+
+            from PIL import Image
+
+            from mcm_amd.folder import ImageFolderU8
+
+            rng = np.random.default_rng(13)
+            sizes = [(375, 500), (500, 375), (333, 500), (500, 333), (480, 640), (400, 400), (256, 341), (600, 800)]
+            root = tempfile.mkdtemp(prefix="mcm_jpeg_")
+            try:
+                import io
+
+                nfiles, fbytes = 4 * B, 0
+                yy, xx = np.mgrid[0:800, 0:800].astype(np.float32)
+                blobs = []
+                for i in range(2 * len(sizes)):  # photograph-like content: smooth structure + texture (noise alone does not compress)
+                    h, w = sizes[i % len(sizes)]
+                    f = rng.uniform(0.01, 0.06, 6)
+                    im = np.stack([127 + 70 * np.sin(f[2 * c] * xx[:h, :w] + i) * np.cos(f[2 * c + 1] * yy[:h, :w]) for c in range(3)], -1)
+                    im = np.clip(im + rng.normal(0, 12, im.shape), 0, 255).astype(np.uint8)
+                    buf = io.BytesIO()
+                    Image.fromarray(im).save(buf, format="JPEG", quality=90)
+                    blobs.append(buf.getvalue())
+                for i in range(nfiles):
+                    d = os.path.join(root, f"class{i % 8}")
+                    os.makedirs(d, exist_ok=True)
+                    with open(os.path.join(d, f"{i:05d}.jpg"), "wb") as fh:
+                        fh.write(blobs[i % len(blobs)])
+                    fbytes += len(blobs[i % len(blobs)])
+                workers = int(os.environ.get("MCM_DECODE_WORKERS", 0)) or None
+                loader = ImageFolderU8(root, net, B, workers=workers)
+                for px, _ in loader:  # warm-up pass: page cache, thread pool, slots
+                    net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
+                torch.cuda.synchronize()
+                passes, t0 = 2, time.perf_counter()
+                for _ in range(passes):
+                    for px, _ in loader:
+                        net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                loader.close()
+                out["host_jpeg"] = {"images_per_sec": passes * nfiles / dt, "ms_per_step": 1e3 * dt / (passes * nfiles / B),
+                                    "steps": passes * nfiles // B, "decode_workers": loader.workers, "host_cpus": os.cpu_count(),
+                                    "cpu_quota_cores": __import__("mcm_amd.hostinfo", fromlist=["cpu_quota"]).cpu_quota(),
+                                    "jpeg_bytes_per_image": fbytes / nfiles,
+                                    "source": f"{nfiles} JPEG files (quality 90, 8 sizes 256x341 ... 600x800) in an image folder, read + "
+                                              "decoded by Pillow in the loader's worker processes (shared-memory hand-over), then the host_raw path; "
+                                              "bound by the host cores this container is given (decode_workers = its CPU quota)"}
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+        except ImportError as e:
+            out["host_jpeg"] = {"skipped": f"Pillow unavailable ({e})"}
     return out
 
 
@@ -421,10 +486,11 @@ def main():
                     help="hard cap on the CPU baseline's timed part (it stops after 256 images); 0 disables it")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="0 disables the sustained-throughput leg")
-    ap.add_argument("--ingest", default="host-u8,host-raw",
+    ap.add_argument("--ingest", default="host-u8,host-raw,host-jpeg",
                     help="comma list of ingest legs reported next to the device-resident number (N = 1): host-u8 (pinned "
                          "224x224 uint8 crops -> copy stream -> mcm_score_u8), host-raw (variable-size decoded images -> one "
-                         "packed copy -> resize/crop on the device -> mcm_score_u8); 'none' skips them")
+                         "packed copy -> resize/crop on the device -> mcm_score_u8), host-jpeg (an image folder of JPEG files through the "
+                         "CLI's loader: Pillow decode on host threads, then the host-raw path); 'none' skips them")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (mcm_amd.engine.GraphedScorer) instead of launching its "
                          "~110 kernels: what a small-batch caller would do (launch-bound below batch ~64); per-kernel events off")

@@ -53,12 +53,7 @@ class FolderIndex:
         return sub
 
 
-def _decode_rgb(path):
-    import numpy as np
-    from PIL import Image
-
-    with Image.open(path) as im:  # torchvision's default loader: PIL, convert("RGB")
-        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+from .decode_pool import DecodePool, decode_rgb as _decode_rgb  # noqa: E402,F401
 
 
 class ImageFolderU8:
@@ -69,9 +64,18 @@ class ImageFolderU8:
         self.dataset = root_or_index if isinstance(root_or_index, FolderIndex) else FolderIndex(root_or_index)
         self.net, self.batch_size = net, int(batch_size)
         self.lo, self.hi = lo, (len(self.dataset) if hi is None else hi)
-        # decode pool (the reference's DataLoader runs 4 worker processes, utils/train_eval_util.py:49): Pillow
-        # releases the GIL while it decodes, so threads scale; batch i+1 is decoded while batch i is scored
-        self.workers = min(32, os.cpu_count() or 4) if workers is None else int(workers)
+        # decode workers (the reference's DataLoader runs 4 worker processes, utils/train_eval_util.py:49): PROCESSES writing
+        # into shared memory (mcm_amd/decode_pool.py) — Pillow decodes under the GIL, threads do not scale.  Default: the
+        # node's cores shared between the ranks on it, at most 64 per rank.  workers <= 1: decode in this thread.
+        if workers is None:
+            from .hostinfo import effective_cpus
+
+            # the CPUs this container may really use (cgroup quota, not os.cpu_count()) shared between the node's ranks; more
+            # workers than that run slower (measured on a 16-core quota: 16 workers 12.9k img/s, 64 workers 13.7k, 128 13.4k)
+            local_ws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            workers = max(1, min(64, effective_cpus() // local_ws))
+        self.workers = int(workers)
+        self._pool, self._pipe = None, None
 
     def __len__(self) -> int:
         return max(0, -(-(self.hi - self.lo) // self.batch_size))
@@ -79,15 +83,26 @@ class ImageFolderU8:
     def shard(self, lo: int, hi: int) -> "ImageFolderU8":
         return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi, self.workers)
 
+    def close(self):
+        """Stops the decode workers (also done when the loader is garbage-collected)."""
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+
     def gather(self, indices):
         """uint8 [b,S,S,3] device batch of the named samples (threshold refinement, mcm_amd/refine.py)."""
-        return self.net.resize_crop([__import__("torch").from_numpy(_decode_rgb(self.dataset.samples[int(i)][0])) for i in indices])
-
-    def decoded_batches(self) -> Iterator:
-        """Host side only: `(list of decoded uint8 [H,W,3] arrays, labels int64 [b])` per batch, in dataset order; with
-        `workers` > 1 batch i+1 is decoded by the pool while the consumer works on batch i."""
+        import numpy as np
         import torch
-        from concurrent.futures import ThreadPoolExecutor
+
+        # (np.array: a writable copy — the decoder's array is a read-only view of Pillow's bytes, which torch warns about)
+        return self.net.resize_crop([torch.from_numpy(np.array(_decode_rgb(self.dataset.samples[int(i)][0]))) for i in indices])
+
+    def decoded_batches(self, copy: bool = True) -> Iterator:
+        """Host side only: `(list of decoded uint8 [H,W,3] arrays, labels int64 [b])` per batch, in dataset order; with
+        `workers` > 1 the next two batches are being decoded by the worker processes while the consumer works on this one.
+        `copy=False` hands out views of the pool's shared memory, valid until the next batch is requested (what the
+        packed pipe wants: it copies them into pinned memory at once)."""
+        import torch
 
         starts = list(range(self.lo, self.hi, self.batch_size))
         chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
@@ -96,15 +111,19 @@ class ImageFolderU8:
             for s in starts:
                 yield [_decode_rgb(p) for p, _ in chunk_of(s)], labels_of(s)
             return
-        pool = ThreadPoolExecutor(self.workers)
-        try:
-            submit = lambda s: [pool.submit(_decode_rgb, p) for p, _ in chunk_of(s)]  # noqa: E731
-            pending = submit(starts[0]) if starts else None
-            for i, s in enumerate(starts):
-                futs, pending = pending, (submit(starts[i + 1]) if i + 1 < len(starts) else None)
-                yield [f.result() for f in futs], labels_of(s)
-        finally:
-            pool.shutdown(wait=False, cancel_futures=True)
+        if self._pool is None or self._pool.batch < self.batch_size:
+            self._pool = DecodePool(self.workers, self.batch_size)
+        pool, ahead = self._pool, self._pool.slots - 1
+        for i in range(min(ahead, len(starts))):
+            pool.submit(i % pool.slots, [p for p, _ in chunk_of(starts[i])])
+        for i, s in enumerate(starts):
+            imgs = pool.collect(i % pool.slots)
+            if copy:
+                imgs = [a.copy() for a in imgs]
+            yield imgs, labels_of(s)
+            # the consumer is done with batch i - that slot's views - once it asks for the next one
+            if i + ahead < len(starts):
+                pool.submit((i + ahead) % pool.slots, [p for p, _ in chunk_of(starts[i + ahead])])
 
     def __iter__(self) -> Iterator:
         """Decode pool → ONE packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on
@@ -114,11 +133,13 @@ class ImageFolderU8:
         labels = []
 
         def images():
-            for imgs, lab in self.decoded_batches():
+            for imgs, lab in self.decoded_batches(copy=False):
                 labels.append(lab)
                 yield imgs
 
-        pipe = PackedImagePipe(self.net, self.batch_size, self.batch_size * 512 * 512 * 3 // 2,   # (slots grow on demand)
-                               pack_threads=min(8, max(1, self.workers)))
+        if self._pipe is None:  # kept across passes: its pinned slots (grown to the largest batch seen) are expensive to make
+            self._pipe = PackedImagePipe(self.net, self.batch_size, self.batch_size * 512 * 512 * 3 // 2,   # (slots grow on demand)
+                                         pack_threads=min(8, max(1, self.workers)))
+        pipe = self._pipe
         for i, dev_batch in enumerate(pipe.stream(images())):
             yield dev_batch, labels[i]

@@ -52,8 +52,11 @@ def test_random_sizes_match_oracle(net):
     rng = np.random.default_rng(11)
     sizes = [(int(rng.integers(20, 900)), int(rng.integers(20, 900))) for _ in range(24)]
     sizes += [(224, 224), (224, 301), (299, 224), (1, 1), (2, 700), (448, 448)]
+    # every branch of the kernel's form choice (preprocess.hip): 8-tap tables with 8 / 4 / 2 rows per LDS pass, 16-tap tables
+    # with 1 row per pass, a window that fits no pass (fused form), more than 16 taps (fused form), upscaling
+    sizes += [(375, 500), (600, 800), (768, 1024), (1200, 1600), (1600, 1200), (2000, 1500), (1800, 4000), (120, 160), (230, 229)]
     imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
-    out = net.resize_crop([_dev(i) for i in imgs]).cpu().numpy()
+    out = np.concatenate([net.resize_crop([_dev(i) for i in imgs[k:k + 20]]).cpu().numpy() for k in range(0, len(imgs), 20)])
     for (h, w), img, got in zip(sizes, imgs, out):
         np.testing.assert_array_equal(got, orc.resize_crop_u8(img, 224), err_msg=f"{h}x{w}")
 

@@ -144,8 +144,8 @@ def test_folder_subset_is_the_reference_rule(tmp_path):
 
 
 def test_image_folder_decode_pool_keeps_order(tmp_path):
-    """The threaded decode (batch i+1 decoded while batch i is scored) yields the same batches, in order, as the
-    serial path."""
+    """The pooled decode (worker processes; the next batches decoded while batch i is scored) yields the same batches, in
+    order, as the serial path."""
     torch = pytest.importorskip("torch")
     from PIL import Image
 
@@ -168,6 +168,75 @@ def test_image_folder_decode_pool_keeps_order(tmp_path):
     assert len(serial) == len(pooled) == 4
     for (a, la), (b, lb) in zip(serial, pooled):
         assert la == lb and len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_decode_worker_processes_overflow_and_errors(tmp_path):
+    """DecodePool (mcm_amd/decode_pool.py): worker PROCESSES write the pixels into shared memory — same images as the serial
+    decode, in order; an image larger than a shared place is decoded by the parent; a file that does not decode raises
+    the decoder's own error in the parent, not a hang; `copy=False` hands out views of the shared slots."""
+    pytest.importorskip("torch")
+    from PIL import Image
+
+    from mcm_amd.folder import DecodePool, ImageFolderU8, _decode_rgb
+
+    rng = np.random.default_rng(1)
+    paths = []
+    for i in range(21):
+        p = tmp_path / "c" / f"{i:02d}.png"
+        p.parent.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(rng.integers(0, 256, (5 + i, 7 + (i % 3), 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    want = [_decode_rgb(p) for p in paths]
+    pool = DecodePool(3, batch=8, slots=3, stride=300)   # 300-byte places: images 11 .. 20 do not fit
+    try:
+        got = []
+        for b in range(3):
+            pool.submit(b, paths[b * 8:(b + 1) * 8])
+        for b in range(3):
+            imgs = pool.collect(b)
+            fits = [a.nbytes <= 300 for a in imgs]
+            shared = np.frombuffer(pool.buf, dtype=np.uint8)
+            assert all(np.shares_memory(a, shared) == f for a, f in zip(imgs, fits))  # views of the slot | parent-decoded
+            got += [a.copy() for a in imgs]
+        assert len(got) == 21 and all(np.array_equal(a, b) for a, b in zip(got, want))
+        bad = tmp_path / "c" / "zz_bad.png"
+        bad.write_bytes(b"not an image")
+        pool.submit(0, [paths[0], str(bad)])
+        with pytest.raises(Exception, match="cannot identify image file"):
+            pool.collect(0)
+    finally:
+        pool.close()
+    assert all(p.poll() is not None for p in pool.procs)   # the workers are gone
+    bad.unlink()
+    ld = ImageFolderU8(str(tmp_path), None, 4, workers=2)
+    views = [imgs for imgs, _ in ld.decoded_batches(copy=False)]
+    assert sum(len(v) for v in views) == 21 and np.array_equal(views[-1][-1], want[-1])   # the last batch is still intact
+    ld.close()
+
+
+def test_effective_cpus_follows_the_cgroup_quota(monkeypatch):
+    """hostinfo.effective_cpus: min(affinity, cgroup CPU quota) — what the decode pool and the CPU baseline size themselves by."""
+    import builtins
+    import io
+
+    from mcm_amd import hostinfo
+
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                return io.StringIO(content)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(hostinfo.os, "sched_getaffinity", lambda _pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert hostinfo.cpu_quota() == 16.0 and hostinfo.effective_cpus() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert hostinfo.cpu_quota() is None and hostinfo.effective_cpus() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert hostinfo.effective_cpus() == 1
 
 
 def test_hash_tokenizer_is_refused_by_a_net_with_real_weights():
