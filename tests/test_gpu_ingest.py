@@ -71,3 +71,45 @@ def test_packed_image_pipe_equals_per_image_resize_crop(net):
         assert pipe.bytes_copied >= sum(x.size for b in batches for x in b)
     with pytest.raises(ValueError):
         list(PackedImagePipe(net, 4, 1 << 20).stream([batch(5, 224, 230)]))
+
+
+def test_jpeg_folder_through_decode_processes_equals_serial_decode(net, tmp_path):
+    """The image-folder loader end to end in a process that holds a HIP context: JPEG / PNG files decoded by the worker
+    PROCESSES of mcm_amd/decode_pool.py (shared-memory hand-over) -> packed copy -> Resize + CenterCrop on the device ->
+    scores, against the same files decoded in this thread; two passes over the same loader (its pool and its pinned slots
+    are kept), ragged last batch, one image larger than a shared place (decoded by the parent)."""
+    from PIL import Image
+
+    from mcm_amd.folder import ImageFolderU8
+
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:700, 0:700].astype(np.float32)
+    n = 0
+    for c in ("a", "b", "c"):
+        (tmp_path / c).mkdir()
+        for i in range(37):
+            h, w = int(rng.integers(226, 520)), int(rng.integers(226, 520))
+            im = np.stack([127 + 90 * np.sin(0.03 * (k + 1) * xx[:h, :w] + i) * np.cos(0.02 * yy[:h, :w] + n) for k in range(3)], -1)
+            im = np.clip(im + rng.normal(0, 10, im.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(im).save(tmp_path / c / f"{i:03d}.{'png' if i % 9 == 0 else 'jpg'}", quality=92)
+            n += 1
+    Image.fromarray(rng.integers(0, 256, (1100, 1300, 3), dtype=np.uint8)).save(tmp_path / "c" / "zz_big.png")  # 4.3 MB > a 3-MB place
+    n += 1
+    bank = _bank(net)
+
+    def scores(loader, passes=1):
+        out = []
+        for _ in range(passes):
+            out.append(torch.cat([net.score_images(px, bank).clone() for px, _ in loader]))
+        return out
+
+    serial = scores(ImageFolderU8(str(tmp_path), net, 48, workers=1))[0]
+    pooled_loader = ImageFolderU8(str(tmp_path), net, 48, workers=5)
+    first, second = scores(pooled_loader, passes=2)
+    pooled_loader.close()
+    assert serial.numel() == n == 112
+    assert torch.equal(first, serial) and torch.equal(second, serial)
+    lo, hi = 50, 101   # a rank's shard of the same folder
+    shard = ImageFolderU8(str(tmp_path), net, 48, workers=3).shard(lo, hi)
+    assert torch.equal(scores(shard)[0], serial[lo:hi])
+    shard.close()
