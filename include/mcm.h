@@ -360,6 +360,9 @@ int mcm_debug_patch_fold(int32_t on);
 /* 0 (shipped): mcm_resize_crop_u8 stages the source window in LDS where it fits; 1: the per-pixel fused form of
    rounds 2 - 3 for every workgroup (A/B). */
 int mcm_debug_resize_fused_only(int32_t on);
+/* 0 (shipped): the persistent GEMM kernels launch one workgroup per CU; n (a multiple of 8): n workgroups, so that two
+   handles on two streams can share the chip (tools/dual_stream_probe.py). */
+int mcm_debug_persistent_grid(int32_t n);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the
  * shipped behaviour) = every LayerNorm as its own launch.  Measured 1 % slower end to end, DESIGN.md 5.5. */

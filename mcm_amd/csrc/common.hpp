@@ -239,6 +239,9 @@ int gemm_fold_kind(int epi, int M, int N);
 bool gemm_patch_takes_pixels(int prec, int M, int N, int kpad, int patch, int image);
 bool gemm_ln_tail_ok(int prec, int M, int N);
 int gemm_persistent_grid();
+#ifdef MCM_HARNESS
+void gemm_set_persistent_grid(int n);  // A/B: n workgroups (a multiple of 8) instead of one per CU; 0 restores
+#endif
 // LayerNorm fold, weight side: c[n] = sum_k gamma[k] W[n,k], bfold[n] = bias[n] + sum_k beta[k] W[n,k]  (W: operand dtype)
 hipError_t launch_fold_prep(int prec, const void* w, const float* gamma, const float* beta, const float* bias,
                             float* c, float* bfold, int N, int K, hipStream_t s);

@@ -1199,7 +1199,13 @@ constexpr int variant() { return -1; }  // the shipped library has the size poli
 // Persistent kernels run one workgroup per CU.  The count comes from the device (a partitioned or
 // CU-masked lease reports fewer than 256) and is rounded down to a multiple of 8: the tile schedule
 // deals M tiles to XCDs by blockIdx % 8.
+#ifdef MCM_HARNESS
+int g_grid_override = 0;  // A/B (mcm_debug_persistent_grid): workgroups of the persistent kernels, 0 = one per CU
+#endif
 int persistent_grid() {
+#ifdef MCM_HARNESS
+  if (g_grid_override > 0) return g_grid_override;
+#endif
   static int n = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1339,6 +1345,9 @@ constexpr int g_group_n = 0, g_dbg = 0;
 
 // LayerNorm in the tail: whether launch_gemm takes a residual GEMM of this size with GemmArgs::ln_y set (the ping-pong
 // kernel, whole tiles, rows of at most 1024 columns); the host then does not launch the LayerNorm that follows
+#ifdef MCM_HARNESS
+void gemm_set_persistent_grid(int n) { g_grid_override = n; }
+#endif
 int gemm_persistent_grid() { return persistent_grid(); }  // workgroups of the persistent kernels (one per CU, multiple of 8)
 bool gemm_ln_tail_ok(int prec, int M, int N) {
 #if !defined(MCM_HARNESS) && !defined(MCM_LN_TAIL)

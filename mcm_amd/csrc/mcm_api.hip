@@ -1192,6 +1192,11 @@ int mcm_debug_patch_fold(int32_t on) {  // 1 (shipped): the patch GEMM gathers p
   g_patch_fold = on ? 1 : 0;
   return MCM_OK;
 }
+int mcm_debug_persistent_grid(int32_t n) {  // 0 (shipped): one workgroup per CU; n: the persistent GEMMs take n CUs (a multiple of 8)
+  if (n < 0 || n % 8 != 0) return MCM_EINVAL;
+  gemm_set_persistent_grid(n);
+  return MCM_OK;
+}
 int mcm_debug_resize_fused_only(int32_t on) {  // 0 (shipped): LDS form where the window fits; 1: the fused form everywhere
   g_resize_fused_only = on ? 1 : 0;
   return MCM_OK;

@@ -1,3 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/r4c34
-timeout 900 python -m pytest tests/test_gpu_ingest.py -x -q -m gpu 2>&1 | tail -15 | tee gpurun_out/r4c34/pytest.txt
+mkdir -p gpurun_out/r4c35
+timeout 900 python tools/dual_stream_probe.py 2> gpurun_out/r4c35/dual.err | tee gpurun_out/r4c35/dual_stream_probe.jsonl; tail -5 gpurun_out/r4c35/dual.err
