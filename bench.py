@@ -671,7 +671,13 @@ def main():
     leg_done("sustained")
     ingest = None
     if ws == 1 and args.ingest != "none":
-        ingest = ingest_legs(net, txt, B, max(6, min(args.steps, 12)), set(args.ingest.split(",")))
+        ingest = {}
+        for leg in args.ingest.split(","):  # a side leg that fails says so in the line; it never costs the headline number
+            try:
+                ingest.update(ingest_legs(net, txt, B, max(6, min(args.steps, 12)), {leg}))
+            except Exception as e:
+                ingest[leg.replace("-", "_")] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                torch.cuda.synchronize()
         leg_done("ingest")
 
     line = None
@@ -779,13 +785,19 @@ def main():
             pxs = [b[:nb_cpu].cpu() for b in bufs]  # the batches the native run scored (bufs[0] first)
             native = first_scores.cpu().numpy() if args.steps >= 1 else None
             leg_done("line")
-            line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
+            try:
+                line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             leg_done("cpu_baseline")
     net.close()
     if rank == 0 and ws == 1 and line.get("roofline") and not args.no_live_traffic and not args.no_profile:
         # roofline.traffic witnessed by this very run (the handle is closed: the children have the device to themselves)
         torch.cuda.empty_cache()
-        fam, per, note = live_pmc_traffic(args)
+        try:
+            fam, per, note = live_pmc_traffic(args)
+        except Exception as e:
+            fam, per, note = None, None, f"{type(e).__name__}: {e}"[:200]
         if fam is not None:
             line["roofline"].update(traffic=fam, traffic_source=note, traffic_per_shape=per)
         else:
@@ -805,8 +817,11 @@ def main():
             if prec == args.precision and wo == args.weight_operands and regime == args.weights_regime:
                 continue
             torch.cuda.empty_cache()
-            arms[name] = arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
-                                 ids, px0, local)
+            try:
+                arms[name] = arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
+                                     ids, px0, local)
+            except Exception as e:
+                arms[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             arms[name]["weights_regime"] = regime
         line["arms"] = arms
         leg_done("arms")
@@ -814,7 +829,10 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0:
         if ws == 1 and not args.no_drift and args.precision != "fp32":
-            line["parity"] = parity_leg(args, K, B, local)
+            try:
+                line["parity"] = parity_leg(args, K, B, local)
+            except Exception as e:
+                line["parity"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             leg_done("parity")
         line["leg_seconds"] = legs
         print(json.dumps(line), flush=True)
