@@ -399,8 +399,7 @@ def ingest_legs(net, txt, B, steps, which):
                     with open(os.path.join(d, f"{i:05d}.jpg"), "wb") as fh:
                         fh.write(blobs[i % len(blobs)])
                     fbytes += len(blobs[i % len(blobs)])
-                workers = int(os.environ.get("MCM_DECODE_WORKERS", 0)) or None
-                loader = ImageFolderU8(root, net, B, workers=workers)
+                loader = ImageFolderU8(root, net, B)  # (MCM_DECODE_WORKERS overrides the loader's own choice: its CPU quota)
                 for px, _ in loader:  # warm-up pass: page cache, thread pool, slots
                     net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
                 torch.cuda.synchronize()

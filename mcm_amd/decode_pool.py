@@ -156,6 +156,12 @@ class DecodePool:
         else:
             self._pending[s] -= n
 
+    def drain(self):
+        """Waits out whatever is still in flight (a consumer that stopped in the middle of a pass)."""
+        for slot in range(self.slots):
+            while self._pending[slot] > 0:
+                self._read_done()
+
     def submit(self, slot: int, paths):
         assert self._pending[slot] == 0 and len(paths) <= self.batch
         self._paths[slot] = list(paths)

@@ -73,7 +73,7 @@ class ImageFolderU8:
             # the CPUs this container may really use (cgroup quota, not os.cpu_count()) shared between the node's ranks; more
             # workers than that run slower (measured on a 16-core quota: 16 workers 12.9k img/s, 64 workers 13.7k, 128 13.4k)
             local_ws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-            workers = max(1, min(64, effective_cpus() // local_ws))
+            workers = int(os.environ.get("MCM_DECODE_WORKERS", 0)) or max(1, min(64, effective_cpus() // local_ws))
         self.workers = int(workers)
         self._pool, self._pipe = None, None
 
@@ -114,6 +114,7 @@ class ImageFolderU8:
         if self._pool is None or self._pool.batch < self.batch_size:
             self._pool = DecodePool(self.workers, self.batch_size)
         pool, ahead = self._pool, self._pool.slots - 1
+        pool.drain()
         for i in range(min(ahead, len(starts))):
             pool.submit(i % pool.slots, [p for p, _ in chunk_of(starts[i])])
         for i, s in enumerate(starts):

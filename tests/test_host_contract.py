@@ -209,6 +209,9 @@ def test_decode_worker_processes_overflow_and_errors(tmp_path):
     assert all(p.poll() is not None for p in pool.procs)   # the workers are gone
     bad.unlink()
     ld = ImageFolderU8(str(tmp_path), None, 4, workers=2)
+    it = ld.decoded_batches()
+    next(it)
+    del it                       # a consumer that stops after one batch: the next pass waits out what was in flight
     views = [imgs for imgs, _ in ld.decoded_batches(copy=False)]
     assert sum(len(v) for v in views) == 21 and np.array_equal(views[-1][-1], want[-1])   # the last batch is still intact
     ld.close()
