@@ -1,14 +1,15 @@
 #!/bin/bash
-# scratch driver (round 4, call 36): whole GPU suite + default bench + smoke on the final tree
-mkdir -p gpurun_out/r4c36
-O=$PWD/gpurun_out/r4c36
-timeout 1800 python -m pytest tests -q -m gpu --durations=6 > $O/pytest.txt 2>&1; tail -12 $O/pytest.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -2 $O/bench_default.err
-python - <<PY
-import json
-d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
-print("value", round(d["value"]), "ingest", {k: round(v.get("images_per_sec", -1)) for k, v in d["ingest"].items()}, d.get("leg_seconds"), "frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
-c=d["cpu_baseline"]; print("cpu", c.get("value"), c.get("cores"))
-print("meets", d["parity"].get("meets_1e-4"), "arms", {k: round(v.get("images_per_sec", -1)) for k, v in d["arms"].items()})
-PY
+# scratch driver (round 4, call 37): rocprofv3 records of the final tree (+ the ingest path's kernels)
+bash tools/profile.sh r04_q > gpurun_out/prof_r04_q.log 2>&1; tail -8 gpurun_out/prof_r04_q.log
+out=$PWD/gpurun_out/prof_r04_q_ingest; mkdir -p $out
+root=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python $root/bench.py --steps 6 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 --no-profile --ingest host-raw --no-arms --no-live-traffic > $out/trace.log 2>&1
+cd $root
+tr=$(find $out/trace \( -name "*_results.db" -o -name "*kernel_stats.csv" \) | head -1)
+case "$tr" in
+  *.db) python tools/rocpd_summary.py $tr > $out/kernel_stats.txt ;;
+  *.csv) cp $tr $out/kernel_stats.txt ;;
+esac
+mkdir -p gpurun_out/prof_r04_q/summaries; cp $out/kernel_stats.txt gpurun_out/prof_r04_q/summaries/r04_q_ingest_kernel_stats.txt
+grep -i "resize\|kernel  " $out/kernel_stats.txt | head
