@@ -104,6 +104,7 @@ class DecodePool:
         finally:
             os.close(done_w)
         self._fin = weakref.finalize(self, DecodePool._shutdown, self.procs, self.done_r, path)
+        self.busy = False  # leased to a loader (mcm_amd/folder.py)
         self._pending = [0] * self.slots
         self._paths = [None] * self.slots
         self._next = 0
@@ -139,6 +140,9 @@ class DecodePool:
 
     def close(self):
         self._fin()
+
+    def alive(self) -> bool:
+        return self._fin.alive and all(p.poll() is None for p in self.procs)
 
     def _read_done(self):
         import select

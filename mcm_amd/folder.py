@@ -56,6 +56,31 @@ class FolderIndex:
 from .decode_pool import DecodePool, decode_rgb as _decode_rgb  # noqa: E402,F401
 
 
+# One decode pool per (workers, batch) and one packed pipe per (scorer, batch) serve every loader of the process: the CLI walks
+# five datasets one after the other, and starting 16 processes + pinning three 200-MB buffers per dataset cost more than
+# scoring the smaller sets.  A loader that finds the shared object in use (two loaders iterated at once) makes its own.
+_POOLS: dict = {}
+
+
+def _lease_pool(workers: int, batch: int) -> DecodePool:
+    p = _POOLS.get((workers, batch))
+    if p is None or not p.alive():
+        p = _POOLS[(workers, batch)] = DecodePool(workers, batch)
+    if p.busy:
+        p = DecodePool(workers, batch)
+        p.private = True
+    p.busy = True
+    p.drain()
+    return p
+
+
+def _release_pool(p: DecodePool):
+    p.drain()
+    p.busy = False
+    if getattr(p, "private", False):
+        p.close()
+
+
 class ImageFolderU8:
     """Iterates `(images uint8 [b,S,S,3] on the device, labels int64 [b])` over [lo, hi) of a FolderIndex."""
 
@@ -75,7 +100,6 @@ class ImageFolderU8:
             local_ws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
             workers = int(os.environ.get("MCM_DECODE_WORKERS", 0)) or max(1, min(64, effective_cpus() // local_ws))
         self.workers = int(workers)
-        self._pool, self._pipe = None, None
 
     def __len__(self) -> int:
         return max(0, -(-(self.hi - self.lo) // self.batch_size))
@@ -84,18 +108,28 @@ class ImageFolderU8:
         return ImageFolderU8(self.dataset, self.net, self.batch_size, lo, hi, self.workers)
 
     def close(self):
-        """Stops the decode workers (also done when the loader is garbage-collected)."""
-        if self._pool is not None:
-            self._pool.close()
-            self._pool = None
+        """Kept for callers of the earlier per-loader pools: the decode workers are shared by the process now and stop with it."""
 
     def gather(self, indices):
-        """uint8 [b,S,S,3] device batch of the named samples (threshold refinement, mcm_amd/refine.py)."""
+        """uint8 [b,S,S,3] device batch of the named samples (threshold refinement, mcm_amd/refine.py); more than a handful
+        are decoded by the worker processes."""
         import numpy as np
         import torch
 
-        # (np.array: a writable copy — the decoder's array is a read-only view of Pillow's bytes, which torch warns about)
-        return self.net.resize_crop([torch.from_numpy(np.array(_decode_rgb(self.dataset.samples[int(i)][0]))) for i in indices])
+        paths = [self.dataset.samples[int(i)][0] for i in indices]
+        if self.workers <= 1 or len(paths) < 32:
+            imgs = [np.array(_decode_rgb(p)) for p in paths]  # (np.array: writable — torch warns about read-only arrays)
+        else:
+            pool, imgs = _lease_pool(self.workers, self.batch_size), []
+            try:
+                for k in range(0, len(paths), pool.batch):
+                    pool.submit(0, paths[k:k + pool.batch])
+                    imgs += [a.copy() for a in pool.collect(0)]
+            finally:
+                _release_pool(pool)
+        out = [self.net.resize_crop([torch.from_numpy(a) for a in imgs[k:k + self.net.max_batch]])
+               for k in range(0, len(imgs), self.net.max_batch)]
+        return out[0] if len(out) == 1 else torch.cat(out)
 
     def decoded_batches(self, copy: bool = True) -> Iterator:
         """Host side only: `(list of decoded uint8 [H,W,3] arrays, labels int64 [b])` per batch, in dataset order; with
@@ -111,20 +145,21 @@ class ImageFolderU8:
             for s in starts:
                 yield [_decode_rgb(p) for p, _ in chunk_of(s)], labels_of(s)
             return
-        if self._pool is None or self._pool.batch < self.batch_size:
-            self._pool = DecodePool(self.workers, self.batch_size)
-        pool, ahead = self._pool, self._pool.slots - 1
-        pool.drain()
-        for i in range(min(ahead, len(starts))):
-            pool.submit(i % pool.slots, [p for p, _ in chunk_of(starts[i])])
-        for i, s in enumerate(starts):
-            imgs = pool.collect(i % pool.slots)
-            if copy:
-                imgs = [a.copy() for a in imgs]
-            yield imgs, labels_of(s)
-            # the consumer is done with batch i - that slot's views - once it asks for the next one
-            if i + ahead < len(starts):
-                pool.submit((i + ahead) % pool.slots, [p for p, _ in chunk_of(starts[i + ahead])])
+        pool = _lease_pool(self.workers, self.batch_size)
+        try:
+            ahead = pool.slots - 1
+            for i in range(min(ahead, len(starts))):
+                pool.submit(i % pool.slots, [p for p, _ in chunk_of(starts[i])])
+            for i, s in enumerate(starts):
+                imgs = pool.collect(i % pool.slots)
+                if copy:
+                    imgs = [a.copy() for a in imgs]
+                yield imgs, labels_of(s)
+                # the consumer is done with batch i - that slot's views - once it asks for the next one
+                if i + ahead < len(starts):
+                    pool.submit((i + ahead) % pool.slots, [p for p, _ in chunk_of(starts[i + ahead])])
+        finally:  # also when the consumer stops in the middle of a pass (generator closed): what is in flight is waited out
+            _release_pool(pool)
 
     def __iter__(self) -> Iterator:
         """Decode pool → ONE packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on
@@ -138,9 +173,16 @@ class ImageFolderU8:
                 labels.append(lab)
                 yield imgs
 
-        if self._pipe is None:  # kept across passes: its pinned slots (grown to the largest batch seen) are expensive to make
-            self._pipe = PackedImagePipe(self.net, self.batch_size, self.batch_size * 512 * 512 * 3 // 2,   # (slots grow on demand)
-                                         pack_threads=min(8, max(1, self.workers)))
-        pipe = self._pipe
-        for i, dev_batch in enumerate(pipe.stream(images())):
-            yield dev_batch, labels[i]
+        # kept on the scorer across passes and loaders: its pinned slots (grown to the largest batch seen) are expensive to make
+        pipes = self.net.__dict__.setdefault("_packed_pipes", {})
+        pipe = pipes.get(self.batch_size)
+        if pipe is None or getattr(pipe, "busy", False):
+            pipe = PackedImagePipe(self.net, self.batch_size, self.batch_size * 512 * 512 * 3 // 2,   # (slots grow on demand)
+                                   pack_threads=min(8, max(1, self.workers)))
+            pipes.setdefault(self.batch_size, pipe)
+        pipe.busy = True
+        try:
+            for i, dev_batch in enumerate(pipe.stream(images())):
+                yield dev_batch, labels[i]
+        finally:
+            pipe.busy = False
