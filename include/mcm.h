@@ -198,6 +198,24 @@ int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const 
 int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, const int64_t* offsets, int32_t n, uint8_t* dst,
                 int64_t dst_bytes, int32_t threads);
 
+/* JPEG ingest, host half (csrc/jpeg_entropy.cpp): file -> markers -> Huffman decode -> quantised DCT coefficients, written by
+ * `threads` native threads into dst (the pinned buffer a batch is uploaded from) — the part of the reference loader's
+ * `Image.open(path).convert("RGB")` (torchvision ImageFolder, utils/train_eval_util.py:96-146) that is bit-serial; the
+ * device half (mcm_jpeg_reconstruct) turns the coefficients into the RGB pixels libjpeg would have produced.
+ * meta[i].status: 0 taken; 1 a JPEG this path does not take (progressive, arithmetic, 12-bit, CMYK / RGB-coded, several
+ * scans, sampling other than 4:4:4 / 4:2:2 / 4:2:0): decode it with the fallback decoder; 2 unreadable or corrupt.
+ * Component c of image i: int16 [hb][wb][64] coefficients in natural order at dst + coef_off[c]; its quantisation table at
+ * quant[(i * 3 + c) * 64].  *bytes_used = bytes of dst the batch needs; MCM_ERANGE (nothing decoded) when dst_bytes is less. */
+typedef struct mcm_jpeg_image {
+  int32_t status;
+  int32_t width, height, ncomp;
+  int32_t hs[3], vs[3];   /* sampling factors */
+  int32_t wb[3], hb[3];   /* blocks per row / per column of the coefficient planes (whole MCUs) */
+  int64_t coef_off[3];
+} mcm_jpeg_image;
+int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void* dst, int64_t dst_bytes, mcm_jpeg_image* meta,
+                            uint16_t* quant, int32_t threads, int64_t* bytes_used);
+
 /* Prompt-ensemble bank (BASELINE config 5): feats_dev = unit-norm text
  * features [K*T, proj_dim], class-major (row k*T + t = template t of class k), as written by
  * mcm_encode_text; bank_dev [K, proj_dim] = normalise(mean over the T templates).  The reference

@@ -21,6 +21,14 @@ WEIGHT_OPERANDS = {"auto": 0, "single": 1, "split": 2}  # include/mcm.h MCM_WEIG
 SCORE_KINDS = {"MCM": 0, "max-logit": 1, "energy": 2, "entropy": 3, "var": 4}
 
 
+class JpegImage(ctypes.Structure):
+    """Field-for-field mirror of `struct mcm_jpeg_image` in include/mcm.h."""
+
+    _fields_ = [("status", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ncomp", ctypes.c_int32),
+                ("hs", ctypes.c_int32 * 3), ("vs", ctypes.c_int32 * 3), ("wb", ctypes.c_int32 * 3), ("hb", ctypes.c_int32 * 3),
+                ("coef_off", ctypes.c_int64 * 3)]
+
+
 class CConfig(ctypes.Structure):
     """Field-for-field mirror of `struct mcm_config` in include/mcm.h."""
 

@@ -91,6 +91,8 @@ def load_library(harness: bool = False):
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mcm_resize_crop_u8.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), i32, vp, vp]
+    L.mcm_jpeg_entropy_decode.argtypes = [ctypes.POINTER(ctypes.c_char_p), i32, vp, ctypes.c_int64, vp, vp, i32,
+                                          ctypes.POINTER(ctypes.c_int64)]
     L.mcm_pack_u8.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), i32, vp,
                               ctypes.c_int64, i32]
     L.mcm_tokenizer_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -128,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
     "mcm_saturation_check", "mcm_saturation_count",
     "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight", "mcm_pack_u8",
+    "mcm_jpeg_entropy_decode",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",

@@ -133,6 +133,24 @@ def resize_crop_u8(img, size=224):
     return out
 
 
+def jpeg_reconstruct(coef, quant, width, height, hs, vs, wb, hb):
+    """Quantised DCT coefficients -> RGB uint8 [height,width,3] as libjpeg's default decompressor gives (oracle/jpeg_ref.c).
+    coef: list of int16 arrays [hb_c, wb_c, 64] (natural order), one per component; quant: uint16 [ncomp, 64]."""
+    ncomp = len(coef)
+    coef = [np.ascontiguousarray(c, dtype=np.int16) for c in coef]
+    quant = np.ascontiguousarray(quant, dtype=np.uint16)
+    out = np.empty((height, width, 3), dtype=np.uint8)
+    ptrs = (ctypes.c_void_p * 3)(*([c.ctypes.data for c in coef] + [None] * (3 - ncomp)))
+    i3 = lambda v: (ctypes.c_int * 3)(*(list(v) + [0] * (3 - len(v))))  # noqa: E731
+    f = lib().orc_jpeg_reconstruct
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = f(ptrs, quant.ctypes.data, width, height, ncomp, i3(hs), i3(vs), i3(wb), i3(hb), out.ctypes.data)
+    if rc:
+        raise RuntimeError(f"orc_jpeg_reconstruct rc={rc}")
+    return out
+
+
 def maha_scores(feats, means, prec):
     """get_Mahalanobis_score's per-sample value for features [B,P], class means [C,P], precision [P,P]."""
     feats = _c32(feats); means = _c32(means); prec = _c32(prec)
