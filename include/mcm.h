@@ -216,6 +216,15 @@ typedef struct mcm_jpeg_image {
 int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void* dst, int64_t dst_bytes, mcm_jpeg_image* meta,
                             uint16_t* quant, int32_t threads, int64_t* bytes_used);
 
+/* JPEG ingest, device half (csrc/jpeg.hip): the coefficients of a batch (uploaded as they were written by
+ * mcm_jpeg_entropy_decode; coef_dev = device copy of its dst) -> dequantisation, libjpeg's default inverse DCT
+ * (jpeg_idct_islow), fancy chroma upsampling and YCbCr -> RGB: uint8 [height_i, width_i, 3] at rgb_dev + rgb_offsets[i] —
+ * byte for byte what Pillow's Image.open(path).convert("RGB") returns (the reference's loader decodes with it).  meta / quant /
+ * rgb_offsets are HOST arrays of length n; images whose status is not 0 are skipped (the caller decodes those with its
+ * fallback and writes their pixels itself).  Asynchronous on `stream`; the output is what mcm_resize_crop_u8 takes. */
+int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_image* meta, const uint16_t* quant, int32_t n,
+                         uint8_t* rgb_dev, const int64_t* rgb_offsets, void* stream);
+
 /* Prompt-ensemble bank (BASELINE config 5): feats_dev = unit-norm text
  * features [K*T, proj_dim], class-major (row k*T + t = template t of class k), as written by
  * mcm_encode_text; bank_dev [K, proj_dim] = normalise(mean over the T templates).  The reference

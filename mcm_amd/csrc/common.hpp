@@ -326,6 +326,17 @@ struct PrepImage {
   int32_t nh, nw;      // size after Resize(S)
   int32_t top, left;   // CenterCrop origin inside the resized image
 };
+// jpeg.hip: one decoded-to-coefficients image as the kernels see it
+struct JpegImageDev {
+  int32_t width, height, ncomp;
+  int32_t H, V;              // luma sampling factors (chroma is 1 x 1)
+  int32_t wb[3], hb[3];      // blocks per row / column of each component
+  int64_t coef_off[3];       // bytes into the coefficient buffer: int16 [hb][wb][64], natural order
+  int64_t plane_off[3];      // bytes into the sample-plane workspace: uint8 [hb * 8][wb * 8]
+  int64_t rgb_off;           // bytes into the output: uint8 [height][width][3]
+};
+hipError_t launch_jpeg_reconstruct(const JpegImageDev* meta_dev, const uint16_t* quant_dev, const void* coef_dev,
+                                   uint8_t* planes_dev, uint8_t* rgb_dev, int n, int max_blocks, int max_pixels, hipStream_t s);
 int prep_max_taps();
 // coef_dev: prep_coef_bytes(max_batch, S) of workspace for the per-image coefficient tables of the LDS form (nullptr: the
 // fused form everywhere); fused_only (A/B, harness builds): every workgroup takes the rounds-2/3 form

@@ -39,6 +39,21 @@ struct Huff {
   int32_t maxcode[18];
   int32_t valoff[17];
   uint16_t look[512];  // (length << 8) | symbol, 0 = longer than 9 bits
+  // AC tables: the next 10 bits -> a whole (run, value) when code + value bits fit in them:
+  // (value << 8) | (run << 4) | total bits; 0 = take the two-step path
+  int16_t fast_ac[1024];
+  void build_fast_ac() {
+    for (int i = 0; i < 1024; ++i) {
+      fast_ac[i] = 0;
+      const uint16_t lk = look[i >> 1];
+      if (!lk) continue;
+      const int len = lk >> 8, rs = lk & 255, run = rs >> 4, sz = rs & 15;
+      if (sz == 0 || len + sz > 10) continue;
+      int v = ((i << len) & 1023) >> (10 - sz);
+      if (v < (1 << (sz - 1))) v += 1 - (1 << sz);  // EXTEND
+      if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)((v * 256) + (run * 16) + (len + sz));
+    }
+  }
   bool build() {
     int code = 0, k = 0;
     memset(look, 0, sizeof look);
@@ -127,6 +142,7 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
         if (cnt > 256 || o + 17 + cnt > sl) return;
         memcpy(h.vals, s + o + 17, (size_t)cnt);
         if (!h.build()) return;
+        if (tc) h.build_fast_ac();
         h.set = true;
         o += 17 + cnt;
       }
@@ -191,11 +207,22 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
 struct Bits {
   const uint8_t* p;
   const uint8_t* end;
-  uint64_t acc = 0;
-  int cnt = 0;
-  bool marker = false;  // a marker was reached: zeros are fed from here on
+  uint64_t acc = 0;  // the next bits, top-aligned
+  int cnt = 0;       // valid bits in acc
+  bool marker = false;  // a marker (or the end) was reached: zeros are fed from here on
+  // after fill(): cnt > 32 — enough for one Huffman code (<= 16 bits) and its value bits (<= 15), so a symbol needs one check
   inline void fill() {
-    while (cnt <= 56) {
+    while (cnt <= 32) {
+      if (!marker && p + 4 <= end) {
+        const uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+        const uint32_t v = ~w;
+        if (!((v - 0x01010101u) & ~v & 0x80808080u)) {  // no 0xFF among the four bytes: no stuffing, no marker
+          acc |= (uint64_t)w << (32 - cnt);
+          cnt += 32;
+          p += 4;
+          continue;
+        }
+      }
       uint32_t b = 0;
       if (!marker && p < end) {
         b = *p;
@@ -216,20 +243,15 @@ struct Bits {
       cnt += 8;
     }
   }
-  inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+  inline uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
   inline void drop(int n) { acc <<= n; cnt -= n; }
-  inline int get(int n) {  // RECEIVE
-    if (cnt < n) fill();
-    const uint32_t v = peek(n);
-    drop(n);
-    return (int)v;
-  }
 };
 
-inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+// T.81 F.2.2.1 EXTEND, branch-free
+inline int extend(int v, int s) { return v + (((v - (1 << (s - 1))) >> 31) & (1 - (1 << s))); }
 
+// DECODE; the caller has made sure of 32 bits
 inline int decode(Bits& b, const Huff& h) {
-  if (b.cnt < 16) b.fill();
   const uint32_t lk = h.look[b.peek(9)];
   if (lk) {
     b.drop(lk >> 8);
@@ -276,11 +298,24 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
         for (int by = 0; by < m.vs[c]; ++by) {
           for (int bx = 0; bx < m.hs[c]; ++bx) {
             int16_t* blk = plane[c] + ((size_t)(y * m.vs[c] + by) * m.wb[c] + (x * m.hs[c] + bx)) * 64;
+            if (b.cnt < 32) b.fill();
             int s = decode(b, hd);
             if (s < 0 || s > 11) return false;
-            if (s) pred[c] += extend(b.get(s), s);
+            if (s) {
+              pred[c] += extend((int)b.peek(s), s);
+              b.drop(s);
+            }
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
+              if (b.cnt < 32) b.fill();
+              const int fa = ha.fast_ac[b.peek(10)];
+              if (fa) {  // code and value in one look-up
+                k += (fa >> 4) & 15;
+                if (k > 63) return false;
+                b.drop(fa & 15);
+                blk[ZIGZAG[k++]] = (int16_t)(fa >> 8);
+                continue;
+              }
               const int rs = decode(b, ha);
               if (rs < 0) return false;
               const int r = rs >> 4;
@@ -288,7 +323,8 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
               if (s) {
                 k += r;
                 if (k > 63) return false;
-                blk[ZIGZAG[k]] = (int16_t)extend(b.get(s), s);
+                blk[ZIGZAG[k]] = (int16_t)extend((int)b.peek(s), s);
+                b.drop(s);
                 ++k;
               } else if (r == 15) {
                 k += 16;

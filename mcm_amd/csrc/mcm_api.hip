@@ -72,6 +72,14 @@ struct mcm_handle {
   static constexpr int PREP_RING = 4;
   PrepImage *prep_pin = nullptr, *prep_dev = nullptr;
   int32_t* prep_coef = nullptr;  // PREP_RING x prep_coef_bytes: the resize kernel's coefficient tables (allocated by the first call)
+  // mcm_jpeg_reconstruct: per-image records + quantisation tables through the same kind of ring (allocated by the first
+  // call), and the sample-plane workspace (grown on demand; one per handle: the kernels of consecutive calls are stream-ordered)
+  char* jpg_pin = nullptr;
+  char* jpg_dev = nullptr;
+  hipEvent_t jpg_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned jpg_next = 0;
+  uint8_t* jpg_planes = nullptr;
+  size_t jpg_planes_bytes = 0;
   hipEvent_t prep_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
   unsigned prep_next = 0;
   int64_t max_rows = 0;
@@ -641,6 +649,10 @@ void mcm_destroy(mcm_handle* h) {
   if (h->ids_pin) (void)hipHostFree(h->ids_pin);
   if (h->rowidx_pin) (void)hipHostFree(h->rowidx_pin);
   if (h->prep_pin) (void)hipHostFree(h->prep_pin);
+  if (h->jpg_pin) (void)hipHostFree(h->jpg_pin);
+  if (h->jpg_planes) (void)hipFree(h->jpg_planes);
+  for (auto& e : h->jpg_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : h->prep_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev_pool) {
@@ -935,6 +947,76 @@ int mcm_resize_crop_u8(mcm_handle* h, const uint8_t* const* src_dev_ptrs, const 
   }
   int32_t* coef = (int32_t*)((char*)h->prep_coef + (size_t)slot * prep_coef_bytes(h->cfg.max_batch, S));
   HIP_TRY(h, launch_resize_crop(dev, coef, B, S, dst_dev, s, g_resize_fused_only != 0));
+  return MCM_OK;
+}
+
+int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_image* meta, const uint16_t* quant, int32_t n,
+                         uint8_t* rgb_dev, const int64_t* rgb_offsets, void* stream) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!coef_dev || !meta || !quant || !rgb_dev || !rgb_offsets) return fail(h, MCM_EINVAL, "null pointer");
+  if (n <= 0) return fail(h, MCM_EINVAL, "n must be positive");
+  if (n > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds max_batch");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t rec = sizeof(JpegImageDev) + 3 * 64 * sizeof(uint16_t), slot_bytes = (size_t)h->cfg.max_batch * rec;
+  if (!h->jpg_pin) {  // first call on this handle
+    if (hipHostMalloc((void**)&h->jpg_pin, mcm_handle::PREP_RING * slot_bytes) != hipSuccess) return fail(h, MCM_ENOMEM, "hipHostMalloc jpeg");
+    rc = dev_alloc(h, (void**)&h->jpg_dev, mcm_handle::PREP_RING * slot_bytes);
+    if (rc) return rc;
+    for (int k = 0; k < mcm_handle::PREP_RING; ++k)
+      if (hipEventCreateWithFlags(&h->jpg_ev[k], hipEventDisableTiming) != hipSuccess) return fail(h, MCM_EHIP, "hipEventCreate jpeg");
+  }
+  const unsigned slot = h->jpg_next++ % mcm_handle::PREP_RING;
+  char* pin = h->jpg_pin + slot * slot_bytes;
+  char* dev = h->jpg_dev + slot * slot_bytes;
+  HIP_TRY(h, hipEventSynchronize(h->jpg_ev[slot]));
+  JpegImageDev* md = (JpegImageDev*)pin;
+  uint16_t* qd = (uint16_t*)(pin + (size_t)h->cfg.max_batch * sizeof(JpegImageDev));
+  size_t planes = 0;
+  int m = 0, max_blocks = 0, max_pixels = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const mcm_jpeg_image& im = meta[i];
+    if (im.status != 0) continue;  // not taken by the entropy decoder: the caller fills this image's pixels itself
+    if (im.width <= 0 || im.height <= 0 || (im.ncomp != 1 && im.ncomp != 3) || rgb_offsets[i] < 0) return fail(h, MCM_EINVAL, "bad jpeg record");
+    JpegImageDev& d = md[m];
+    d.width = im.width; d.height = im.height; d.ncomp = im.ncomp;
+    d.H = im.ncomp == 3 ? im.hs[0] : 1;
+    d.V = im.ncomp == 3 ? im.vs[0] : 1;
+    if (im.ncomp == 3 && !((d.H == 1 && d.V == 1) || (d.H == 2 && d.V == 1) || (d.H == 2 && d.V == 2))) return fail(h, MCM_EINVAL, "sampling not taken");
+    int blocks = 0;
+    for (int c = 0; c < 3; ++c) {
+      d.wb[c] = c < im.ncomp ? im.wb[c] : 0;
+      d.hb[c] = c < im.ncomp ? im.hb[c] : 0;
+      d.coef_off[c] = c < im.ncomp ? im.coef_off[c] : 0;
+      d.plane_off[c] = (int64_t)planes;
+      if (c < im.ncomp) {
+        if (im.wb[c] <= 0 || im.hb[c] <= 0 || im.coef_off[c] < 0 || (im.coef_off[c] & 15)) return fail(h, MCM_EINVAL, "bad jpeg plane");
+        planes += (size_t)im.wb[c] * im.hb[c] * 64;
+        blocks += im.wb[c] * im.hb[c];
+      }
+    }
+    d.rgb_off = rgb_offsets[i];
+    memcpy(qd + (size_t)m * 192, quant + (size_t)i * 192, 192 * sizeof(uint16_t));
+    max_blocks = blocks > max_blocks ? blocks : max_blocks;
+    max_pixels = im.width * im.height > max_pixels ? im.width * im.height : max_pixels;
+    ++m;
+  }
+  if (m == 0) return MCM_OK;
+  if (planes > h->jpg_planes_bytes) {  // grow (synchronous, rare: the first batches of a run)
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (h->jpg_planes) (void)hipFree(h->jpg_planes);
+    h->jpg_planes = nullptr;
+    h->jpg_planes_bytes = 0;
+    const size_t want = planes + planes / 4 + (1 << 20);
+    if (hipMalloc((void**)&h->jpg_planes, want) != hipSuccess) return fail(h, MCM_ENOMEM, "hipMalloc jpeg planes");
+    h->jpg_planes_bytes = want;
+  }
+  HIP_TRY(h, hipMemcpyAsync(dev, pin, (size_t)m * sizeof(JpegImageDev), hipMemcpyHostToDevice, s));
+  const size_t qoff = (size_t)h->cfg.max_batch * sizeof(JpegImageDev);
+  HIP_TRY(h, hipMemcpyAsync(dev + qoff, pin + qoff, (size_t)m * 192 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipEventRecord(h->jpg_ev[slot], s));
+  HIP_TRY(h, launch_jpeg_reconstruct((const JpegImageDev*)dev, (const uint16_t*)(dev + qoff), coef_dev, h->jpg_planes, rgb_dev, m,
+                                     max_blocks, max_pixels, s));
   return MCM_OK;
 }
 

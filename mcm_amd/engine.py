@@ -91,6 +91,7 @@ def load_library(harness: bool = False):
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mcm_resize_crop_u8.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32), i32, vp, vp]
+    L.mcm_jpeg_reconstruct.argtypes = [vp, vp, vp, vp, i32, vp, ctypes.POINTER(ctypes.c_int64), vp]
     L.mcm_jpeg_entropy_decode.argtypes = [ctypes.POINTER(ctypes.c_char_p), i32, vp, ctypes.c_int64, vp, vp, i32,
                                           ctypes.POINTER(ctypes.c_int64)]
     L.mcm_pack_u8.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), i32, vp,
@@ -130,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "mcm_encode_image_ex", "mcm_encode_text_ex", "mcm_score_histogram",
     "mcm_saturation_check", "mcm_saturation_count",
     "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight", "mcm_pack_u8",
-    "mcm_jpeg_entropy_decode",
+    "mcm_jpeg_entropy_decode", "mcm_jpeg_reconstruct",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
@@ -379,6 +380,15 @@ class NativeCLIP:
             out = torch.empty((B, S, S, 3), device=self.device, dtype=torch.uint8)
         self._check(self._lib.mcm_resize_crop_u8(self._h, ptrs, hs, ws, B, out.data_ptr(), _stream_ptr()))
         return out
+
+    def jpeg_reconstruct(self, coef_dev, meta, quant, n: int, rgb_dev, rgb_offsets):
+        """Device half of the JPEG ingest (mcm_jpeg_reconstruct): the coefficients mcm_jpeg_entropy_decode wrote (device
+        copy `coef_dev`, uint8 1-D) -> RGB uint8 [H_i, W_i, 3] at rgb_dev + rgb_offsets[i], byte for byte Pillow's decode.
+        `meta`: ctypes array of config.JpegImage, `quant`: uint16 numpy [n, 3, 64] (both as the entropy decoder filled them);
+        images whose status is not 0 are skipped.  Asynchronous on the current stream."""
+        offs = (ctypes.c_int64 * n)(*[int(o) for o in rgb_offsets])
+        self._check(self._lib.mcm_jpeg_reconstruct(self._h, coef_dev.data_ptr(), ctypes.addressof(meta), quant.ctypes.data, n,
+                                                   rgb_dev.data_ptr(), offs, _stream_ptr()))
 
     def measures(self, pos_scores, neg_scores, recall_level: float = 0.95, negate: bool = False):
         """`get_measures` (reference utils/detection_util.py:108-119) on device score vectors:

@@ -10,6 +10,10 @@ the patch gather) runs on the device.
   PackedImagePipe   variable-size decoded images [H_i,W_i,3]: packed back to back into ONE pinned buffer, ONE copy per
                     batch, then `mcm_resize_crop_u8` over device pointers into the packed buffer (round 3 uploaded every
                     image with its own synchronous `.to(device)`: 512 unpinned copies per batch on the compute stream)
+  JpegFilePipe      JPEG FILES: native threads do the bit-serial part of the decode (markers + Huffman,
+                    mcm_jpeg_entropy_decode) straight into the pinned upload buffer, the DCT coefficients cross PCIe in place
+                    of pixels, and the device does the rest of libjpeg's work (mcm_jpeg_reconstruct: inverse DCT, chroma
+                    upsampling, colour conversion — byte for byte Pillow's pixels) before Resize + CenterCrop
 
 PyTorch is plumbing here (pinned allocations, streams, events); no arithmetic.
 """
@@ -213,3 +217,143 @@ class PackedImagePipe(_Pipe):
         b = len(offs)
         yield self.net.resize_crop_packed(s.dev, offs, hs, ws, out=out[:b])
         self.done(s)
+
+
+class _JSlot:
+    def __init__(self, max_batch: int, coef_bytes: int, device):
+        import torch
+
+        from .config import JpegImage
+
+        self.host = torch.empty(int(coef_bytes), dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.empty(0, dtype=torch.uint8, device=device)
+        self.rgb = torch.empty(0, dtype=torch.uint8, device=device)
+        self.meta = (JpegImage * max_batch)()
+        self.quant = np.zeros((max_batch, 3, 64), dtype=np.uint16)
+        self.copied, self.consumed = torch.cuda.Event(), torch.cuda.Event()
+        self.used = False
+
+
+class JpegFilePipe:
+    """Batches of JPEG file names → uint8 [b,S,S,3] device batches, bit-identical to Pillow decode + Resize + CenterCrop.
+
+        pipe = JpegFilePipe(net, max_batch)
+        for dev_batch in pipe.stream(batches_of_paths):   # each item: a list of file names
+            scores = net.score_images(dev_batch, bank)
+
+    A producer thread runs the native entropy decoder (`threads` host threads, no GIL) for the next batches into pinned
+    slots while this thread uploads, reconstructs, resizes and hands out the current one.  Files the entropy decoder does not
+    take (progressive / CMYK JPEGs, PNGs, …) are decoded by Pillow in the producer thread and uploaded as pixels; a file
+    nothing can decode raises Pillow's error in the consumer."""
+
+    ALIGN = 16
+
+    def __init__(self, net, max_batch: int, depth: int = 3, threads: int | None = None):
+        import torch
+
+        from .hostinfo import effective_cpus
+
+        self.net, self.device, self.max_batch = net, net.device, int(max_batch)
+        self.threads = int(threads) if threads else max(1, effective_cpus() - 1)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = [_JSlot(self.max_batch, self.max_batch * (640 << 10), self.device) for _ in range(max(2, depth))]
+        S = net.geo.image_size
+        self.out = [torch.empty((self.max_batch, S, S, 3), dtype=torch.uint8, device=self.device) for _ in self.slots]
+        self.bytes_copied = 0
+        self.fallback_images = 0
+        self.busy = False
+
+    def _produce(self, batches, q, stop):
+        import ctypes
+        import os
+
+        import torch
+
+        from .decode_pool import decode_rgb
+
+        lib = self.net._lib
+        try:
+            for i, paths in enumerate(batches):
+                n = len(paths)
+                if n > self.max_batch:
+                    raise ValueError(f"{n} files exceed max_batch {self.max_batch}")
+                s = self.slots[i % len(self.slots)]
+                if s.used:
+                    s.consumed.synchronize()
+                    s.copied.synchronize()
+                arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+                used = ctypes.c_int64(0)
+                while True:
+                    rc = lib.mcm_jpeg_entropy_decode(arr, n, s.host.data_ptr(), s.host.numel(), s.meta, s.quant.ctypes.data,
+                                                     self.threads, ctypes.byref(used))
+                    if rc == 0:
+                        break
+                    if rc != -7 or used.value <= s.host.numel():  # MCM_ERANGE = the slot is too small: grow and retry
+                        raise RuntimeError(f"mcm_jpeg_entropy_decode rc={rc}")
+                    s.host = torch.empty(int(used.value * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
+                fallbacks = {j: decode_rgb(paths[j]) for j in range(n) if s.meta[j].status != 0}
+                item = (i, s, n, int(used.value), fallbacks)
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.2)
+                        break
+                    except Exception:
+                        continue
+                if stop.is_set():
+                    return
+            q.put(None)
+        except BaseException as e:  # handed to the consumer
+            q.put(e)
+
+    def stream(self, batches: Iterable[Sequence]) -> Iterator:
+        import queue
+        import threading
+
+        import torch
+
+        q = queue.Queue(maxsize=max(1, len(self.slots) - 2))
+        stop = threading.Event()
+        th = threading.Thread(target=self._produce, args=(iter(batches), q, stop), daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                i, s, n, nbytes, fallbacks = item
+                hs, ws, offs, o = [], [], [], 0
+                for j in range(n):
+                    h, w = fallbacks[j].shape[:2] if j in fallbacks else (s.meta[j].height, s.meta[j].width)
+                    hs.append(h)
+                    ws.append(w)
+                    offs.append(o)
+                    o += (h * w * 3 + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                if s.dev.numel() < nbytes or s.rgb.numel() < o:  # this slot's device buffers grow to the largest batch seen
+                    if s.used:
+                        s.consumed.synchronize()
+                    if s.dev.numel() < nbytes:
+                        s.dev = torch.empty(int(nbytes * 1.25) + (1 << 20), dtype=torch.uint8, device=self.device)
+                    if s.rgb.numel() < o:
+                        s.rgb = torch.empty(int(o * 1.25) + (1 << 20), dtype=torch.uint8, device=self.device)
+                with torch.cuda.stream(self.copy_stream):
+                    if s.used:
+                        self.copy_stream.wait_event(s.consumed)
+                    if nbytes:
+                        s.dev[:nbytes].copy_(s.host[:nbytes], non_blocking=True)
+                    for j, a in fallbacks.items():  # (rare; pageable pixels, a copy each)
+                        s.rgb[offs[j]: offs[j] + a.size].copy_(torch.from_numpy(np.array(a)).reshape(-1))
+                    s.copied.record(self.copy_stream)
+                s.used = True
+                self.bytes_copied += nbytes
+                self.fallback_images += len(fallbacks)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(s.copied)
+                if len(fallbacks) < n:
+                    self.net.jpeg_reconstruct(s.dev, s.meta, s.quant, n, s.rgb, offs)
+                out = self.net.resize_crop_packed(s.rgb, offs, hs, ws, out=self.out[i % len(self.slots)][:n])
+                yield out
+                s.consumed.record(torch.cuda.current_stream(self.device))
+        finally:
+            stop.set()
