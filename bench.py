@@ -400,6 +400,8 @@ def ingest_legs(net, txt, B, steps, which):
                         fh.write(blobs[i % len(blobs)])
                     fbytes += len(blobs[i % len(blobs)])
                 loader = ImageFolderU8(root, net, B)  # (MCM_DECODE_WORKERS overrides the loader's own choice: its CPU quota)
+                route = ("entropy decode on host threads, inverse DCT + upsampling + colour on the device"
+                         if os.environ.get("MCM_GPU_JPEG", "1") != "0" else "Pillow in worker processes")
                 for px, _ in loader:  # warm-up pass: page cache, thread pool, slots
                     net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
                 torch.cuda.synchronize()
@@ -414,8 +416,9 @@ def ingest_legs(net, txt, B, steps, which):
                                     "steps": passes * nfiles // B, "decode_workers": loader.workers, "host_cpus": os.cpu_count(),
                                     "cpu_quota_cores": __import__("mcm_amd.hostinfo", fromlist=["cpu_quota"]).cpu_quota(),
                                     "jpeg_bytes_per_image": fbytes / nfiles,
+                                    "decoder": route,
                                     "source": f"{nfiles} JPEG files (quality 90, 8 sizes 256x341 ... 600x800) in an image folder, read + "
-                                              "decoded by Pillow in the loader's worker processes (shared-memory hand-over), then the host_raw path; "
+                                              "decoded by the CLI's loader (see decoder), Resize + CenterCrop + scoring on the device; "
                                               "bound by the host cores this container is given (decode_workers = its CPU quota)"}
             finally:
                 shutil.rmtree(root, ignore_errors=True)

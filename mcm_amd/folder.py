@@ -161,9 +161,34 @@ class ImageFolderU8:
         finally:  # also when the consumer stops in the middle of a pass (generator closed): what is in flight is waited out
             _release_pool(pool)
 
+    def _iter_jpeg(self) -> Iterator:
+        """Files → native entropy decode into pinned memory → coefficients over PCIe → inverse DCT, upsampling, colour, Resize
+        + CenterCrop on the device (mcm_amd.ingest.JpegFilePipe); anything that is not a baseline JPEG takes Pillow inside it."""
+        import torch
+
+        from .ingest import JpegFilePipe
+
+        starts = list(range(self.lo, self.hi, self.batch_size))
+        chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
+        pipes = self.net.__dict__.setdefault("_jpeg_pipes", {})
+        pipe = pipes.get(self.batch_size)
+        if pipe is None or pipe.busy:
+            pipe = JpegFilePipe(self.net, self.batch_size, threads=self.workers)
+            pipes.setdefault(self.batch_size, pipe)
+        pipe.busy = True
+        try:
+            for i, dev_batch in enumerate(pipe.stream([p for p, _ in chunk_of(s)] for s in starts)):
+                yield dev_batch, torch.tensor([t for _, t in chunk_of(starts[i])], dtype=torch.long)
+        finally:
+            pipe.busy = False
+
     def __iter__(self) -> Iterator:
-        """Decode pool → ONE packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on
-        the device (mcm_amd.ingest.PackedImagePipe): batch i+1 is decoded, packed and copied while batch i is scored."""
+        """Default (MCM_GPU_JPEG unset or 1): `_iter_jpeg`.  MCM_GPU_JPEG=0: decode pool (Pillow in worker processes) → ONE
+        packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on the device
+        (mcm_amd.ingest.PackedImagePipe): batch i+1 is decoded, packed and copied while batch i is scored."""
+        if os.environ.get("MCM_GPU_JPEG", "1") != "0":
+            yield from self._iter_jpeg()
+            return
         from .ingest import PackedImagePipe
 
         labels = []

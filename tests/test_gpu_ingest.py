@@ -73,7 +73,7 @@ def test_packed_image_pipe_equals_per_image_resize_crop(net):
         list(PackedImagePipe(net, 4, 1 << 20).stream([batch(5, 224, 230)]))
 
 
-def test_jpeg_folder_through_decode_processes_equals_serial_decode(net, tmp_path):
+def test_jpeg_folder_through_decode_processes_equals_serial_decode(net, tmp_path, monkeypatch):
     """The image-folder loader end to end in a process that holds a HIP context: JPEG / PNG files decoded by the worker
     PROCESSES of mcm_amd/decode_pool.py (shared-memory hand-over) -> packed copy -> Resize + CenterCrop on the device ->
     scores, against the same files decoded in this thread; two passes over the same loader (its pool and its pinned slots
@@ -103,6 +103,7 @@ def test_jpeg_folder_through_decode_processes_equals_serial_decode(net, tmp_path
             out.append(torch.cat([net.score_images(px, bank).clone() for px, _ in loader]))
         return out
 
+    monkeypatch.setenv("MCM_GPU_JPEG", "0")   # the Pillow routes first: in this thread, then in the worker processes
     serial = scores(ImageFolderU8(str(tmp_path), net, 48, workers=1))[0]
     pooled_loader = ImageFolderU8(str(tmp_path), net, 48, workers=5)
     first, second = scores(pooled_loader, passes=2)
@@ -113,3 +114,10 @@ def test_jpeg_folder_through_decode_processes_equals_serial_decode(net, tmp_path
     shard = ImageFolderU8(str(tmp_path), net, 48, workers=3).shard(lo, hi)
     assert torch.equal(scores(shard)[0], serial[lo:hi])
     shard.close()
+    # the default route: entropy decode on host threads, the rest of the JPEG decode on the device (the PNG files and the
+    # oversized PNG take Pillow inside the pipe) — the same scores, bit for bit, over two passes and over a shard
+    monkeypatch.setenv("MCM_GPU_JPEG", "1")
+    dev_loader = ImageFolderU8(str(tmp_path), net, 48, workers=3)
+    first, second = scores(dev_loader, passes=2)
+    assert torch.equal(first, serial) and torch.equal(second, serial)
+    assert torch.equal(scores(dev_loader.shard(lo, hi))[0], serial[lo:hi])
