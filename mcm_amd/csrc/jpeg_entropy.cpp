@@ -39,17 +39,18 @@ struct Huff {
   int32_t maxcode[18];
   int32_t valoff[17];
   uint16_t look[512];  // (length << 8) | symbol, 0 = longer than 9 bits
-  // AC tables: the next 10 bits -> a whole (run, value) when code + value bits fit in them:
+  // AC tables: the next FAST bits -> a whole (run, value) when code + value bits fit in them:
   // (value << 8) | (run << 4) | total bits; 0 = take the two-step path
-  int16_t fast_ac[1024];
+  static constexpr int FAST = 10;  // (12: slower — the tables stop fitting beside the data in L1)
+  int16_t fast_ac[1 << FAST];
   void build_fast_ac() {
-    for (int i = 0; i < 1024; ++i) {
+    for (int i = 0; i < (1 << FAST); ++i) {
       fast_ac[i] = 0;
-      const uint16_t lk = look[i >> 1];
+      const uint16_t lk = look[i >> (FAST - 9)];
       if (!lk) continue;
       const int len = lk >> 8, rs = lk & 255, run = rs >> 4, sz = rs & 15;
-      if (sz == 0 || len + sz > 10) continue;
-      int v = ((i << len) & 1023) >> (10 - sz);
+      if (sz == 0 || len + sz > FAST) continue;
+      int v = ((i << len) & ((1 << FAST) - 1)) >> (FAST - sz);
       if (v < (1 << (sz - 1))) v += 1 - (1 << sz);  // EXTEND
       if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)((v * 256) + (run * 16) + (len + sz));
     }
@@ -267,7 +268,7 @@ inline int decode(Bits& b, const Huff& h) {
   return h.vals[(code + h.valoff[l]) & 255];
 }
 
-// one image's scan -> coefficient planes (already zeroed)
+// one image's scan -> coefficient planes (every block of every plane is written: zeroed, then its non-zero coefficients)
 bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
   Bits b;
   b.p = p.file.data() + p.scan;
@@ -298,6 +299,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
         for (int by = 0; by < m.vs[c]; ++by) {
           for (int bx = 0; bx < m.hs[c]; ++bx) {
             int16_t* blk = plane[c] + ((size_t)(y * m.vs[c] + by) * m.wb[c] + (x * m.hs[c] + bx)) * 64;
+            memset(blk, 0, 128);  // (here, not as a pass over the whole plane: the block is written while it is in L1)
             if (b.cnt < 32) b.fill();
             int s = decode(b, hd);
             if (s < 0 || s > 11) return false;
@@ -308,7 +310,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
               if (b.cnt < 32) b.fill();
-              const int fa = ha.fast_ac[b.peek(10)];
+              const int fa = ha.fast_ac[b.peek(Huff::FAST)];
               if (fa) {  // code and value in one look-up
                 k += (fa >> 4) & 15;
                 if (k > 63) return false;
@@ -373,7 +375,6 @@ extern "C" int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void
   parallel([&](int i) {
     mcm_jpeg_image& m = meta[i];
     if (m.status) return;
-    for (int c = 0; c < m.ncomp; ++c) memset((uint8_t*)dst + m.coef_off[c], 0, (size_t)m.wb[c] * m.hb[c] * 128);
     if (!entropy(parsed[(size_t)i], m, (uint8_t*)dst)) m.status = 2;
   });
   return MCM_OK;

@@ -168,3 +168,18 @@ def test_resize_kernel_keeps_lds_address_space_and_avoids_the_packed_shift(prepr
     # nothing in the LDS form multiplies on the quarter-rate 32-bit multiplier: the only v_mul_lo_u32 left are the fused
     # form's taps and index arithmetic
     assert body.count("v_mul_u32_u24") + body.count("v_mad_u32_u24") > 100
+
+
+def test_jpeg_kernels_have_no_scratch_and_no_packed_shift(tmp_path_factory):
+    """jpeg.hip: the IDCT kernel keeps its 64 values in registers (a dynamic index into the by-value image record once sent
+    it to scratch) and neither kernel may contain v_ashr_pk_u8_i32 (the (shift, clamp) pair hipcc fuses into it is exactly
+    what both kernels end with; on the MI355X its upper half is not zero, preprocess.hip)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa_j")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "mcm_amd", "csrc"),
+           "-c", os.path.join(ROOT, "mcm_amd", "csrc", "jpeg.hip"), "-o", str(out / "jpeg.o"), "-save-temps=obj"]
+    subprocess.run(cmd, check=True, cwd=str(out), capture_output=True, timeout=600)
+    isa = open(out / [f for f in os.listdir(out) if f.endswith("gfx950.s")][0]).read()
+    assert "v_ashr_pk" not in isa and "scratch_" not in isa
+    assert isa.count(".private_segment_fixed_size: 0") == 2   # both kernels
