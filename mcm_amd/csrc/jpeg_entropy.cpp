@@ -86,6 +86,7 @@ struct Parsed {
 };
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+constexpr int SANE = 4095;  // |dequantised coefficient| of anything a JPEG encoder produces from 8-bit samples
 
 // markers up to and including SOS; fills m (status 0 / 1 / 2) and p
 void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
@@ -154,6 +155,7 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
       m.width = rd16(s + 3);
       m.ncomp = s[5];
       if (prec != 8 || (m.ncomp != 1 && m.ncomp != 3) || m.width <= 0 || m.height <= 0) { m.status = 1; return; }
+      if ((int64_t)m.width * m.height > ((int64_t)64 << 20)) { m.status = 1; return; }  // (left to the fallback's own size policy)
       if (sl < 6 + 3 * m.ncomp) return;
       for (int c = 0; c < m.ncomp; ++c) {
         cid[c] = s[6 + 3 * c];
@@ -210,6 +212,7 @@ struct Bits {
   const uint8_t* end;
   uint64_t acc = 0;  // the next bits, top-aligned
   int cnt = 0;       // valid bits in acc
+  int pad = 0;       // ... of which this many, at the end, are zeros fed after a marker / the end of the data
   bool marker = false;  // a marker (or the end) was reached: zeros are fed from here on
   // after fill(): cnt > 32 — enough for one Huffman code (<= 16 bits) and its value bits (<= 15), so a symbol needs one check
   inline void fill() {
@@ -240,9 +243,17 @@ struct Bits {
       } else {
         marker = true;
       }
+      if (marker) pad += 8;
       acc |= (uint64_t)b << (56 - cnt);
       cnt += 8;
     }
+  }
+  // The segment just decoded ended cleanly: no fed zero was consumed, fewer than eight real bits (the padding of the last
+  // byte) are left, and the marker `mk` follows at once.  Anything else — premature end, extraneous bytes, a different
+  // marker — is libjpeg's warning-and-recovery territory, whose output this decoder does not reproduce: not taken.
+  inline bool clean_end(int mk) const {
+    if (cnt < pad || cnt - pad >= 8) return false;
+    return p + 1 < end && p[0] == 0xFF && p[1] == mk;
   }
   inline uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
   inline void drop(int n) { acc <<= n; cnt -= n; }
@@ -281,14 +292,12 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
   for (int y = 0; y < my; ++y) {
     for (int x = 0; x < mx; ++x) {
       if (p.restart && until_restart == 0) {
-        // byte-align, expect RSTn
+        if (!b.clean_end(0xD0 + next_rst)) return false;  // the expected RSTn, byte-aligned, nothing in between
+        b.p += 2;
         b.acc = 0;
         b.cnt = 0;
+        b.pad = 0;
         b.marker = false;
-        const uint8_t* q = b.p;
-        while (q + 1 < b.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;  // (skips any padding in front of it)
-        if (q + 1 >= b.end || q[1] != 0xD0 + next_rst) return false;
-        b.p = q + 2;
         next_rst = (next_rst + 1) & 7;
         until_restart = p.restart;
         pred[0] = pred[1] = pred[2] = 0;
@@ -296,6 +305,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
       for (int c = 0; c < m.ncomp; ++c) {
         const Huff& hd = p.dc[p.cdc[c]];
         const Huff& ha = p.ac[p.cac[c]];
+        const uint16_t* qt = p.q[p.cq[c]];
         for (int by = 0; by < m.vs[c]; ++by) {
           for (int bx = 0; bx < m.hs[c]; ++bx) {
             int16_t* blk = plane[c] + ((size_t)(y * m.vs[c] + by) * m.wb[c] + (x * m.hs[c] + bx)) * 64;
@@ -307,6 +317,10 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
               pred[c] += extend((int)b.peek(s), s);
               b.drop(s);
             }
+            // A dequantised coefficient of an 8-bit image stays below ~1200 (DC: 8 x 128 + rounding).  Beyond SANE the data
+            // is damaged, and what libjpeg-turbo's 16-bit SIMD arithmetic makes of it is not what exact arithmetic
+            // makes of it: not taken (the fallback decoder decides).
+            if (pred[c] * (int)qt[0] > SANE || pred[c] * (int)qt[0] < -SANE) return false;
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
               if (b.cnt < 32) b.fill();
@@ -315,7 +329,9 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
                 k += (fa >> 4) & 15;
                 if (k > 63) return false;
                 b.drop(fa & 15);
-                blk[ZIGZAG[k++]] = (int16_t)(fa >> 8);
+                const int v = fa >> 8, z = ZIGZAG[k++];
+                if (v * (int)qt[z] > SANE || v * (int)qt[z] < -SANE) return false;
+                blk[z] = (int16_t)v;
                 continue;
               }
               const int rs = decode(b, ha);
@@ -325,7 +341,9 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
               if (s) {
                 k += r;
                 if (k > 63) return false;
-                blk[ZIGZAG[k]] = (int16_t)extend((int)b.peek(s), s);
+                const int v = extend((int)b.peek(s), s), z = ZIGZAG[k];
+                if (v * (int)qt[z] > SANE || v * (int)qt[z] < -SANE) return false;
+                blk[z] = (int16_t)v;
                 b.drop(s);
                 ++k;
               } else if (r == 15) {
@@ -340,7 +358,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
       if (p.restart) --until_restart;
     }
   }
-  return true;
+  return b.clean_end(0xD9);  // EOI right behind the last MCU
 }
 
 }  // namespace

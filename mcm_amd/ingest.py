@@ -273,6 +273,7 @@ class JpegFilePipe:
 
         lib = self.net._lib
         try:
+            torch.cuda.set_device(self.device)  # (this thread pins memory when a slot grows: on the scorer's device)
             for i, paths in enumerate(batches):
                 n = len(paths)
                 if n > self.max_batch:
