@@ -203,7 +203,9 @@ int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, const int64_t*
  * `Image.open(path).convert("RGB")` (torchvision ImageFolder, utils/train_eval_util.py:96-146) that is bit-serial; the
  * device half (mcm_jpeg_reconstruct) turns the coefficients into the RGB pixels libjpeg would have produced.
  * meta[i].status: 0 taken; 1 a JPEG this path does not take (progressive, arithmetic, 12-bit, CMYK / RGB-coded, several
- * scans, sampling other than 4:4:4 / 4:2:2 / 4:2:0): decode it with the fallback decoder; 2 unreadable or corrupt.
+ * scans, sampling other than 4:4:4 / 4:2:2 / 4:2:0): decode it with the fallback decoder; 2 unreadable, corrupt, or merely
+ * suspicious — a scan is taken only if every RSTn and the EOI sit exactly where a clean scan has them and every dequantised
+ * coefficient is plausible for 8-bit samples; libjpeg's warn-and-recover output for anything else is the fallback's to give.
  * Component c of image i: int16 [hb][wb][64] coefficients in natural order at dst + coef_off[c]; its quantisation table at
  * quant[(i * 3 + c) * 64].  *bytes_used = bytes of dst the batch needs; MCM_ERANGE (nothing decoded) when dst_bytes is less. */
 typedef struct mcm_jpeg_image {

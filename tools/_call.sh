@@ -1,20 +1,14 @@
 #!/bin/bash
-# scratch driver (round 4, call 46): colour kernel with dword stores — tests + kernel trace of the JPEG ingest leg
-mkdir -p gpurun_out/r4c46
-timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_gpu_ingest.py -x -q -m gpu 2>&1 | tail -3
-out=$PWD/gpurun_out/prof_r04_v_jpeg; mkdir -p $out
-root=$PWD
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python $root/bench.py --steps 6 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 --no-profile --ingest host-jpeg --no-arms --no-live-traffic > $out/trace.log 2>&1
-cd $root
-tr=$(find $out/trace \( -name "*_results.db" -o -name "*kernel_stats.csv" \) | head -1)
-case "$tr" in
-  *.db) python tools/rocpd_summary.py $tr > $out/kernel_stats.txt ;;
-  *.csv) cp $tr $out/kernel_stats.txt ;;
-esac
-grep -i "jpeg\|resize\|kernel  " $out/kernel_stats.txt | head
-tail -1 $out/trace.log | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print({k: round(v.get('images_per_sec',-1)) for k,v in d['ingest'].items()})"
+# scratch driver (round 4, call 47): whole GPU suite + smoke + default bench on the tree with the JPEG device route
+mkdir -p gpurun_out/r4c47
+O=$PWD/gpurun_out/r4c47
+timeout 1800 python -m pytest tests -q -m gpu --durations=6 > $O/pytest.txt 2>&1; tail -12 $O/pytest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -2 $O/bench_default.err
+python - <<PY
+import json
+d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+print("value", round(d["value"]), "ingest", {k: round(v.get("images_per_sec", -1)) for k, v in d["ingest"].items()}, d.get("leg_seconds"), "frac", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
+c=d["cpu_baseline"]; print("cpu", c.get("value"), c.get("cores"))
+print("meets", d["parity"].get("meets_1e-4"), "arms", {k: round(v.get("images_per_sec", -1)) for k, v in d["arms"].items()})
+PY
