@@ -171,9 +171,8 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
     } else if (mk == 0xDD) {
       if (sl < 2) return;
       p.restart = rd16(s);
-    } else if (mk == 0xEE) {  // Adobe: a colour transform other than YCbCr for 3 components is not this path's
-      if (sl >= 12 && !memcmp(s, "Adobe", 5) && m.ncomp != 1 && s[11] != 1) { m.status = 1; return; }
-      if (sl >= 12 && !memcmp(s, "Adobe", 5) && !sof && s[11] != 1) { m.status = 1; return; }
+    } else if (mk == 0xEE) {  // Adobe: libjpeg reads the colour transform from it — anything but "YCbCr" goes to the fallback
+      if (sl >= 12 && !memcmp(s, "Adobe", 5) && s[11] != 1) { m.status = 1; return; }
     } else if (mk == 0xDA) {  // SOS
       if (!sof) return;
       if (sl < 1 || s[0] != m.ncomp || sl < 1 + 2 * m.ncomp + 3) { m.status = 1; return; }  // not one interleaved scan
