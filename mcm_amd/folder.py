@@ -117,6 +117,9 @@ class ImageFolderU8:
         import torch
 
         paths = [self.dataset.samples[int(i)][0] for i in indices]
+        if os.environ.get("MCM_GPU_JPEG", "1") != "0" and len(paths) >= 8:  # the default route, as in __iter__
+            out = [b.clone() for b in self._jpeg_stream(paths[k:k + self.batch_size] for k in range(0, len(paths), self.batch_size))]
+            return out[0] if len(out) == 1 else torch.cat(out)
         if self.workers <= 1 or len(paths) < 32:
             imgs = [np.array(_decode_rgb(p)) for p in paths]  # (np.array: writable — torch warns about read-only arrays)
         else:
@@ -161,15 +164,11 @@ class ImageFolderU8:
         finally:  # also when the consumer stops in the middle of a pass (generator closed): what is in flight is waited out
             _release_pool(pool)
 
-    def _iter_jpeg(self) -> Iterator:
-        """Files → native entropy decode into pinned memory → coefficients over PCIe → inverse DCT, upsampling, colour, Resize
-        + CenterCrop on the device (mcm_amd.ingest.JpegFilePipe); anything that is not a baseline JPEG takes Pillow inside it."""
-        import torch
-
+    def _jpeg_stream(self, path_batches) -> Iterator:
+        """uint8 [b,S,S,3] device batches for batches of file names through the scorer's JpegFilePipe (kept on the scorer across
+        passes and loaders; a second one is made when it is in use)."""
         from .ingest import JpegFilePipe
 
-        starts = list(range(self.lo, self.hi, self.batch_size))
-        chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
         pipes = self.net.__dict__.setdefault("_jpeg_pipes", {})
         pipe = pipes.get(self.batch_size)
         if pipe is None or pipe.busy:
@@ -177,10 +176,19 @@ class ImageFolderU8:
             pipes.setdefault(self.batch_size, pipe)
         pipe.busy = True
         try:
-            for i, dev_batch in enumerate(pipe.stream([p for p, _ in chunk_of(s)] for s in starts)):
-                yield dev_batch, torch.tensor([t for _, t in chunk_of(starts[i])], dtype=torch.long)
+            yield from pipe.stream(path_batches)
         finally:
             pipe.busy = False
+
+    def _iter_jpeg(self) -> Iterator:
+        """Files → native entropy decode into pinned memory → coefficients over PCIe → inverse DCT, upsampling, colour, Resize
+        + CenterCrop on the device (mcm_amd.ingest.JpegFilePipe); anything that is not a baseline JPEG takes Pillow inside it."""
+        import torch
+
+        starts = list(range(self.lo, self.hi, self.batch_size))
+        chunk_of = lambda s: self.dataset.samples[s:min(s + self.batch_size, self.hi)]  # noqa: E731
+        for i, dev_batch in enumerate(self._jpeg_stream([p for p, _ in chunk_of(s)] for s in starts)):
+            yield dev_batch, torch.tensor([t for _, t in chunk_of(starts[i])], dtype=torch.long)
 
     def __iter__(self) -> Iterator:
         """Default (MCM_GPU_JPEG unset or 1): `_iter_jpeg`.  MCM_GPU_JPEG=0: decode pool (Pillow in worker processes) → ONE
