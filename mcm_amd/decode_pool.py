@@ -191,5 +191,30 @@ class DecodePool:
         return out
 
 
+# One pool per (workers, batch) serves every loader of the process: the CLI walks five datasets one after the other, and
+# starting the workers per dataset cost more than scoring the smaller sets.  A caller that finds the shared pool in use makes
+# its own (closed on release).
+_POOLS: dict = {}
+
+
+def lease_pool(workers: int, batch: int) -> DecodePool:
+    p = _POOLS.get((workers, batch))
+    if p is None or not p.alive():
+        p = _POOLS[(workers, batch)] = DecodePool(workers, batch)
+    if p.busy:
+        p = DecodePool(workers, batch)
+        p.private = True
+    p.busy = True
+    p.drain()
+    return p
+
+
+def release_pool(p: DecodePool):
+    p.drain()
+    p.busy = False
+    if getattr(p, "private", False):
+        p.close()
+
+
 if __name__ == "__main__":
     _worker_main(sys.argv[1:])

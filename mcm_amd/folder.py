@@ -53,32 +53,7 @@ class FolderIndex:
         return sub
 
 
-from .decode_pool import DecodePool, decode_rgb as _decode_rgb  # noqa: E402,F401
-
-
-# One decode pool per (workers, batch) and one packed pipe per (scorer, batch) serve every loader of the process: the CLI walks
-# five datasets one after the other, and starting 16 processes + pinning three 200-MB buffers per dataset cost more than
-# scoring the smaller sets.  A loader that finds the shared object in use (two loaders iterated at once) makes its own.
-_POOLS: dict = {}
-
-
-def _lease_pool(workers: int, batch: int) -> DecodePool:
-    p = _POOLS.get((workers, batch))
-    if p is None or not p.alive():
-        p = _POOLS[(workers, batch)] = DecodePool(workers, batch)
-    if p.busy:
-        p = DecodePool(workers, batch)
-        p.private = True
-    p.busy = True
-    p.drain()
-    return p
-
-
-def _release_pool(p: DecodePool):
-    p.drain()
-    p.busy = False
-    if getattr(p, "private", False):
-        p.close()
+from .decode_pool import DecodePool, decode_rgb as _decode_rgb, lease_pool as _lease_pool, release_pool as _release_pool  # noqa: E402,F401
 
 
 class ImageFolderU8:

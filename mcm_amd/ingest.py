@@ -292,7 +292,18 @@ class JpegFilePipe:
                     if rc != -7 or used.value <= s.host.numel():  # MCM_ERANGE = the slot is too small: grow and retry
                         raise RuntimeError(f"mcm_jpeg_entropy_decode rc={rc}")
                     s.host = torch.empty(int(used.value * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
-                fallbacks = {j: decode_rgb(paths[j]) for j in range(n) if s.meta[j].status != 0}
+                fb = [j for j in range(n) if s.meta[j].status != 0]
+                if len(fb) >= 4 and self.threads > 1:  # several files for Pillow (progressive JPEGs, PNGs): its worker processes
+                    from .decode_pool import lease_pool, release_pool
+
+                    pool = lease_pool(min(self.threads, 16), self.max_batch)
+                    try:
+                        pool.submit(0, [paths[j] for j in fb])
+                        fallbacks = {j: a.copy() for j, a in zip(fb, pool.collect(0))}
+                    finally:
+                        release_pool(pool)
+                else:
+                    fallbacks = {j: decode_rgb(paths[j]) for j in fb}
                 item = (i, s, n, int(used.value), fallbacks)
                 while not stop.is_set():
                     try:
