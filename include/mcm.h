@@ -202,8 +202,9 @@ int mcm_pack_u8(const uint8_t* const* srcs, const int64_t* sizes, const int64_t*
  * `threads` native threads into dst (the pinned buffer a batch is uploaded from) — the part of the reference loader's
  * `Image.open(path).convert("RGB")` (torchvision ImageFolder, utils/train_eval_util.py:96-146) that is bit-serial; the
  * device half (mcm_jpeg_reconstruct) turns the coefficients into the RGB pixels libjpeg would have produced.
- * meta[i].status: 0 taken; 1 a JPEG this path does not take (progressive, arithmetic, 12-bit, CMYK / RGB-coded, several
- * scans, sampling other than 4:4:4 / 4:2:2 / 4:2:0): decode it with the fallback decoder; 2 unreadable, corrupt, or merely
+ * Baseline / extended-sequential and progressive Huffman JPEGs are taken.
+ * meta[i].status: 0 taken; 1 a JPEG this path does not take (arithmetic, 12-bit, CMYK / RGB-coded, sequential multi-scan,
+ * sampling other than 4:4:4 / 4:2:2 / 4:2:0): decode it with the fallback decoder; 2 unreadable, corrupt, or merely
  * suspicious — a scan is taken only if every RSTn and the EOI sit exactly where a clean scan has them and every dequantised
  * coefficient is plausible for 8-bit samples; libjpeg's warn-and-recover output for anything else is the fallback's to give.
  * Component c of image i: int16 [hb][wb][64] coefficients in natural order at dst + coef_off[c]; its quantisation table at

@@ -9,11 +9,14 @@
 // threads — no Pillow, no GIL, no worker processes, no host-side pixels at all.  The coefficients cross PCIe in place of
 // the pixels (same size: 1.5 int16 per pixel for 4:2:0 against 3 bytes).
 //
-// Taken: baseline / extended-sequential 8-bit Huffman JPEGs (SOF0, SOF1), one interleaved scan, grayscale or YCbCr with
-// chroma 1x1 and luma 1x1 / 2x1 / 2x2 (4:4:4, 4:2:2, 4:2:0), restart intervals.  Everything else (progressive, arithmetic,
-// 12-bit, CMYK / RGB-coded files, multi-scan) is reported as status 1 and left to the caller's fallback decoder.
+// Taken: 8-bit Huffman JPEGs — baseline / extended-sequential (SOF0, SOF1; one interleaved scan) and progressive (SOF2;
+// spectral selection + successive approximation, any legal scan script) — grayscale or YCbCr with chroma 1x1 and luma
+// 1x1 / 2x1 / 2x2 (4:4:4, 4:2:2, 4:2:0), restart intervals.  Everything else (arithmetic coding, 12-bit, CMYK / RGB-coded
+// files, sequential multi-scan, other samplings) and every file that shows ANY irregularity (a scan that does not end exactly
+// where a clean one ends, implausible coefficients, a progression with gaps) is reported as not taken and left to the
+// caller's fallback decoder, so that libjpeg's warn-and-recover behaviour on such files stays libjpeg's.
 // The third-party algorithm restated here is the JPEG standard's (ITU T.81 Annex F.2: DECODE, RECEIVE, EXTEND; F.1.2.1.1
-// DC prediction; E.2 restart) — the bit-exact parts that depend on libjpeg's arithmetic are all on the device side.
+// DC prediction; E.2 restart; Annex G progressive scans) — the bit-exact parts that depend on libjpeg's arithmetic are all on the device side.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -82,11 +85,47 @@ struct Parsed {
   bool qset[4] = {false, false, false, false};
   Huff dc[4], ac[4];
   int cq[3], cdc[3], cac[3];
+  int cid[3] = {0, 0, 0};
   int restart = 0;
+  bool progressive = false;
+  size_t first_sos = 0;  // progressive: offset of the first SOS segment's length field
 };
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 constexpr int SANE = 4095;  // |dequantised coefficient| of anything a JPEG encoder produces from 8-bit samples
+
+bool parse_dqt(Parsed& p, const uint8_t* s, int sl) {
+  int o = 0;
+  while (o < sl) {
+    const int pq = s[o] >> 4, tq = s[o] & 15;
+    ++o;
+    if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) return false;
+    for (int k = 0; k < 64; ++k) p.q[tq][ZIGZAG[k]] = pq ? (uint16_t)rd16(s + o + 2 * k) : s[o + k];
+    p.qset[tq] = true;
+    o += pq ? 128 : 64;
+  }
+  return true;
+}
+
+bool parse_dht(Parsed& p, const uint8_t* s, int sl) {
+  int o = 0;
+  while (o < sl) {
+    if (o + 17 > sl) return false;
+    const int tc = s[o] >> 4, th = s[o] & 15;
+    if (tc > 1 || th > 3) return false;
+    Huff& h = tc ? p.ac[th] : p.dc[th];
+    int cnt = 0;
+    h.bits[0] = 0;
+    for (int l = 1; l <= 16; ++l) cnt += (h.bits[l] = s[o + l]);
+    if (cnt > 256 || o + 17 + cnt > sl) return false;
+    memcpy(h.vals, s + o + 17, (size_t)cnt);
+    if (!h.build()) return false;
+    if (tc) h.build_fast_ac();
+    h.set = true;
+    o += 17 + cnt;
+  }
+  return true;
+}
 
 // markers up to and including SOS; fills m (status 0 / 1 / 2) and p
 void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
@@ -119,37 +158,13 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
     if (len < 2 || pos + len > (size_t)n) return;
     const uint8_t* s = d + pos + 2;
     const int sl = len - 2;
-    if (mk == 0xDB) {  // DQT
-      int o = 0;
-      while (o < sl) {
-        const int pq = s[o] >> 4, tq = s[o] & 15;
-        ++o;
-        if (tq > 3 || o + (pq ? 128 : 64) > sl) return;
-        for (int k = 0; k < 64; ++k) {
-          p.q[tq][ZIGZAG[k]] = pq ? (uint16_t)rd16(s + o + 2 * k) : s[o + k];
-        }
-        p.qset[tq] = true;
-        o += pq ? 128 : 64;
-      }
-    } else if (mk == 0xC4) {  // DHT
-      int o = 0;
-      while (o < sl) {
-        if (o + 17 > sl) return;
-        const int tc = s[o] >> 4, th = s[o] & 15;
-        if (tc > 1 || th > 3) return;
-        Huff& h = tc ? p.ac[th] : p.dc[th];
-        int cnt = 0;
-        h.bits[0] = 0;
-        for (int l = 1; l <= 16; ++l) cnt += (h.bits[l] = s[o + l]);
-        if (cnt > 256 || o + 17 + cnt > sl) return;
-        memcpy(h.vals, s + o + 17, (size_t)cnt);
-        if (!h.build()) return;
-        if (tc) h.build_fast_ac();
-        h.set = true;
-        o += 17 + cnt;
-      }
-    } else if (mk == 0xC0 || mk == 0xC1) {  // SOF0 / SOF1
+    if (mk == 0xDB) {
+      if (!parse_dqt(p, s, sl)) return;
+    } else if (mk == 0xC4) {
+      if (!parse_dht(p, s, sl)) return;
+    } else if (mk == 0xC0 || mk == 0xC1 || mk == 0xC2) {  // SOF0 / SOF1 / SOF2 (progressive)
       if (sl < 6 || sof) return;
+      p.progressive = mk == 0xC2;
       const int prec = s[0];
       m.height = rd16(s + 1);
       m.width = rd16(s + 3);
@@ -158,15 +173,15 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
       if ((int64_t)m.width * m.height > ((int64_t)64 << 20)) { m.status = 1; return; }  // (left to the fallback's own size policy)
       if (sl < 6 + 3 * m.ncomp) return;
       for (int c = 0; c < m.ncomp; ++c) {
-        cid[c] = s[6 + 3 * c];
+        cid[c] = p.cid[c] = s[6 + 3 * c];
         m.hs[c] = s[7 + 3 * c] >> 4;
         m.vs[c] = s[7 + 3 * c] & 15;
         p.cq[c] = s[8 + 3 * c];
         if (p.cq[c] > 3) return;
       }
       sof = true;
-    } else if (mk >= 0xC2 && mk <= 0xCF && mk != 0xC4 && mk != 0xC8 && mk != 0xCC) {
-      m.status = 1;  // progressive / lossless / arithmetic
+    } else if (mk >= 0xC3 && mk <= 0xCF && mk != 0xC4 && mk != 0xC8 && mk != 0xCC) {
+      m.status = 1;  // lossless / arithmetic / hierarchical
       return;
     } else if (mk == 0xDD) {
       if (sl < 2) return;
@@ -175,6 +190,11 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
       if (sl >= 12 && !memcmp(s, "Adobe", 5) && s[11] != 1) { m.status = 1; return; }
     } else if (mk == 0xDA) {  // SOS
       if (!sof) return;
+      if (p.progressive) {
+        for (int c = 0; c < m.ncomp; ++c)
+          if (!p.qset[p.cq[c]]) { m.status = 1; return; }  // (quantisation tables are latched at the first scan here)
+        p.first_sos = pos;
+      } else {
       if (sl < 1 || s[0] != m.ncomp || sl < 1 + 2 * m.ncomp + 3) { m.status = 1; return; }  // not one interleaved scan
       for (int c = 0; c < m.ncomp; ++c) {
         if (s[1 + 2 * c] != cid[c]) { m.status = 1; return; }
@@ -183,6 +203,7 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
         if (p.cdc[c] > 3 || p.cac[c] > 3 || !p.dc[p.cdc[c]].set || !p.ac[p.cac[c]].set || !p.qset[p.cq[c]]) return;
       }
       p.scan = pos + len;
+      }
       // geometry this path takes
       if (m.ncomp == 1) {
         m.hs[0] = m.vs[0] = 1;
@@ -360,6 +381,232 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
   return b.clean_end(0xD9);  // EOI right behind the last MCU
 }
 
+// ---- progressive (SOF2): T.81 Annex G.  Several scans refine the same coefficient planes — DC first / DC refinement over
+// (possibly interleaved) MCUs, AC first / AC refinement over one component's own block raster with end-of-band runs; what
+// comes out after the last scan is the coefficient array a sequential file would have carried, and libjpeg reconstructs it
+// the same way (its inter-block smoothing only applies while coefficients are still incomplete: a file is taken only if
+// every coefficient of every component reached its last bit, in a progression without gaps).
+struct BitsP : Bits {
+  inline int bit() {
+    if (cnt < 1) fill();
+    const int v = (int)(acc >> 63);
+    drop(1);
+    return v;
+  }
+  inline int bits(int n) {  // n <= 16
+    if (cnt < n) fill();
+    const int v = (int)peek(n);
+    drop(n);
+    return v;
+  }
+  // any marker but RSTn, right behind a cleanly ended scan
+  inline bool clean_scan_end() const {
+    if (cnt < pad || cnt - pad >= 8) return false;
+    return p + 1 < end && p[0] == 0xFF && p[1] != 0 && !(p[1] >= 0xD0 && p[1] <= 0xD7);
+  }
+};
+
+bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
+  const uint8_t* d = p.file.data();
+  const size_t n = p.file.size() - 8;
+  int16_t* plane[3];
+  for (int c = 0; c < m.ncomp; ++c) {
+    plane[c] = (int16_t*)(dst + m.coef_off[c]);
+    memset(plane[c], 0, (size_t)m.wb[c] * m.hb[c] * 128);
+  }
+  // successive-approximation state per coefficient: -1 = not seen yet, else the Al of its last scan
+  int8_t al_of[3][64];
+  memset(al_of, -1, sizeof al_of);
+  const int hmax = m.hs[0], vmax = m.vs[0];  // (luma carries the largest factors in everything this path takes)
+  size_t pos = p.first_sos;
+  for (int nscan = 0; nscan < 1000; ++nscan) {
+    if (pos + 2 > n) return false;
+    const int len = rd16(d + pos);
+    if (len < 8 || pos + len > n) return false;
+    const uint8_t* s = d + pos + 2;
+    const int ns = s[0];
+    if (ns < 1 || ns > m.ncomp || len != 6 + 2 * ns) return false;
+    int ci[3], td[3], ta[3];
+    for (int i = 0; i < ns; ++i) {
+      ci[i] = -1;
+      for (int c = 0; c < m.ncomp; ++c)
+        if (p.cid[c] == s[1 + 2 * i]) ci[i] = c;
+      if (ci[i] < 0 || (i && ci[i] <= ci[i - 1])) return false;
+      td[i] = s[2 + 2 * i] >> 4;
+      ta[i] = s[2 + 2 * i] & 15;
+      if (td[i] > 3 || ta[i] > 3) return false;
+    }
+    const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+    if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah && Ah != Al + 1)) return false;
+    for (int i = 0; i < ns; ++i) {
+      for (int k = Ss; k <= Se; ++k) {  // a progression without gaps: first scans first, then one bit at a time
+        int8_t& prev = al_of[ci[i]][k];
+        if (Ah == 0 ? prev != -1 : prev != Ah) return false;
+        prev = (int8_t)Al;
+      }
+      if (Ss == 0 ? (Ah == 0 && !p.dc[td[i]].set) : !p.ac[ta[i]].set) return false;
+    }
+    BitsP b;
+    b.p = d + pos + len;
+    b.end = d + n;
+    int pred[3] = {0, 0, 0}, eobrun = 0, until_restart = p.restart, next_rst = 0;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto restart_if_due = [&]() -> bool {
+      if (!p.restart || until_restart) return true;
+      if (!b.clean_end(0xD0 + next_rst)) return false;
+      b.p += 2;
+      b.acc = 0; b.cnt = 0; b.pad = 0; b.marker = false;
+      next_rst = (next_rst + 1) & 7;
+      until_restart = p.restart;
+      pred[0] = pred[1] = pred[2] = 0;
+      eobrun = 0;
+      return true;
+    };
+    if (Ss == 0) {  // ---- DC scans
+      const bool inter = ns > 1;
+      const int c0 = ci[0];
+      const int mx = inter ? m.wb[0] / m.hs[0] : (((m.width * m.hs[c0] + hmax - 1) / hmax) + 7) / 8;
+      const int my = inter ? m.hb[0] / m.vs[0] : (((m.height * m.vs[c0] + vmax - 1) / vmax) + 7) / 8;
+      for (int y = 0; y < my; ++y)
+        for (int x = 0; x < mx; ++x) {
+          if (!restart_if_due()) return false;
+          for (int i = 0; i < ns; ++i) {
+            const int c = ci[i], nh = inter ? m.hs[c] : 1, nv = inter ? m.vs[c] : 1;
+            for (int by = 0; by < nv; ++by)
+              for (int bx = 0; bx < nh; ++bx) {
+                int16_t* blk = plane[c] + ((size_t)(y * nv + by) * m.wb[c] + (x * nh + bx)) * 64;
+                if (Ah == 0) {
+                  if (b.cnt < 32) b.fill();
+                  const int sz = decode(b, p.dc[td[i]]);
+                  if (sz < 0 || sz > 11) return false;
+                  if (sz) {
+                    pred[c] += extend((int)b.peek(sz), sz);
+                    b.drop(sz);
+                  }
+                  const int v = pred[c] * p1;
+                  if (v > 32767 || v < -32768) return false;
+                  blk[0] = (int16_t)v;
+                } else if (b.bit()) {
+                  blk[0] |= (int16_t)p1;
+                }
+              }
+          }
+          if (p.restart) --until_restart;
+        }
+    } else {  // ---- AC scans: one component, its own block raster (not padded to whole MCUs)
+      const int c = ci[0];
+      const Huff& ha = p.ac[ta[0]];
+      const int bw = (((m.width * m.hs[c] + hmax - 1) / hmax) + 7) / 8, bh = (((m.height * m.vs[c] + vmax - 1) / vmax) + 7) / 8;
+      for (int y = 0; y < bh; ++y)
+        for (int x = 0; x < bw; ++x) {
+          if (!restart_if_due()) return false;
+          int16_t* blk = plane[c] + ((size_t)y * m.wb[c] + x) * 64;
+          if (Ah == 0) {  // G.1.2.2: first scan of the band
+            if (eobrun > 0) {
+              --eobrun;
+            } else {
+              for (int k = Ss; k <= Se; ++k) {
+                if (b.cnt < 32) b.fill();
+                const int rs = decode(b, ha);
+                if (rs < 0) return false;
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz) {
+                  k += r;
+                  if (k > Se) return false;
+                  const int v = extend((int)b.peek(sz), sz) * p1;
+                  b.drop(sz);
+                  if (v > 32767 || v < -32768) return false;
+                  blk[ZIGZAG[k]] = (int16_t)v;
+                } else if (r == 15) {
+                  k += 15;
+                } else {
+                  eobrun = 1 << r;
+                  if (r) eobrun += b.bits(r);
+                  --eobrun;
+                  break;
+                }
+              }
+            }
+          } else {  // G.1.2.3: refinement — new +-1s between correction bits of the coefficients that are already non-zero
+            int k = Ss;
+            if (eobrun == 0) {
+              for (; k <= Se; ++k) {
+                if (b.cnt < 32) b.fill();
+                const int rs = decode(b, ha);
+                if (rs < 0) return false;
+                int r = rs >> 4, sz = rs & 15, val = 0;
+                if (sz) {
+                  if (sz != 1) return false;
+                  val = b.bit() ? p1 : m1;
+                } else if (r != 15) {
+                  eobrun = 1 << r;
+                  if (r) eobrun += b.bits(r);
+                  break;
+                }
+                do {
+                  int16_t& co = blk[ZIGZAG[k]];
+                  if (co != 0) {
+                    if (b.bit() && (co & p1) == 0) co = (int16_t)(co >= 0 ? co + p1 : co + m1);
+                  } else if (--r < 0) {
+                    break;
+                  }
+                  ++k;
+                } while (k <= Se);
+                if (val) {
+                  if (k > Se) return false;
+                  blk[ZIGZAG[k]] = (int16_t)val;
+                }
+              }
+            }
+            if (eobrun > 0) {
+              for (; k <= Se; ++k) {
+                int16_t& co = blk[ZIGZAG[k]];
+                if (co != 0 && b.bit() && (co & p1) == 0) co = (int16_t)(co >= 0 ? co + p1 : co + m1);
+              }
+              --eobrun;
+            }
+          }
+          if (p.restart) --until_restart;
+        }
+    }
+    if (!b.clean_scan_end()) return false;
+    // the markers between this scan and the next (tables may change), or EOI
+    pos = (size_t)(b.p - d);
+    for (;;) {
+      if (pos + 2 > n || d[pos] != 0xFF) return false;
+      const int mk = d[pos + 1];
+      pos += 2;
+      if (mk == 0xD9) {  // EOI: complete?
+        for (int c = 0; c < m.ncomp; ++c) {
+          for (int k = 0; k < 64; ++k)
+            if (al_of[c][k] != 0) return false;
+          const uint16_t* qt = p.q[p.cq[c]];
+          const int16_t* co = plane[c];
+          for (size_t i = 0, e = (size_t)m.wb[c] * m.hb[c] * 64; i < e; ++i) {
+            const int v = co[i] * (int)qt[i & 63];
+            if (v > SANE || v < -SANE) return false;
+          }
+        }
+        return true;
+      }
+      if (pos + 2 > n) return false;
+      const int sl = rd16(d + pos);
+      if (sl < 2 || pos + sl > n) return false;
+      if (mk == 0xDA) break;  // the next scan: pos is at its length field
+      if (mk == 0xC4) {
+        if (!parse_dht(p, d + pos + 2, sl - 2)) return false;
+      } else if (mk == 0xDD) {
+        if (sl < 4) return false;
+        p.restart = rd16(d + pos + 2);
+      } else if (!((mk >= 0xE0 && mk <= 0xEF) || mk == 0xFE)) {
+        return false;  // (DQT mid-image, DNL, anything unusual: the fallback's business)
+      }
+      pos += sl;
+    }
+  }
+  return false;
+}
+
 }  // namespace
 
 extern "C" int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void* dst, int64_t dst_bytes,
@@ -392,7 +639,8 @@ extern "C" int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void
   parallel([&](int i) {
     mcm_jpeg_image& m = meta[i];
     if (m.status) return;
-    if (!entropy(parsed[(size_t)i], m, (uint8_t*)dst)) m.status = 2;
+    Parsed& pp = parsed[(size_t)i];
+    if (!(pp.progressive ? entropy_progressive(pp, m, (uint8_t*)dst) : entropy(pp, m, (uint8_t*)dst))) m.status = 2;
   });
   return MCM_OK;
 }

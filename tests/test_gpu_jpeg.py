@@ -42,12 +42,13 @@ def test_device_reconstruction_equals_pillow_on_a_mixed_batch(net, tmp_path):
         p = str(tmp_path / f"g{k}.jpg")
         Image.fromarray(_photo(h, w, k)[:, :, 0]).save(p, quality=88)
         paths.append(p)
-    p = str(tmp_path / "prog.jpg")
-    Image.fromarray(_photo(90, 120, 5)).save(p, quality=90, progressive=True)   # not taken: skipped by the device call
+    p = str(tmp_path / "cmyk.jpg")
+    Image.fromarray(_photo(90, 120, 5)).convert("CMYK").save(p, quality=90)   # not taken: skipped by the device call
     paths.append(p)
     meta, quant, buf = entropy_decode(paths, threads=4)
     n = len(paths)
     want = [_pil(p) for p in paths]
+    assert [m.status for m in meta].count(0) == n - 1 and meta[n - 1].status == 1
     offs, o = [], 0
     for a in want:
         offs.append(o)
@@ -77,11 +78,16 @@ def test_file_pipe_equals_the_pillow_route_with_fallbacks_and_errors(net, tmp_pa
         kw = dict(quality=int(rng.integers(40, 98)), subsampling=int(rng.integers(0, 3)))
         kw["optimize"] = bool(k % 2) and kw["quality"] <= 85   # (Pillow's encoder buffer is too small for optimize at high quality)
         if k % 11 == 0:
-            kw = dict(quality=85, progressive=True)   # Pillow fallback inside the pipe
+            kw = dict(quality=85, progressive=True)   # progressive: taken by the entropy decoder as well
+        if k % 17 == 3:
+            kw = dict(quality=85, cmyk=True)          # CMYK: Pillow fallback inside the pipe
         if k % 13 == 5:
             p = p[:-4] + ".png"                 # not a JPEG at all: Pillow fallback
             kw = {}
-        Image.fromarray(_photo(h, w, 100 + k)).save(p, **kw)
+        im = Image.fromarray(_photo(h, w, 100 + k))
+        if kw.pop("cmyk", False):
+            im = im.convert("CMYK")
+        im.save(p, **kw)
         paths.append(p)
     want = np.stack([orc.resize_crop_u8(_pil(p), 224) for p in paths])
     pipe = JpegFilePipe(net, 32, threads=3)
@@ -89,7 +95,7 @@ def test_file_pipe_equals_the_pillow_route_with_fallbacks_and_errors(net, tmp_pa
         batches = [paths[0:32], paths[32:49], paths[49:70]]
         got = torch.cat([b.clone() for b in pipe.stream(batches)]).cpu().numpy()
         np.testing.assert_array_equal(got, want)
-    assert pipe.fallback_images == 2 * sum(1 for k in range(70) if k % 11 == 0 or k % 13 == 5)
+    assert pipe.fallback_images == 2 * sum(1 for k in range(70) if k % 13 == 5 or k % 17 == 3)
     bad = str(tmp_path / "bad.jpg")
     open(bad, "wb").write(open(paths[1], "rb").read()[:500])
     with pytest.raises(Exception):

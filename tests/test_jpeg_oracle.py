@@ -55,6 +55,11 @@ CASES = [  # (h, w, save kwargs)
     (241, 319, dict(quality=90, subsampling=0)), (241, 319, dict(quality=90, subsampling=1)), (241, 319, dict(quality=90, subsampling=2)),
     (480, 641, dict(quality=100)), (600, 800, dict(quality=20)), (255, 257, dict(quality=85, optimize=True, subsampling=1)),
     (300, 301, dict(quality=90, restart_marker_blocks=7)), (300, 301, dict(quality=90, restart_marker_rows=1, subsampling=0)),
+    # progressive (SOF2): spectral selection + successive approximation, DC / AC first and refinement scans
+    (375, 500, dict(quality=90, progressive=True)), (241, 319, dict(quality=75, progressive=True, subsampling=0)),
+    (241, 319, dict(quality=60, progressive=True, subsampling=1)), (97, 131, dict(quality=95, progressive=True, subsampling=2)),
+    (17, 23, dict(quality=90, progressive=True)), (300, 301, dict(quality=85, progressive=True, restart_marker_blocks=5)),
+    (600, 800, dict(quality=30, progressive=True)),
 ]
 
 
@@ -77,8 +82,8 @@ def test_grayscale_batch_and_files_the_path_does_not_take(tmp_path):
         p = str(tmp_path / f"g{i}.jpg")
         Image.fromarray(_photo(h, w, i)[:, :, 0]).save(p, quality=88)
         paths.append(p)
-    p = str(tmp_path / "prog.jpg")
-    Image.fromarray(_photo(90, 120, 5)).save(p, quality=90, progressive=True)
+    p = str(tmp_path / "prog_gray.jpg")
+    Image.fromarray(_photo(90, 120, 5)[:, :, 1]).save(p, quality=90, progressive=True)
     paths.append(p)
     p = str(tmp_path / "cmyk.jpg")
     Image.fromarray(_photo(90, 120, 6)).convert("CMYK").save(p, quality=90)
@@ -95,8 +100,8 @@ def test_grayscale_batch_and_files_the_path_does_not_take(tmp_path):
     paths.append(q)
     meta, quant, buf = entropy_decode(paths, threads=3)
     # (the truncated file is NOT taken: its scan does not end in EOI — Pillow, the fallback, raises for it as the reference would)
-    assert [m.status for m in meta] == [0, 0, 0, 1, 1, 2, 2, 2, 0], [m.status for m in meta]
-    for i in (0, 1, 2, 8):
+    assert [m.status for m in meta] == [0, 0, 0, 0, 1, 2, 2, 2, 0], [m.status for m in meta]
+    for i in (0, 1, 2, 3, 8):
         with Image.open(paths[i]) as im:
             np.testing.assert_array_equal(reconstruct(meta[i], quant[i], buf), np.asarray(im.convert("RGB")))
 
@@ -108,7 +113,7 @@ def test_damaged_files_never_crash_the_entropy_decoder(tmp_path):
     rng = np.random.default_rng(17)
     good = []
     for k, kw in enumerate([dict(quality=90), dict(quality=60, subsampling=0, optimize=True), dict(quality=85, subsampling=1),
-                            dict(quality=90, restart_marker_blocks=5)]):
+                            dict(quality=90, restart_marker_blocks=5), dict(quality=88, progressive=True)]):
         p = str(tmp_path / f"good{k}.jpg")
         Image.fromarray(_photo(70 + 9 * k, 90 + 7 * k, k)).save(p, **kw)
         good.append(open(p, "rb").read())
