@@ -382,7 +382,7 @@ def ingest_legs(net, txt, B, steps, which):
             try:
                 import io
 
-                nfiles, fbytes = 4 * B, 0
+                nfiles, fbytes = 16 * B, 0   # (a pass of 16 batches: the first batch of a pass pays for the pipe's start)
                 yy, xx = np.mgrid[0:800, 0:800].astype(np.float32)
                 blobs = []
                 for i in range(2 * len(sizes)):  # photograph-like content: smooth structure + texture (noise alone does not compress)
@@ -393,11 +393,13 @@ def ingest_legs(net, txt, B, steps, which):
                     buf = io.BytesIO()
                     Image.fromarray(im).save(buf, format="JPEG", quality=90)
                     blobs.append(buf.getvalue())
-                for i in range(nfiles):
-                    d = os.path.join(root, f"class{i % 8}")
-                    os.makedirs(d, exist_ok=True)
-                    with open(os.path.join(d, f"{i:05d}.jpg"), "wb") as fh:
-                        fh.write(blobs[i % len(blobs)])
+                for c in range(8):
+                    os.makedirs(os.path.join(root, f"class{c}"))
+                for j, blob in enumerate(blobs):
+                    with open(os.path.join(root, f"blob{j}.bin"), "wb") as fh:
+                        fh.write(blob)
+                for i in range(nfiles):  # hard links to the 16 files: a folder of 8 192 entries without 700 MB of writes
+                    os.link(os.path.join(root, f"blob{i % len(blobs)}.bin"), os.path.join(root, f"class{i % 8}", f"{i:05d}.jpg"))
                     fbytes += len(blobs[i % len(blobs)])
                 loader = ImageFolderU8(root, net, B)  # (MCM_DECODE_WORKERS overrides the loader's own choice: its CPU quota)
                 route = ("entropy decode on host threads, inverse DCT + upsampling + colour on the device"
@@ -405,18 +407,21 @@ def ingest_legs(net, txt, B, steps, which):
                 for px, _ in loader:  # warm-up pass: page cache, thread pool, slots
                     net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
                 torch.cuda.synchronize()
-                passes, t0 = 2, time.perf_counter()
+                passes, t0 = 1, time.perf_counter()
                 for _ in range(passes):
                     for px, _ in loader:
                         net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
+                pipe = next(iter(net.__dict__.get("_jpeg_pipes", {}).values()), None)
                 loader.close()
                 out["host_jpeg"] = {"images_per_sec": passes * nfiles / dt, "ms_per_step": 1e3 * dt / (passes * nfiles / B),
                                     "steps": passes * nfiles // B, "decode_workers": loader.workers, "host_cpus": os.cpu_count(),
                                     "cpu_quota_cores": __import__("mcm_amd.hostinfo", fromlist=["cpu_quota"]).cpu_quota(),
                                     "jpeg_bytes_per_image": fbytes / nfiles,
                                     "decoder": route,
+                                    "pipe_seconds_per_batch": ({k: round(v / max(1, pipe.stats["batches"]), 4) for k, v in pipe.stats.items()
+                                                                if k != "batches"} if pipe is not None else None),
                                     "source": f"{nfiles} JPEG files (quality 90, 8 sizes 256x341 ... 600x800) in an image folder, read + "
                                               "decoded by the CLI's loader (see decoder), Resize + CenterCrop + scoring on the device; "
                                               "bound by the host cores this container is given (decode_workers = its CPU quota)"}

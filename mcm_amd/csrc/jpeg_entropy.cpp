@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -89,6 +90,12 @@ struct Parsed {
   int restart = 0;
   bool progressive = false;
   size_t first_sos = 0;  // progressive: offset of the first SOS segment's length field
+  void reset() {  // (records are re-used from call to call: their file buffers keep their capacity)
+    scan = first_sos = 0;
+    restart = 0;
+    progressive = false;
+    for (int t = 0; t < 4; ++t) qset[t] = dc[t].set = ac[t].set = false;
+  }
 };
 
 inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -132,6 +139,7 @@ void parse(const char* path, Parsed& p, mcm_jpeg_image& m) {
   memset(&m, 0, sizeof m);
   m.status = 2;
   for (int c = 0; c < 3; ++c) m.coef_off[c] = -1;
+  p.reset();
   FILE* f = fopen(path, "rb");
   if (!f) return;
   fseek(f, 0, SEEK_END);
@@ -612,7 +620,15 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
 extern "C" int mcm_jpeg_entropy_decode(const char* const* paths, int32_t n, void* dst, int64_t dst_bytes,
                                        mcm_jpeg_image* meta, uint16_t* quant, int32_t threads, int64_t* bytes_used) {
   if (!paths || !meta || !quant || !bytes_used || n < 0 || threads < 1 || (!dst && dst_bytes > 0)) return MCM_EINVAL;
-  std::vector<Parsed> parsed((size_t)n);
+  // per-image parse records (tables, file bytes: 30 KB + the file each), kept between calls — their allocation and first
+  // touch would otherwise be a serial millisecond or two in front of every batch.  One cached set per process; a call that
+  // finds it in use (two pipes decoding at once) works on records of its own.
+  static std::mutex cache_mu;
+  static std::vector<Parsed> cache;
+  std::unique_lock<std::mutex> lk(cache_mu, std::try_to_lock);
+  std::vector<Parsed> own;
+  std::vector<Parsed>& parsed = lk.owns_lock() ? cache : own;
+  if (parsed.size() < (size_t)n) parsed.resize((size_t)n);
   const int nt = std::max(1, std::min<int>(threads, n));
   auto parallel = [&](auto&& body) {
     std::atomic<int> next{0};

@@ -50,6 +50,14 @@ def load_library(harness: bool = False):
         raise NativeLibraryMissing(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C mcm_amd/csrc).  mcm_amd has no CPU fallback.")
+    # Both this library and PyTorch link libamdhip64, each from its own ROCm tree.  Whichever is loaded first provides the
+    # HIP runtime of the process; when ours (/opt/rocm) came first, torch's later calls failed with "no ROCm-capable device
+    # is detected" (measured).  The host code that owns buffers and streams here is torch's, so torch goes first when it
+    # is installed; a torch-less process (tests/c_abi) simply runs on /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(path)
     vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
     L.mcm_abi_version.restype = i32

@@ -262,10 +262,14 @@ class JpegFilePipe:
         self.bytes_copied = 0
         self.fallback_images = 0
         self.busy = False
+        # where the wall clock of a pass goes (seconds, summed over batches): the producer thread waiting for a free slot /
+        # decoding; this thread waiting for the producer / preparing and launching a batch
+        self.stats = {"batches": 0, "producer_wait_slot_s": 0.0, "producer_decode_s": 0.0, "consumer_wait_s": 0.0, "consumer_launch_s": 0.0}
 
     def _produce(self, batches, q, stop):
         import ctypes
         import os
+        import time
 
         import torch
 
@@ -279,9 +283,11 @@ class JpegFilePipe:
                 if n > self.max_batch:
                     raise ValueError(f"{n} files exceed max_batch {self.max_batch}")
                 s = self.slots[i % len(self.slots)]
+                t0 = time.perf_counter()
                 if s.used:
                     s.consumed.synchronize()
                     s.copied.synchronize()
+                t1 = time.perf_counter()
                 arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
                 used = ctypes.c_int64(0)
                 while True:
@@ -304,6 +310,11 @@ class JpegFilePipe:
                         release_pool(pool)
                 else:
                     fallbacks = {j: decode_rgb(paths[j]) for j in fb}
+                t2 = time.perf_counter()
+                st = self.stats
+                st["batches"] += 1
+                st["producer_wait_slot_s"] += t1 - t0
+                st["producer_decode_s"] += t2 - t1
                 item = (i, s, n, int(used.value), fallbacks)
                 while not stop.is_set():
                     try:
@@ -320,6 +331,7 @@ class JpegFilePipe:
     def stream(self, batches: Iterable[Sequence]) -> Iterator:
         import queue
         import threading
+        import time
 
         import torch
 
@@ -329,11 +341,14 @@ class JpegFilePipe:
         th.start()
         try:
             while True:
+                tq = time.perf_counter()
                 item = q.get()
                 if item is None:
                     break
                 if isinstance(item, BaseException):
                     raise item
+                tg = time.perf_counter()
+                self.stats["consumer_wait_s"] += tg - tq
                 i, s, n, nbytes, fallbacks = item
                 hs, ws, offs, o = [], [], [], 0
                 for j in range(n):
@@ -365,6 +380,7 @@ class JpegFilePipe:
                 if len(fallbacks) < n:
                     self.net.jpeg_reconstruct(s.dev, s.meta, s.quant, n, s.rgb, offs)
                 out = self.net.resize_crop_packed(s.rgb, offs, hs, ws, out=self.out[i % len(self.slots)][:n])
+                self.stats["consumer_launch_s"] += time.perf_counter() - tg
                 yield out
                 s.consumed.record(torch.cuda.current_stream(self.device))
         finally:
