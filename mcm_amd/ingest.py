@@ -221,6 +221,8 @@ class PackedImagePipe(_Pipe):
 
 class _JSlot:
     def __init__(self, max_batch: int, coef_bytes: int, device):
+        import ctypes
+
         import torch
 
         from .config import JpegImage
@@ -229,6 +231,8 @@ class _JSlot:
         self.dev = torch.empty(0, dtype=torch.uint8, device=device)
         self.rgb = torch.empty(0, dtype=torch.uint8, device=device)
         self.meta = (JpegImage * max_batch)()
+        # the same records as int32 columns (status, width, height, ncomp, ...): whole-batch reads without 512 ctypes objects
+        self.fields = np.frombuffer(self.meta, dtype=np.int32).reshape(max_batch, ctypes.sizeof(JpegImage) // 4)
         self.quant = np.zeros((max_batch, 3, 64), dtype=np.uint16)
         self.copied, self.consumed = torch.cuda.Event(), torch.cuda.Event()
         self.used = False
@@ -298,7 +302,7 @@ class JpegFilePipe:
                     if rc != -7 or used.value <= s.host.numel():  # MCM_ERANGE = the slot is too small: grow and retry
                         raise RuntimeError(f"mcm_jpeg_entropy_decode rc={rc}")
                     s.host = torch.empty(int(used.value * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
-                fb = [j for j in range(n) if s.meta[j].status != 0]
+                fb = np.nonzero(s.fields[:n, 0])[0].tolist()  # status != 0
                 if len(fb) >= 4 and self.threads > 1:  # several files for Pillow (progressive JPEGs, PNGs): its worker processes
                     from .decode_pool import lease_pool, release_pool
 
@@ -350,13 +354,12 @@ class JpegFilePipe:
                 tg = time.perf_counter()
                 self.stats["consumer_wait_s"] += tg - tq
                 i, s, n, nbytes, fallbacks = item
-                hs, ws, offs, o = [], [], [], 0
-                for j in range(n):
-                    h, w = fallbacks[j].shape[:2] if j in fallbacks else (s.meta[j].height, s.meta[j].width)
-                    hs.append(h)
-                    ws.append(w)
-                    offs.append(o)
-                    o += (h * w * 3 + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                wsa, hsa = s.fields[:n, 1].astype(np.int64), s.fields[:n, 2].astype(np.int64)  # (width, height) as decoded
+                for j, a in fallbacks.items():
+                    hsa[j], wsa[j] = a.shape[:2]
+                sizes = (hsa * wsa * 3 + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                offs = (np.cumsum(sizes) - sizes).tolist()
+                hs, ws, o = hsa.tolist(), wsa.tolist(), int(sizes.sum())
                 if s.dev.numel() < nbytes or s.rgb.numel() < o:  # this slot's device buffers grow to the largest batch seen
                     if s.used:
                         s.consumed.synchronize()
