@@ -317,6 +317,18 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
   int16_t* plane[3];
   for (int c = 0; c < m.ncomp; ++c) plane[c] = (int16_t*)(dst + m.coef_off[c]);
   int until_restart = p.restart, next_rst = 0;
+  // |v| <= lim[c][z] <=> |v * q| <= SANE; values of the one-look-up path are within +-128: unchecked where 128 q <= SANE
+  int16_t lim[3][64];
+  bool fast_unchecked[3];
+  for (int c = 0; c < m.ncomp; ++c) {
+    int qmax = 1;
+    for (int z = 0; z < 64; ++z) {
+      const int q = std::max<int>(1, p.q[p.cq[c]][z]);
+      lim[c][z] = (int16_t)std::min(32767, SANE / q);
+      qmax = std::max(qmax, q);
+    }
+    fast_unchecked[c] = 128 * qmax <= SANE;
+  }
   for (int y = 0; y < my; ++y) {
     for (int x = 0; x < mx; ++x) {
       if (p.restart && until_restart == 0) {
@@ -333,7 +345,8 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
       for (int c = 0; c < m.ncomp; ++c) {
         const Huff& hd = p.dc[p.cdc[c]];
         const Huff& ha = p.ac[p.cac[c]];
-        const uint16_t* qt = p.q[p.cq[c]];
+        const int16_t* lm = lim[c];
+        const bool fchk = !fast_unchecked[c];
         for (int by = 0; by < m.vs[c]; ++by) {
           for (int bx = 0; bx < m.hs[c]; ++bx) {
             int16_t* blk = plane[c] + ((size_t)(y * m.vs[c] + by) * m.wb[c] + (x * m.hs[c] + bx)) * 64;
@@ -348,7 +361,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
             // A dequantised coefficient of an 8-bit image stays below ~1200 (DC: 8 x 128 + rounding).  Beyond SANE the data
             // is damaged, and what libjpeg-turbo's 16-bit SIMD arithmetic makes of it is not what exact arithmetic
             // makes of it: not taken (the fallback decoder decides).
-            if (pred[c] * (int)qt[0] > SANE || pred[c] * (int)qt[0] < -SANE) return false;
+            if (pred[c] > lm[0] || pred[c] < -lm[0]) return false;
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
               if (b.cnt < 32) b.fill();
@@ -358,7 +371,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
                 if (k > 63) return false;
                 b.drop(fa & 15);
                 const int v = fa >> 8, z = ZIGZAG[k++];
-                if (v * (int)qt[z] > SANE || v * (int)qt[z] < -SANE) return false;
+                if (fchk && (v > lm[z] || v < -lm[z])) return false;
                 blk[z] = (int16_t)v;
                 continue;
               }
@@ -370,7 +383,7 @@ bool entropy(const Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
                 k += r;
                 if (k > 63) return false;
                 const int v = extend((int)b.peek(s), s), z = ZIGZAG[k];
-                if (v * (int)qt[z] > SANE || v * (int)qt[z] < -SANE) return false;
+                if (v > lm[z] || v < -lm[z]) return false;
                 blk[z] = (int16_t)v;
                 b.drop(s);
                 ++k;
