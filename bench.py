@@ -420,6 +420,7 @@ def ingest_legs(net, txt, B, steps, which):
                                     "cpu_quota_cores": __import__("mcm_amd.hostinfo", fromlist=["cpu_quota"]).cpu_quota(),
                                     "jpeg_bytes_per_image": fbytes / nfiles,
                                     "decoder": route,
+                                    "files_decoded_by_pillow_inside_the_pipe": (pipe.fallback_images if pipe is not None else None),
                                     "pipe_seconds_per_batch": ({k: round(v / max(1, pipe.stats["batches"]), 4) for k, v in pipe.stats.items()
                                                                 if k != "batches"} if pipe is not None else None),
                                     "source": f"{nfiles} JPEG files (quality 90, 8 sizes 256x341 ... 600x800) in an image folder, read + "
