@@ -148,6 +148,18 @@ def _loader(args, net, what, n, ood, sources):
     return DevicePatternLoader(n, net.geo.image_size, args.n_cls, args.batch_size, net.device, ood=ood, seed=seed)
 
 
+def _note_pillow_files(net, sources, what, log):
+    """How many files of the set just scored were decoded by Pillow inside the JPEG pipe (files that are not Huffman
+    YCbCr / grayscale JPEGs, or that show any irregularity): recorded with the set's data source."""
+    total = sum(p.fallback_images for p in net.__dict__.get("_jpeg_pipes", {}).values())
+    seen = net.__dict__.get("_pillow_files_seen", 0)
+    if what in sources and sources[what].get("kind") == "folder":
+        sources[what]["decoded_by_pillow"] = total - seen
+        if total - seen:
+            log.debug(f"{what}: {total - seen} file(s) decoded by Pillow (not taken by the device JPEG route)")
+    net.__dict__["_pillow_files_seen"] = total
+
+
 def main(argv=None):
     import json
 
@@ -219,6 +231,7 @@ def main(argv=None):
         in_score = get_Mahalanobis_score(args, net, test_loader, classwise_mean, precision, in_dist=True)
     else:
         in_score = get_ood_scores_clip(args, net, test_loader, test_labels, in_dist=True, device_out=on_dev)
+        _note_pillow_files(net, sources, "id", log)
     net.warn_if_saturated(f"the ID set {args.in_dataset}")
     refiner, net32 = None, None
     refinable = args.score != "maha" and args.dtype != "fp32"  # (with --host-metrics the scores are host arrays: refined in place too)
@@ -248,6 +261,7 @@ def main(argv=None):
             out_score = get_Mahalanobis_score(args, net, ood_loader, classwise_mean, precision, in_dist=False)
         else:
             out_score = get_ood_scores_clip(args, net, ood_loader, test_labels, device_out=on_dev)
+            _note_pillow_files(net, sources, out_dataset, log)
             if refiner is not None:
                 set_loaders[out_dataset] = ood_loader
                 refiner.apply(out_dataset, out_score if on_dev else torch.from_numpy(out_score))
