@@ -137,6 +137,14 @@ __global__ __launch_bounds__(256) void jpeg_colour_kernel(const JpegImageDev* __
           cbv[j] = ((j < 4 ? bw.x : bw.y) >> (8 * (j & 3))) & 255;
           crv[j] = ((j < 4 ? rw.x : rw.y) >> (8 * (j & 3))) & 255;
         }
+      } else if (dw <= 2) {  // jdsample.c jinit_upsampler: the fancy filters need downsampled_width > 2; else plain replication
+        const int r = m.V == 2 ? y >> 1 : y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = min((x0 + j) >> 1, dw - 1);
+          cbv[j] = pb[(size_t)r * s1 + c];
+          crv[j] = pr[(size_t)r * s2 + c];
+        }
       } else {
         const int c0 = x0 >> 1;
         const int r = m.V == 2 ? y >> 1 : y;

@@ -6,7 +6,8 @@
  *
  * Third-party algorithms restated (libjpeg 6b / libjpeg-turbo, IJG licence; no source under /root/reference):
  *   jidctint.c  jpeg_idct_islow   the default dct_method: 13-bit fixed-point constants, PASS1_BITS 2, two passes
- *   jdsample.c  h2v1_fancy_upsample / h2v2_fancy_upsample   the default do_fancy_upsampling triangle filters;
+ *   jdsample.c  h2v1_fancy_upsample / h2v2_fancy_upsample   the default do_fancy_upsampling triangle filters (plain
+ *               replication when the chroma plane is at most two samples wide);
  *               jdmainct.c's context rows: above the first / below the last REAL chroma row the edge row is repeated
  *   jdcolor.c   build_ycc_rgb_table / ycc_rgb_convert   16-bit fixed-point YCbCr -> RGB
  */
@@ -129,6 +130,9 @@ int orc_jpeg_reconstruct(const int16_t* const* coef, const uint16_t* quant, int 
           if (H == 1) {
             cb = plane[1][(size_t)y * s1 + x];
             cr = plane[2][(size_t)y * s2 + x];
+          } else if (dw <= 2) {  /* jdsample.c jinit_upsampler: the fancy filters need downsampled_width > 2; else replication */
+            cb = plane[1][(size_t)(y / V) * s1 + (x >> 1)];
+            cr = plane[2][(size_t)(y / V) * s2 + (x >> 1)];
           } else if (V == 1) {
             cb = up_h2v1(plane[1], s1, dw, x, y);
             cr = up_h2v1(plane[2], s2, dw, x, y);

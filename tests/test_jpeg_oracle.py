@@ -60,6 +60,9 @@ CASES = [  # (h, w, save kwargs)
     (241, 319, dict(quality=60, progressive=True, subsampling=1)), (97, 131, dict(quality=95, progressive=True, subsampling=2)),
     (17, 23, dict(quality=90, progressive=True)), (300, 301, dict(quality=85, progressive=True, restart_marker_blocks=5)),
     (600, 800, dict(quality=30, progressive=True)),
+    # chroma planes at most two samples wide: libjpeg replicates instead of filtering (jdsample.c jinit_upsampler)
+    (279, 2, dict(quality=21, subsampling=2)), (196, 4, dict(quality=25, subsampling=1)), (390, 1, dict(quality=15, subsampling=2)),
+    (21, 4, dict(quality=79, subsampling=1)), (40, 3, dict(quality=90, subsampling=2, progressive=True)), (3, 5, dict(quality=90, subsampling=2)),
 ]
 
 
