@@ -1,3 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r4c61
-timeout 1500 python tools/resize_sweep.py --n 720 2>/tmp/s.err | tail -1 | tee gpurun_out/r4c61/resize_sweep.json | cut -c1-900; grep -i "Traceback\|Error" -A3 /tmp/s.err | head -8
+# scratch driver for one `gpurun` call (rewritten per call during development; the last one ran the JPEG / ingest / preprocess
+# GPU tests).  Kept so that `gpurun -- 'bash tools/_call.sh'` is always a valid smoke of the ingest path.
+timeout 900 python -m pytest tests/test_gpu_jpeg.py tests/test_gpu_ingest.py tests/test_gpu_preprocess.py -x -q -m gpu 2>&1 | tail -2
