@@ -958,7 +958,10 @@ int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_ima
   if (n <= 0) return fail(h, MCM_EINVAL, "n must be positive");
   if (n > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds max_batch");
   hipStream_t s = (hipStream_t)stream;
-  const size_t rec = sizeof(JpegImageDev) + 3 * 64 * sizeof(uint16_t), slot_bytes = (size_t)h->cfg.max_batch * rec;
+  // a slot of the staging ring: max_batch records, then (16-byte aligned: the kernel reads them as 16-byte rows) the tables
+  const size_t qoff = ((size_t)h->cfg.max_batch * sizeof(JpegImageDev) + 15) / 16 * 16;
+  const size_t slot_bytes = (qoff + (size_t)h->cfg.max_batch * 3 * 64 * sizeof(uint16_t) + 255) / 256 * 256;
+  if ((uintptr_t)coef_dev & 15) return fail(h, MCM_EINVAL, "coef_dev must be 16-byte aligned");
   if (!h->jpg_pin) {  // first call on this handle
     if (hipHostMalloc((void**)&h->jpg_pin, mcm_handle::PREP_RING * slot_bytes) != hipSuccess) return fail(h, MCM_ENOMEM, "hipHostMalloc jpeg");
     rc = dev_alloc(h, (void**)&h->jpg_dev, mcm_handle::PREP_RING * slot_bytes);
@@ -971,7 +974,7 @@ int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_ima
   char* dev = h->jpg_dev + slot * slot_bytes;
   HIP_TRY(h, hipEventSynchronize(h->jpg_ev[slot]));
   JpegImageDev* md = (JpegImageDev*)pin;
-  uint16_t* qd = (uint16_t*)(pin + (size_t)h->cfg.max_batch * sizeof(JpegImageDev));
+  uint16_t* qd = (uint16_t*)(pin + qoff);
   size_t planes = 0;
   int m = 0, max_blocks = 0, max_pixels = 0;
   for (int32_t i = 0; i < n; ++i) {
@@ -1012,7 +1015,6 @@ int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_ima
     h->jpg_planes_bytes = want;
   }
   HIP_TRY(h, hipMemcpyAsync(dev, pin, (size_t)m * sizeof(JpegImageDev), hipMemcpyHostToDevice, s));
-  const size_t qoff = (size_t)h->cfg.max_batch * sizeof(JpegImageDev);
   HIP_TRY(h, hipMemcpyAsync(dev + qoff, pin + qoff, (size_t)m * 192 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipEventRecord(h->jpg_ev[slot], s));
   HIP_TRY(h, launch_jpeg_reconstruct((const JpegImageDev*)dev, (const uint16_t*)(dev + qoff), coef_dev, h->jpg_planes, rgb_dev, m,

@@ -103,3 +103,33 @@ def test_file_pipe_equals_the_pillow_route_with_fallbacks_and_errors(net, tmp_pa
             pass
     got = torch.cat([b.clone() for b in pipe.stream([paths[:5]])]).cpu().numpy()   # the pipe is usable after an error
     np.testing.assert_array_equal(got, want[:5])
+
+
+def test_reconstruction_with_an_odd_max_batch(tmp_path):
+    """The staging ring of mcm_jpeg_reconstruct keeps the quantisation tables behind max_batch records; the kernel reads them
+    in 16-byte rows, so their offset must be aligned whatever max_batch is (7 records end on an odd multiple of 8 bytes)."""
+    from mcm_amd.config import geometry
+    from mcm_amd.engine import NativeCLIP
+    from mcm_amd.weights import synth_state_dict
+
+    geo = geometry("B16-2L")
+    net = NativeCLIP(geo, synth_state_dict(geo, 0, "fp16-exact"), precision="fp16", max_batch=7, max_prompt_tokens=1024)
+    try:
+        paths = []
+        for k, (h, w, kw) in enumerate(CASES[:5]):
+            p = str(tmp_path / f"{k}.jpg")
+            Image.fromarray(_photo(h, w, 40 + k)).save(p, **kw)
+            paths.append(p)
+        meta, quant, buf = entropy_decode(paths)
+        want = [_pil(p) for p in paths]
+        offs, o = [], 0
+        for a in want:
+            offs.append(o)
+            o += (a.size + 15) // 16 * 16
+        rgb = torch.zeros(o, dtype=torch.uint8, device="cuda")
+        net.jpeg_reconstruct(torch.from_numpy(buf).cuda(), meta, quant, len(paths), rgb, offs)
+        got = rgb.cpu().numpy()
+        for i, a in enumerate(want):
+            np.testing.assert_array_equal(got[offs[i]: offs[i] + a.size].reshape(a.shape), a)
+    finally:
+        net.close()
