@@ -438,6 +438,10 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
   // successive-approximation state per coefficient: -1 = not seen yet, else the Al of its last scan
   int8_t al_of[3][64];
   memset(al_of, -1, sizeof al_of);
+  // which AC coefficients of a block are non-zero so far, bit k = zigzag position k: a refinement scan visits the non-zero
+  // ones (a correction bit each) and counts the zero ones in between, instead of looking at all 63 positions of every block
+  std::vector<uint64_t> nzbits[3];
+  for (int c = 0; c < m.ncomp; ++c) nzbits[c].assign((size_t)m.wb[c] * m.hb[c], 0);
   const int hmax = m.hs[0], vmax = m.vs[0];  // (luma carries the largest factors in everything this path takes)
   size_t pos = p.first_sos;
   for (int nscan = 0; nscan < 1000; ++nscan) {
@@ -522,6 +526,7 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
         for (int x = 0; x < bw; ++x) {
           if (!restart_if_due()) return false;
           int16_t* blk = plane[c] + ((size_t)y * m.wb[c] + x) * 64;
+          uint64_t& nz = nzbits[c][(size_t)y * m.wb[c] + x];
           if (Ah == 0) {  // G.1.2.2: first scan of the band
             if (eobrun > 0) {
               --eobrun;
@@ -538,6 +543,7 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
                   b.drop(sz);
                   if (v > 32767 || v < -32768) return false;
                   blk[ZIGZAG[k]] = (int16_t)v;
+                  nz |= (uint64_t)1 << k;
                 } else if (r == 15) {
                   k += 15;
                 } else {
@@ -549,6 +555,11 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
               }
             }
           } else {  // G.1.2.3: refinement — new +-1s between correction bits of the coefficients that are already non-zero
+            const uint64_t band = (Se == 63 ? ~(uint64_t)0 : (((uint64_t)1 << (Se + 1)) - 1));
+            auto correct = [&](int kk) {  // one correction bit for the non-zero coefficient at zigzag position kk
+              int16_t& co = blk[ZIGZAG[kk]];
+              if (b.bit() && (co & p1) == 0) co = (int16_t)(co >= 0 ? co + p1 : co + m1);
+            };
             int k = Ss;
             if (eobrun == 0) {
               for (; k <= Se; ++k) {
@@ -564,25 +575,31 @@ bool entropy_progressive(Parsed& p, const mcm_jpeg_image& m, uint8_t* dst) {
                   if (r) eobrun += b.bits(r);
                   break;
                 }
-                do {
-                  int16_t& co = blk[ZIGZAG[k]];
-                  if (co != 0) {
-                    if (b.bit() && (co & p1) == 0) co = (int16_t)(co >= 0 ? co + p1 : co + m1);
-                  } else if (--r < 0) {
+                // over r still-zero coefficients (and every non-zero one on the way, with its correction bit) to the next zero
+                for (;;) {
+                  const uint64_t ahead = (nz & band) >> k;                       // non-zero coefficients at k, k+1, ...
+                  const int gap = ahead ? __builtin_ctzll(ahead) : Se + 1 - k;   // zeros in front of the next one
+                  if (gap > r) {
+                    k += r;
                     break;
                   }
+                  r -= gap;
+                  k += gap;
+                  if (k > Se) break;
+                  correct(k);
                   ++k;
-                } while (k <= Se);
+                  if (k > Se) break;
+                }
                 if (val) {
                   if (k > Se) return false;
                   blk[ZIGZAG[k]] = (int16_t)val;
+                  nz |= (uint64_t)1 << k;
                 }
               }
             }
-            if (eobrun > 0) {
-              for (; k <= Se; ++k) {
-                int16_t& co = blk[ZIGZAG[k]];
-                if (co != 0 && b.bit() && (co & p1) == 0) co = (int16_t)(co >= 0 ? co + p1 : co + m1);
+            if (eobrun > 0) {  // the rest of the band: correction bits only
+              if (k <= Se) {
+                for (uint64_t rest = (nz & band) >> k << k; rest; rest &= rest - 1) correct(__builtin_ctzll(rest));
               }
               --eobrun;
             }
