@@ -15,19 +15,21 @@ the timed region (weak scaling).  If the box has fewer devices than ranks (a 1-G
 2-rank logic check) the ranks share devices and the collective falls back to gloo, because RCCL refuses
 two ranks on one device; the JSON line says so (`"collective"`).
 
-Prints ONE JSON line (rank 0) with
+Output (rank 0): ONE JSON line of at most 4 KB (`short_line`; tests/test_bench_line.py holds it to that) — the contract
+keys, `roofline`, `cpu_baseline` and one scalar per side leg — printed last on stdout; every leg's full record goes to
+`bench_detail.json` beside this file (and to gpurun_out/ when that directory exists).  Legs (tools/bench_legs.py), all
+outside the timed region, N = 1 only:
   roofline      GEMM kernel family: algorithmic FLOP ÷ HIP-event time of the launches of every 4th timed
                 step (`profiled_steps`; bracketing every launch of every step costs 2.3 % of throughput);
+                `traffic` from two rocprofv3 --pmc child passes of this script;
   cpu_baseline  the reference's own arithmetic — HF transformers CLIPModel, fp32 — driven by a re-statement
-                of the reference loop on the host cores (BASELINE.md §3 protocol: one warm-up batch, then 256
-                images at batch 64; `value` = prompts re-encoded per batch as the reference does,
-                `value_hoisted` = bank encoded once); the C oracle if transformers is unavailable;
-  sustained     the same step repeated for >= 5 s after the timed region, with sclk / package power sampled
-                through rocm-smi: what the part holds at its power limit, next to the short timed burst;
-  parity        (N = 1) AUROC / AUPR / FPR95 on the headline configuration (mcm_amd/parity.py): full B/16,
-                K = 1000, 50 000 ID + 10 000 OOD device-generated images, every native arm (exact-fp32, fp16,
-                bf16) AND the HF CLIPModel fp32 reference on this device scoring the same pixels
-                (`parity.vs_hf`), in both weight regimes (fp16-exact and fp32-valued seeded weights).
+                of the reference loop on the host cores (BASELINE.md §3 protocol);
+  sustained     the same step repeated for >= 5 s with sclk / package power sampled through rocm-smi;
+  refined       `value_refined`: BASELINE config 3's sizes (50 000 ID + 35 640 OOD device-resident images) scored AND
+                threshold-refined (mcm_amd/refine.py: the route that holds FPR95 to the reference), wall-clock images/sec;
+  arms/configs  3 timed steps each of the other precision arms and of BASELINE configs 2 and 4 (K = 100; ViT-L/14);
+  parity        AUROC / AUPR / FPR95 on config 3 of every native arm against the exact-fp32 arm and against the HF
+                CLIPModel fp32 reference on this device over the same pixels (mcm_amd/parity.py).
 """
 from __future__ import annotations
 
@@ -36,7 +38,6 @@ import json
 import os
 import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -46,422 +47,99 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
 DEFAULT_PRECISION = "fp16"  # the 16-bit mode that holds AUROC/FPR95 to the fp32 arm
+LINE_LIMIT = 4096           # bytes of the printed line (a 33.6 KB line left the driver with parsed = null)
+# harness A/B switches (libmcm_hip_harness.so, mcm_debug_*): `--harness gemm_variant=3,ln_tail=1`; never the shipped policy
+HARNESS_KEYS = {"gemm_variant": "mcm_debug_gemm_variant", "attn_variant": "mcm_debug_attention_variant",
+                "ln_fold": "mcm_debug_ln_fold", "ln_tail": "mcm_debug_ln_tail", "patch_fold": "mcm_debug_patch_fold",
+                "group_n": "mcm_debug_gemm_group_n", "nsplit": "mcm_debug_nsplit", "qkv_chunks": "mcm_debug_qkv_chunks",
+                "gemm_dbg": "mcm_debug_gemm_dbg"}
 
 
-def pmc_traffic(family="gemm"):
-    """L2<->fabric bytes per launch of a kernel family (and per GEMM shape class) from the committed rocprofv3
-    PMC passes (profiles/*_traffic.json, written by tools/traffic_json.py); None when absent."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None, None, None
+def _r(x, sig=5):
+    """Floats to `sig` significant digits (the line is read by a parser, the full precision is in bench_detail.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
     try:
-        per = json.load(open(files[-1]))["per_launch_bytes"]
-        shapes = {k: {"l2_fabric_bytes": v["hbm_bytes"], "algorithmic_bytes": v.get("algorithmic_bytes"),
-                      "ratio": v.get("ratio")} for k, v in per.items() if k.startswith("gemm_") and "text" not in k}
-        return per[family]["hbm_bytes"], os.path.basename(files[-1]), shapes or None
-    except Exception:
-        return None, None, None
+        return float(f"{float(x):.{sig}g}")
+    except (TypeError, ValueError):
+        return None
 
 
-def live_pmc_traffic(args):
-    """L2<->fabric bytes per GEMM launch measured IN THIS RUN: two short child runs of this script under
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, /opt/skills/guides/MI355X_MICROARCH.md
-    HBM section; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the gfx950 half-count correction of FETCH_SIZE), summarised by
-    tools/traffic_json.py.  Returns (family bytes per launch, per-shape dict, note) — (None, None, why) when rocprofv3 is not
-    there or a pass fails (the committed profiles/*_traffic.json is then used and labelled as such)."""
-    import importlib.util
-    import shutil
-    import tempfile
-
-    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(rp):
-        return None, None, "rocprofv3 not found"
-    spec = importlib.util.spec_from_file_location("traffic_json", os.path.join(ROOT, "tools", "traffic_json.py"))
-    tj = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(tj)
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-drift", "--cpu-seconds", "0",
-             "--sustain-seconds", "0", "--no-profile", "--ingest", "none", "--no-arms", "--no-live-traffic", "--ckpt", args.ckpt,
-             "--batch", str(args.batch), "--prompts", str(args.prompts), "--precision", args.precision,
-             "--weights-regime", args.weights_regime, "--weight-operands", args.weight_operands]
-    env = dict(os.environ, TMPDIR="/tmp")
-    found = {}
-    with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(d, counter)
-            try:
-                r = subprocess.run([rp, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--"] + child, cwd="/tmp", env=env,
-                                   capture_output=True, text=True, timeout=240)
-            except Exception as e:
-                return None, None, f"rocprofv3 {counter} pass: {type(e).__name__}"
-            hits = [os.path.join(dp, f) for dp, _d, fs in os.walk(out) for f in fs
-                    if f.endswith("_results.db") or f.endswith("counter_collection.csv")]
-            if r.returncode or not hits:
-                return None, None, f"rocprofv3 {counter} pass failed (rc {r.returncode})"
-            try:
-                found[counter] = tj.mean_by_family(hits[0], counter)
-            except Exception as e:
-                return None, None, f"parsing the {counter} pass: {type(e).__name__}: {e}"
-    fetch, write = found["FETCH_SIZE"], found["WRITE_SIZE"]
-    if "gemm" not in fetch:
-        return None, None, "no GEMM dispatches in the counter pass"
-    per = {}
-    for f, (fb, n) in fetch.items():
-        if f == "gemm" or f.startswith("gemm_"):
-            wb = write.get(f, (0.0, 0))[0]
-            per[f] = {"l2_fabric_bytes": (2 * fb + wb) * 1024, "launches_sampled": n}
-            if f in tj.ALGO and args.batch == 512 and args.ckpt == "ViT-B/16":
-                per[f]["algorithmic_bytes"] = tj.ALGO[f]
-                per[f]["ratio"] = per[f]["l2_fabric_bytes"] / tj.ALGO[f]
-    fam = per.pop("gemm")["l2_fabric_bytes"]
-    per.pop("gemm_fp32_text_tower", None)
-    return fam, per, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 3 steps each"
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
 
 
-class SmiSampler(threading.Thread):
-    """sclk (MHz) and package power (W) of device 0 every `period` s through rocm-smi."""
-
-    def __init__(self, period=0.5):
-        super().__init__(daemon=True)
-        self.period, self.samples, self._stop_evt = period, [], threading.Event()
-
-    def run(self):
-        import re
-
-        while not self._stop_evt.is_set():
-            try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
-                                     timeout=5).stdout
-                clk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
-                pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
-                if clk and pw:
-                    self.samples.append((int(clk.group(1)), float(pw.group(1))))
-            except Exception:
-                pass
-            self._stop_evt.wait(self.period)
-
-    def stop(self):
-        self._stop_evt.set()
-        self.join(timeout=10)
-        busy = [s for s in self.samples if s[1] > 300]
-        if not busy:
-            return {"samples": len(self.samples), "busy_samples": 0}
-        return {"samples": len(self.samples), "busy_samples": len(busy),
-                "sclk_mhz_mean": sum(s[0] for s in busy) / len(busy),
-                "power_w_mean": sum(s[1] for s in busy) / len(busy)}
-
-
-def cpu_baseline(geo, sd, ids, mask, K, px_batches, max_seconds, native_first):
-    """The reference loop on the host cores (utils/detection_util.py:219-248): per batch, image features →
-    normalise → (re-)encode the K prompts → normalise → matmul → softmax → -max, fp32 torch CPU through HF
-    CLIPModel.  BASELINE.md §3: one warm-up batch, then >= 256 images at batch 64.  The image part and the
-    text part of every batch are timed separately, so one pass gives both figures: `value` (what the
-    reference does: text bank re-encoded per batch) and `value_hoisted` (bank encoded once)."""
-    import numpy as np
-    import torch
-
-    from mcm_amd.hostinfo import cpu_quota, effective_cpus
-
-    # torch defaults to one thread per visible core; a container is scheduled on its cgroup quota (the GPU boxes here: 256
-    # CPUs visible, 16 cores of quota), and threads beyond it only take turns.  `cores` = the threads used = that allocation.
-    threads_default = torch.get_num_threads()
-    torch.set_num_threads(min(threads_default, effective_cpus()))
-    info = {"cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "cpu_quota_cores": cpu_quota(),
-            "torch_default_threads": threads_default, "unit": "images/sec"}
-    bs = px_batches[0].shape[0]
-    try:
-        from oracle.hf_reference import HFReference
-
-        h = HFReference(geo, sd, device="cpu")
-        h.set_bank(ids, mask)
-
-        def image_part(px):   # features, normalise, similarity, softmax, -max against the current bank
-            return h.score_batch(px, 1.0, "MCM").numpy()
-
-        def text_part():      # the loop-invariant work the reference repeats every batch (:228-231)
-            h.set_bank(ids, mask)
-
-        kind = "reference"
-    except Exception as e:  # transformers missing on the box: time the C oracle instead
-        from oracle import oracle as orc
-
-        o = orc.OracleCLIP(geo, sd)
-        bank = {"t": o.encode_text(ids)}
-
-        def image_part(px):
-            return orc.score_features(o.encode_image(px.numpy()), bank["t"], 1.0, 0)
-
-        def text_part():
-            bank["t"] = o.encode_text(ids)
-
-        kind = "port"
-        info["note"] = f"transformers unavailable ({type(e).__name__}); C oracle timed"
-    t0 = time.perf_counter()
-    text_part()
-    image_part(px_batches[0][:8])  # warm-up: thread pool, allocator, oneDNN primitive caches (8 images: the timed batches follow)
-    warm = time.perf_counter() - t0
-    n, t_img, t_txt, i = 0, 0.0, 0.0, 0
-    target = 256
-    first = None
-    while n < target and (t_img + t_txt) < max_seconds:
-        px = px_batches[i % len(px_batches)]
-        t0 = time.perf_counter()
-        text_part()
-        t1 = time.perf_counter()
-        got = image_part(px)
-        t2 = time.perf_counter()
-        if first is None:
-            first = got  # batch 0 = the pixels the native run scored first: the parity check below
-        t_txt += t1 - t0
-        t_img += t2 - t1
-        n += px.shape[0]
-        i += 1
-    info.update(value=n / (t_img + t_txt) if n else None, value_hoisted=n / t_img if n else None, kind=kind,
-                seconds={"warmup_batch": warm, "image_part": t_img, "text_part": t_txt},
-                sample=f"{n} images, batch {bs} (K={K} prompts; value: bank re-encoded per batch as the reference "
-                       f"does, value_hoisted: bank encoded once) after a warm-up (bank + 8 images) of {warm:.1f} s; same seeded "
-                       f"weights and pixels as the native run" + ("" if n >= target else
-                                                                  f"; stopped at the {max_seconds:.0f} s cap"))
-    torch.set_num_threads(threads_default)
-    if native_first is not None and first is not None:
-        d = np.abs(first - native_first)
-        info["parity_max_abs_dscore_vs_native"] = float(d.max())
-        info["parity_images"] = int(d.size)
-    return info
-
-
-def parity_leg(args, K, B, device):
-    """AUROC / AUPR / FPR95 of every native arm against the exact-fp32 arm AND against the HF CLIPModel fp32
-    reference running on the same device over the same 50 000 + 10 000 device-generated images, in both weight
-    regimes.  Outside the timed region; the HF scorer is the checker (oracle/hf_reference.py), never measured."""
-    from mcm_amd.parity import CONFIG3_OOD_SETS, HEADLINE_PIXELS, measure_drift
-
-    external, hf_note = None, None
-    if not args.no_hf:
-        try:
-            from oracle.hf_reference import hf_available, hf_scorer_factory
-
-            why = hf_available()
-            if why is None:
-                external = {"hf": hf_scorer_factory()}
-            else:
-                hf_note = f"transformers unavailable on this box ({why}): vs_hf not measured"
-        except Exception as e:
-            hf_note = f"HF reference scorer unavailable ({type(e).__name__}: {e}): vs_hf not measured"
-    from mcm_amd.parity import REALISTIC_PIXELS, meets_bar
-
-    arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16", "fp16+refine")))
-    c3 = tuple(args.drift_n) == (50000, 10000)  # default: BASELINE config 3 — ImageNet-1k vs the four OOD sets
-    ood_sets = CONFIG3_OOD_SETS if c3 else None
-    out = {"config": "BASELINE config 3: ImageNet-1k-sized ID set (50 000) vs iNaturalist / SUN / Places / Textures-sized "
-                     "OOD sets (10 000 / 10 000 / 10 000 / 5 640), K = 1000; headline keys = the AVG row of the reference's "
-                     "CSV, per_set = every OOD set on its own" if c3 else "one ID and one OOD set (--drift-n)",
-           "n_id": args.drift_n[0], "n_ood": {n: c for n, c, _ in CONFIG3_OOD_SETS} if c3 else args.drift_n[1],
-           "pixels": {k: HEADLINE_PIXELS[k] for k in ("amp", "tile")},
-           "bar": "north_star: |dAUROC|, |dFPR95| <= 1e-4.  FPR95 of ONE set is a count of images on the ID side of one "
-                  "threshold (quantum 1e-4 at 10 000 images): per_set carries it as d_fpr95_images",
-           "reference_arms": "exact-fp32 MFMA arm of this library; HF transformers CLIPModel fp32 eager on this device"}
-    if hf_note:
-        out["vs_hf_note"] = hf_note
-    keys = ("d_auroc", "d_aupr", "d_fpr95", "max_abs_dscore", "rms_dscore")
-    for regime, weights in (("fp16_exact_weights", "fp16-exact"), ("fp32_valued_weights", "fp32")):
-        t0 = time.perf_counter()
-        # fp32-valued weights: the 16-bit arms run the split-weight GEMMs (weight_operands auto); "fp16:single" is what
-        # rounds 1 - 3 did there (one rounded operand per weight), kept as the comparison
-        arms_w = arms + (("fp16:single",) if weights == "fp32" else ())
-        d = measure_drift(args.ckpt, K=K, n_id=args.drift_n[0], n_ood=args.drift_n[1], batch=B, arms=arms_w,
-                          device=device, amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights,
-                          external=external, ood_sets=ood_sets)
-        r = {"auroc_fp32_arm": d["reference"]["auroc"], "fpr95_fp32_arm": d["reference"]["fpr95"],
-             "score_std_id": d["reference"]["score_std_id"], "seconds": time.perf_counter() - t0,
-             "fp16_saturation_events": d["fp16_saturation_events"].get("fp16"),
-             "weight_operands": d["weight_operands"], "refine": d.get("refine"),
-             "vs_fp32_arm": {p: {k: d["arms"][p][k] for k in keys + ("max_set",) + (("per_set",) if c3 else ())} for p in arms_w}}
-        if "external" in d:
-            r["auroc_hf"], r["fpr95_hf"] = d["external"]["hf"]["auroc"], d["external"]["hf"]["fpr95"]
-            r["vs_hf"] = {"fp32_arm": d["reference"]["vs_external"]["hf"],
-                          **{p: d["arms"][p]["vs_external"]["hf"] for p in arms_w}}
-        out[regime] = r
-    head = out["fp16_exact_weights"]
-    # headline keys (what round 2's line carried): the benchmarked dtype, fp16-exact weights
-    out["weights"] = "fp16-exact (headline keys below); fp32-valued regime under fp32_valued_weights"
-    out["vs"] = "HF CLIPModel fp32 on this device" if "vs_hf" in head else "exact-fp32 MFMA arm"
-    src = head["vs_hf"][args.precision] if "vs_hf" in head else head["vs_fp32_arm"][args.precision]
-    out.update({k: src[k] for k in keys})
-    if "vs_hf" in head:
-        out["vs_hf"] = {"fp16_exact_weights": head["vs_hf"], "fp32_valued_weights": out["fp32_valued_weights"]["vs_hf"]}
-    out["bf16"] = {w: out[w]["vs_hf" if "vs_hf" in out[w] else "vs_fp32_arm"]["bf16"]
-                   for w in ("fp16_exact_weights", "fp32_valued_weights")}
-    # judged PER OOD SET (the AVG row lets opposite-sign drifts cancel): |dAUROC|, |dAUPR| <= 1e-4 on every set and FPR95
-    # within N images of the reference on every set — N = 1 is the quantum of a 10 000-image set; on this ordering-stress
-    # set a 16-bit arm's activation rounding moves 0 - 2 images depending on the draw (DESIGN.md section 2.1)
-    for key, n_img in (("meets_1e-4", 2), ("meets_1e-4_fpr95_within_1_image", 1)):
-        out[key] = {w: {p: meets_bar(v, 1e-4, n_img) and bool(v["d_fpr95"] <= 1e-4 + 1e-12)
-                        for p, v in out[w]["vs_hf" if "vs_hf" in out[w] else "vs_fp32_arm"].items()}
-                    for w in ("fp16_exact_weights", "fp32_valued_weights")}
-    # the realistic operating point (mcm_amd/parity.py REALISTIC_PIXELS): reference AUROC 0.9, score noise ~0.1 % of the spread
-    if c3:
-        t0 = time.perf_counter()
-        d = measure_drift(args.ckpt, K=K, n_id=16000, n_ood=16000, batch=500, arms=arms, device=device,
-                          amp=REALISTIC_PIXELS["amp"], tile=REALISTIC_PIXELS["tile"], tile_ood=REALISTIC_PIXELS["tile_ood"],
-                          weights="fp16-exact", operating_point=0.9)
-        out["operating_point_auroc_0.9"] = dict(d["operating_point"], seconds=time.perf_counter() - t0,
-                                                pixels=d["pixels"], vs="exact-fp32 MFMA arm")
-    return out
-
-
-def ingest_legs(net, txt, B, steps, which):
-    """uint8 host → scores, end to end (§7 hard part 4).  `host_u8`: 224² uint8 crops sitting in PINNED
-    host memory → double-buffered asynchronous copies on a copy stream → mcm_score_u8 (ToTensor + Normalize fused into the
-    patch gather).  `host_raw`: variable-size decoded RGB images (an ImageNet-like size mix, mean ≈ 0.5 MB) → packed into
-    one pinned buffer per batch by the host → ONE copy per batch → mcm_resize_crop_u8 (Resize 224 + CenterCrop 224,
-    bit-exact vs Pillow) → mcm_score_u8.  JPEG decode itself is host-CPU work outside this path.  Outside the timed
-    region of the headline number; reported next to it."""
-    import numpy as np
-    import torch
-
-    from mcm_amd.ingest import PackedImagePipe, PinnedBatchPipe
-
-    S = net.geo.image_size
-    out = {}
-    sc = torch.empty(B, device=net.device)
-    if "host-u8" in which:
-        g = torch.Generator().manual_seed(7)
-        host = [torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(3)]
-        pipe = PinnedBatchPipe(net, B)
-        for px in pipe.stream(host[:2]):  # warm-up: pinned buffers, copy stream, the u8 patchify kernel
-            net.score_images(px, txt, 1.0, "MCM", out=sc)
-        torch.cuda.synchronize()
-        b0, t0 = pipe.bytes_copied, time.perf_counter()
-        for px in pipe.stream(host[i % 3] for i in range(steps)):
-            net.score_images(px, txt, 1.0, "MCM", out=sc)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["host_u8"] = {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                          "pcie_gb_per_sec": (pipe.bytes_copied - b0) / dt / 1e9, "bytes_per_image": S * S * 3,
-                          "source": "uint8 [B,224,224,3] crops in pinned host memory, one async copy per batch on a copy "
-                                    "stream, 3 device buffers"}
-        del pipe, host
-    if "host-raw" in which:
-        rng = np.random.default_rng(11)
-        sizes = [(375, 500), (500, 375), (333, 500), (500, 333), (480, 640), (400, 400), (256, 341), (600, 800)]
-        base = {hw: rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8) for hw in sizes}
-        batch = [base[sizes[i % len(sizes)]] for i in range(B)]
-        nbytes = PackedImagePipe.packed_bytes(batch)
-        pipe = PackedImagePipe(net, B, nbytes + (1 << 20), pack_threads=int(os.environ.get("MCM_PACK_THREADS", min(16, os.cpu_count() or 1))))
-        for px in pipe.stream([batch, batch]):
-            net.score_images(px, txt, 1.0, "MCM", out=sc)
-        torch.cuda.synchronize()
-        b0, t0 = pipe.bytes_copied, time.perf_counter()
-        for px in pipe.stream(batch for _ in range(steps)):
-            net.score_images(px, txt, 1.0, "MCM", out=sc)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["host_raw"] = {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                           "pcie_gb_per_sec": (pipe.bytes_copied - b0) / dt / 1e9, "bytes_per_image": nbytes / B,
-                           "pack_threads": pipe.pack_threads,
-                           "source": "decoded RGB images of 8 sizes (256x341 ... 600x800) in pageable host memory, packed "
-                                     "into one pinned buffer and copied once per batch, Resize + CenterCrop on the device"}
-        del pipe
-    if "host-jpeg" in which:
-        # the CLI's own loader on an image folder of JPEG files: file read + Pillow decode in the loader's worker processes (host
-        # work, like the reference's DataLoader workers) -> packed copy -> Resize + CenterCrop + scoring on the device
-        try:
-            import shutil
-            import tempfile
-
-            from PIL import Image
-
-            from mcm_amd.folder import ImageFolderU8
-
-            rng = np.random.default_rng(13)
-            sizes = [(375, 500), (500, 375), (333, 500), (500, 333), (480, 640), (400, 400), (256, 341), (600, 800)]
-            root = tempfile.mkdtemp(prefix="mcm_jpeg_")
-            try:
-                import io
-
-                nfiles, fbytes = 16 * B, 0   # (a pass of 16 batches: the first batch of a pass pays for the pipe's start)
-                yy, xx = np.mgrid[0:800, 0:800].astype(np.float32)
-                blobs = []
-                for i in range(2 * len(sizes)):  # photograph-like content: smooth structure + texture (noise alone does not compress)
-                    h, w = sizes[i % len(sizes)]
-                    f = rng.uniform(0.01, 0.06, 6)
-                    im = np.stack([127 + 70 * np.sin(f[2 * c] * xx[:h, :w] + i) * np.cos(f[2 * c + 1] * yy[:h, :w]) for c in range(3)], -1)
-                    im = np.clip(im + rng.normal(0, 12, im.shape), 0, 255).astype(np.uint8)
-                    buf = io.BytesIO()
-                    Image.fromarray(im).save(buf, format="JPEG", quality=90)
-                    blobs.append(buf.getvalue())
-                for c in range(8):
-                    os.makedirs(os.path.join(root, f"class{c}"))
-                for j, blob in enumerate(blobs):
-                    with open(os.path.join(root, f"blob{j}.bin"), "wb") as fh:
-                        fh.write(blob)
-                for i in range(nfiles):  # hard links to the 16 files: a folder of 8 192 entries without 700 MB of writes
-                    os.link(os.path.join(root, f"blob{i % len(blobs)}.bin"), os.path.join(root, f"class{i % 8}", f"{i:05d}.jpg"))
-                    fbytes += len(blobs[i % len(blobs)])
-                loader = ImageFolderU8(root, net, B)  # (MCM_DECODE_WORKERS overrides the loader's own choice: its CPU quota)
-                route = ("entropy decode on host threads, inverse DCT + upsampling + colour on the device"
-                         if os.environ.get("MCM_GPU_JPEG", "1") != "0" else "Pillow in worker processes")
-                for px, _ in loader:  # warm-up pass: page cache, thread pool, slots
-                    net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
-                torch.cuda.synchronize()
-                passes, t0 = 1, time.perf_counter()
-                for _ in range(passes):
-                    for px, _ in loader:
-                        net.score_images(px, txt, 1.0, "MCM", out=sc[: px.shape[0]])
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                pipe = next(iter(net.__dict__.get("_jpeg_pipes", {}).values()), None)
-                loader.close()
-                out["host_jpeg"] = {"images_per_sec": passes * nfiles / dt, "ms_per_step": 1e3 * dt / (passes * nfiles / B),
-                                    "steps": passes * nfiles // B, "decode_workers": loader.workers, "host_cpus": os.cpu_count(),
-                                    "cpu_quota_cores": __import__("mcm_amd.hostinfo", fromlist=["cpu_quota"]).cpu_quota(),
-                                    "jpeg_bytes_per_image": fbytes / nfiles,
-                                    "decoder": route,
-                                    "files_decoded_by_pillow_inside_the_pipe": (pipe.fallback_images if pipe is not None else None),
-                                    "pipe_seconds_per_batch": ({k: round(v / max(1, pipe.stats["batches"]), 4) for k, v in pipe.stats.items()
-                                                                if k != "batches"} if pipe is not None else None),
-                                    "source": f"{nfiles} JPEG files (quality 90, 8 sizes 256x341 ... 600x800) in an image folder, read + "
-                                              "decoded by the CLI's loader (see decoder), Resize + CenterCrop + scoring on the device; "
-                                              "bound by the host cores this container is given (decode_workers = its CPU quota)"}
-            finally:
-                shutil.rmtree(root, ignore_errors=True)
-        except ImportError as e:
-            out["host_jpeg"] = {"skipped": f"Pillow unavailable ({e})"}
-    return out
-
-
-def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3):
-    """Throughput of one more arm on the same workload, 3 timed steps after one warm-up step, outside the timed region
-    of the headline number: (images/s, GEMM-family TFLOP/s by HIP events, fraction of that dtype's dense MFMA peak)."""
-    import torch
-
-    from mcm_amd.engine import NativeCLIP
-
-    net = NativeCLIP(geo, sd, device=device, precision=precision, max_batch=B, weight_operands=weight_operands,
-                     max_prompt_tokens=max(K * ids.shape[1], 77))
-    try:
-        txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
-        out = torch.empty(B, device=px.device)
-        net.score_images(px, txt, 1.0, "MCM", out=out)
-        net.profile(True)
-        net.profile_read()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            net.score_images(px, txt, 1.0, "MCM", out=out)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        g = net.profile_read()["gemm"]
-        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
-        peak = MFMA_PEAK_TFLOPS[precision]
-        return {"images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                "gemm_tflops": ach, "peak_tflops": peak, "frac": ach / peak if ach else None,
-                "split_weight_gemms": net.split_weights, "finite": bool(torch.isfinite(out).all())}
-    finally:
-        net.close()
+def short_line(d):
+    """The ONE line the driver parses: the contract keys verbatim, `roofline` / `cpu_baseline` as the task defines them, and
+    one scalar (or a flat dict of scalars) per side leg.  `d` is the full record (what bench_detail.json holds).  Anything
+    that could grow with the number of OOD sets, arms or shapes stays in the detail file."""
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 7), _r(line["ms_per_step"], 6)
+    line["config"] = {k: _get(d, "config", k) for k in ("workload", "batch_per_gpu", "prompts", "parallelism")}
+    if d.get("collective"):
+        line["collective"] = str(d["collective"])[:120]
+    for k in ("harness", "note"):
+        if d.get(k):
+            line[k] = str(d[k])[:160]
+    rf = d.get("refined")
+    if rf:
+        line["value_refined"] = _r(rf.get("images_per_sec"), 7)
+        line["refined"] = {k: _r(rf.get(k)) for k in ("images", "rescored", "rescored_exact", "seconds", "seconds_refine",
+                                                       "rescorer", "fpr95_images_vs_fp32_arm_max_set", "error") if k in rf}
+    ro = d.get("roofline")
+    if ro:
+        line["roofline"] = {k: _r(ro.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                        "avg_launch_us", "flop_per_launch", "sustained_sclk_mhz")}
+        line["roofline"]["kernel"] = str(ro.get("kernel"))[:64]
+        line["roofline"]["traffic_source"] = "live rocprofv3 --pmc" if str(ro.get("traffic_source", "")).startswith("measured in this run") \
+            else ("committed profiles/" if ro.get("traffic") else None)
+    hb = d.get("roofline_hbm_kernels")
+    if hb:
+        line["roofline_hbm"] = {k: {"gbs": _r(v.get("achieved"), 4), "frac": _r(v.get("frac"), 3), "us": _r(v.get("avg_launch_us"), 4)}
+                                for k, v in hb.items()}
+    if d.get("kernel_ms_per_step"):
+        line["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in d["kernel_ms_per_step"].items() if v}
+    cb = d.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "value_hoisted", "unit", "cores", "kind",
+                                                            "parity_max_abs_dscore_vs_native", "error") if k in cb}
+        if cb.get("sample"):
+            line["cpu_baseline"]["sample"] = str(cb["sample"])[:96]
+    if d.get("sustained_images_per_sec"):
+        line["sustained"] = {"img_s": _r(d["sustained_images_per_sec"]), "sclk_mhz": _r(_get(d, "sustained", "sclk_mhz_mean"), 4),
+                             "power_w": _r(_get(d, "sustained", "power_w_mean"), 4)}
+    for key in ("arms", "configs"):
+        if d.get(key):
+            line[key] = {n: ({"img_s": _r(a.get("images_per_sec")), "frac": _r(a.get("frac"), 3)} if "error" not in a
+                             else {"error": str(a["error"])[:60]}) for n, a in d[key].items()}
+    if d.get("ingest"):
+        line["ingest"] = {n: _r(v.get("images_per_sec")) if "images_per_sec" in v else str(v.get("error", v.get("skipped")))[:60]
+                          for n, v in d["ingest"].items()}
+    p = d.get("parity")
+    if p and "error" in p:
+        line["parity"] = {"error": str(p["error"])[:160]}
+    elif p:
+        sp = {"vs": p.get("vs"), "meets_1e-4": p.get("meets_1e-4"), "max_set": {}}
+        for regime in ("fp16_exact_weights", "fp32_valued_weights"):
+            src = _get(p, regime, "vs_hf") or _get(p, regime, "vs_fp32_arm")
+            if src:
+                sp["max_set"][regime] = {arm: [_r(_get(v, "max_set", "d_auroc"), 3), _get(v, "max_set", "d_fpr95_images")]
+                                         for arm, v in src.items()}
+        sp["max_set_is"] = "[max over OOD sets |dAUROC|, FPR95 images moved]"
+        op = p.get("operating_point_auroc_0.9")
+        if op:
+            sp["op_auroc_0.9"] = {arm: [_r(v.get("d_auroc"), 3), v.get("d_fpr95_images")] for arm, v in op.get("arms", {}).items()}
+        line["parity"] = sp
+    line["seconds"] = _r(sum((d.get("leg_seconds") or {}).values()), 4)
+    line["detail"] = d.get("detail_file", "bench_detail.json")
+    return line
 
 
 def respawn_under_torchrun(n):
@@ -476,7 +154,7 @@ def respawn_under_torchrun(n):
     sys.exit(subprocess.call(cmd))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -490,47 +168,86 @@ def main():
                          "fp16: one fp16 operand per weight is lossless) or as drawn (fp32-valued: the 16-bit arms then run "
                          "the split-weight GEMMs unless --weight-operands single)")
     ap.add_argument("--weight-operands", default="auto", choices=["auto", "single", "split"])
-    ap.add_argument("--cpu-seconds", type=float, default=150.0,
+    ap.add_argument("--quick", action="store_true", help="the timed region and its roofline only: every side leg off")
+    ap.add_argument("--cpu-seconds", type=float, default=120.0,
                     help="hard cap on the CPU baseline's timed part (it stops after 256 images); 0 disables it")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="0 disables the sustained-throughput leg")
-    ap.add_argument("--ingest", default="host-u8,host-raw,host-jpeg",
+    ap.add_argument("--ingest", default="host-u8,host-raw",
                     help="comma list of ingest legs reported next to the device-resident number (N = 1): host-u8 (pinned "
                          "224x224 uint8 crops -> copy stream -> mcm_score_u8), host-raw (variable-size decoded images -> one "
-                         "packed copy -> resize/crop on the device -> mcm_score_u8), host-jpeg (an image folder of JPEG files through the "
-                         "CLI's loader: Pillow decode on host threads, then the host-raw path); 'none' skips them")
+                         "packed copy -> resize/crop on the device -> mcm_score_u8), host-jpeg (an image folder of JPEG files "
+                         "through the CLI's loader; not in the default: host-core bound); 'none' skips them")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (mcm_amd.engine.GraphedScorer) instead of launching its "
                          "~110 kernels: what a small-batch caller would do (launch-bound below batch ~64); per-kernel events off")
     ap.add_argument("--no-live-traffic", action="store_true",
-                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~40 s); the committed "
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes); the committed "
                          "profiles/*_traffic.json is reported instead")
     ap.add_argument("--no-arms", action="store_true", help="skip the 3-step runs of the other precision arms (N = 1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 3-step runs of BASELINE configs 2 and 4 (N = 1)")
+    ap.add_argument("--no-refined", action="store_true", help="skip the config-3-sized scored-and-refined pass (value_refined)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group even for one rank, so that the score all-gather really runs "
                          "(torchrun --nproc-per-node 1: RCCL on the one device)")
     ap.add_argument("--no-drift", action="store_true", help="skip the AUROC/FPR95 parity leg (N = 1 only)")
     ap.add_argument("--no-hf", action="store_true", help="parity leg without the HF-on-device reference scorer")
+    ap.add_argument("--parity-regimes", default="fp16-exact",
+                    help="comma list of weight regimes of the parity leg: fp16-exact (with HF on the device), fp32 (vs the "
+                         "exact-fp32 arm only; tests/test_gpu_headline_parity.py asserts it on every round-end run)")
     ap.add_argument("--drift-n", type=int, nargs=2, default=[50000, 10000], metavar=("N_ID", "N_OOD"))
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
-    ap.add_argument("--gemm-variant", type=int, default=-1,
-                    help="A/B hook: >= 0 loads libmcm_hip_harness.so and forces a GEMM kernel variant "
-                         "(mcm_debug_gemm_variant); -1 = the shipped library and its own choice")
-    ap.add_argument("--qkv-chunks", type=int, default=1, help="A/B hook (harness library): QKV + attention per batch chunk")
-    ap.add_argument("--gemm-dbg", type=int, default=0, help="A/B hook (harness library): GEMM ablation / A-B bits")
-    ap.add_argument("--attn-variant", type=int, default=-1, help="A/B hook (harness library): 16-bit attention kernel arm")
-    ap.add_argument("--ln-fold", type=int, default=-1, help="A/B hook (harness library): 0 = every LayerNorm as its own launch")
-    ap.add_argument("--ln-tail", type=int, default=-1, help="A/B hook (harness library): 1 = LayerNorm in the tail of the residual GEMMs")
-    ap.add_argument("--patch-fold", type=int, default=-1, help="A/B hook (harness library): 0 = patchify + plain patch GEMM (rounds 1 - 3)")
-    ap.add_argument("--group-n", type=int, default=0, help="A/B hook (harness library): N tiles of the persistent walk in groups of g")
-    ap.add_argument("--nsplit", type=int, default=1, help="A/B hook (harness library): QKV / fc1 as n column-block launches")
+    ap.add_argument("--harness", default="",
+                    help="A/B hooks of libmcm_hip_harness.so as k=v[,k=v]: " + ", ".join(sorted(HARNESS_KEYS)) +
+                         " (EXPERIMENTS.md); the line is then labelled and is not the shipped policy")
     ap.add_argument("--idle-ms", type=float, default=-1.0,
-                    help="measurement hook (DESIGN.md 5.5, the energy reading of the step): >= 0 = synchronise after every "
+                    help="measurement hook (EXPERIMENTS.md, the energy reading of the step): >= 0 = synchronise after every "
                          "timed step and leave the device idle for this long; the line is then NOT a throughput figure")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every kernel of every N-th timed step with HIP events (each pair costs "
                          "~3 us of stream serialisation: all steps = -2.3 %% throughput, every 4th = -0.6 %%)")
-    args = ap.parse_args()
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes")
+    args = ap.parse_args(argv)
+    args.harness_kv = {}
+    for kv in filter(None, args.harness.split(",")):
+        k, _, v = kv.partition("=")
+        if k not in HARNESS_KEYS:
+            ap.error(f"unknown --harness key {k!r}")
+        args.harness_kv[k] = int(v)
+    if args.quick:
+        args.cpu_seconds = args.sustain_seconds = 0.0
+        args.ingest = "none"
+        args.no_live_traffic = args.no_arms = args.no_configs = args.no_refined = args.no_drift = True
+    return args
+
+
+def hbm_kernels(prof, n_prof, geo, B, precision):
+    """The HBM-bound kernels of the step against the HBM roof (north_star: "rocprof HBM GB/s ... against peak"):
+    ALGORITHMIC bytes of one step ÷ HIP-event time of that family in one step.  out-proj is the one GEMM shape that is
+    HBM-bound (N = K = width: its fp32 read-modify-write of the residual outweighs its FLOP at the machine balance): X in,
+    W in, residual read + written in fp32."""
+    M, D, L, es = B * geo.v_tokens, geo.v_width, geo.v_layers, 2 if precision != "fp32" else 4
+    ln_bytes = ((2 * (L - 1) + 1) * M * D * (4 + es)      # layer_norm1/2 of the full layers + the last layer_norm1
+                + B * D * (4 + es)                          # the last layer's layer_norm2: CLS rows only
+                + M * D * 4)                                # the fused pre_layrnorm pass also rewrites x in fp32
+    at_bytes = (L - 1) * M * 4 * D * es + (M * 2 * D * es + 2 * B * D * es)   # qkv in + out; last layer: K, V + CLS
+    op_bytes = (L - 1) * (M * D * es + D * D * es + 2 * M * D * 4)              # full layers; the last one is CLS-only
+    hbm = {}
+    for name, key, nbytes in (("layernorm", "layernorm", ln_bytes), ("attention", "attention", at_bytes),
+                              ("outproj", "gemm_outproj", op_bytes)):
+        p = prof.get(key)
+        if not p or not p.get("ms"):
+            continue
+        ms = p["ms"] / n_prof
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        hbm[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "frac_of_measured_copy_rate": gbs / 6290.0, "algorithmic_bytes_per_step": nbytes, "ms_per_step": ms,
+                     "avg_launch_us": 1e3 * p["ms"] / p["launches"] if p.get("launches") else None}
+    return hbm
+
+
+def main():
+    args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         respawn_under_torchrun(args.gpus)
 
@@ -567,33 +284,20 @@ def main():
     sd = synth_state_dict(geo, 0, args.weights_regime)
     K, B = args.prompts, args.batch
     ids, mask = make_token_ids(K, seed=2)
-    net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B,
-                     max_prompt_tokens=max(K * ids.shape[1], 77), weight_operands=args.weight_operands, harness=args.gemm_variant >= 0 or args.qkv_chunks > 1 or args.gemm_dbg != 0 or args.attn_variant >= 0 or args.ln_fold >= 0 or args.ln_tail >= 0 or args.nsplit > 1 or args.group_n > 0 or args.patch_fold >= 0)
-    if args.gemm_variant >= 0 and net._lib.mcm_debug_gemm_variant(args.gemm_variant) != 0:
-        raise SystemExit(f"unknown --gemm-variant {args.gemm_variant}")
-    if args.attn_variant >= 0 and net._lib.mcm_debug_attention_variant(args.attn_variant) != 0:
-        raise SystemExit(f"unknown --attn-variant {args.attn_variant}")
-    if args.ln_fold >= 0:
-        net._lib.mcm_debug_ln_fold(args.ln_fold)
-    if args.ln_tail >= 0:
-        net._lib.mcm_debug_ln_tail(args.ln_tail)
-    if args.patch_fold >= 0:
-        net._lib.mcm_debug_patch_fold(args.patch_fold)
-    if args.group_n > 0 and net._lib.mcm_debug_gemm_group_n(args.group_n) != 0:
-        raise SystemExit("bad --group-n")
-    if args.nsplit > 1 and net._lib.mcm_debug_nsplit(args.nsplit) != 0:
-        raise SystemExit("bad --nsplit")
-    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
-                                normalize=True)
-    if args.qkv_chunks > 1 and net._lib.mcm_debug_qkv_chunks(args.qkv_chunks) != 0:
-        raise SystemExit("bad --qkv-chunks")
-    if args.gemm_dbg:
-        net._lib.mcm_debug_gemm_dbg(args.gemm_dbg)
+    net = NativeCLIP(geo, sd, device=local, precision=args.precision, max_batch=B, max_prompt_tokens=max(K * ids.shape[1], 77),
+                     weight_operands=args.weight_operands, harness=bool(args.harness_kv))
+    late = {k: v for k, v in args.harness_kv.items() if k in ("qkv_chunks", "gemm_dbg")}  # after the text tower ran
+    for k, v in args.harness_kv.items():
+        if k not in late and getattr(net._lib, HARNESS_KEYS[k])(v) != 0:
+            raise SystemExit(f"--harness {k}={v} refused")
+    txt = net.get_text_features(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), normalize=True)
+    for k, v in late.items():
+        if getattr(net._lib, HARNESS_KEYS[k])(v) != 0:
+            raise SystemExit(f"--harness {k}={v} refused")
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     nbuf = min(4, max(1, args.steps))
-    bufs = [torch.randn((B, 3, geo.image_size, geo.image_size), generator=gen, device=dev)
-            for _ in range(nbuf)]
+    bufs = [torch.randn((B, 3, geo.image_size, geo.image_size), generator=gen, device=dev) for _ in range(nbuf)]
     scores = torch.empty((args.steps, B), device=dev)
 
     def barrier():
@@ -605,7 +309,6 @@ def main():
         from mcm_amd.engine import GraphedScorer
 
         args.no_profile = True
-        graphs = []
         graphs = [GraphedScorer(net, B, txt, 1.0, "MCM", input=b) for b in bufs]
 
     def step(i, out):
@@ -658,10 +361,13 @@ def main():
     first_scores = scores[0][:nb_cpu].clone()  # step 0 scored bufs[0]; the sustained leg overwrites scores[]
     leg_done("timed_steps")
 
+    side = rank == 0 and ws == 1   # the side legs: one GPU, rank 0
+    from tools import bench_legs as bl
+
     sustained = None
     if args.sustain_seconds > 0:  # every rank runs it (the chip-level power state is what is being measured)
         n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
-        sampler = SmiSampler() if rank == 0 else None
+        sampler = bl.SmiSampler() if rank == 0 else None
         if sampler:
             sampler.start()
         barrier()
@@ -675,14 +381,14 @@ def main():
         sustained = {"steps": n_sus, "seconds": dts, "images_per_sec": ws * n_sus * B / dts}
         if sampler:
             sustained.update(sampler.stop())
+        leg_done("sustained")
 
-    leg_done("sustained")
     ingest = None
-    if ws == 1 and args.ingest != "none":
+    if side and args.ingest != "none":
         ingest = {}
         for leg in args.ingest.split(","):  # a side leg that fails says so in the line; it never costs the headline number
             try:
-                ingest.update(ingest_legs(net, txt, B, max(6, min(args.steps, 12)), {leg}))
+                ingest.update(bl.ingest_legs(net, txt, B, max(6, min(args.steps, 12)), {leg}))
             except Exception as e:
                 ingest[leg.replace("-", "_")] = {"error": f"{type(e).__name__}: {e}"[:400]}
                 torch.cuda.synchronize()
@@ -690,8 +396,7 @@ def main():
 
     line = None
     if rank == 0:
-        total_images = ws * args.steps * B
-        value = total_images / dt
+        value = ws * args.steps * B / dt
         nominal = geo.vision_flops_per_image() / 1e9 + 2e-9 * geo.proj_dim * K
         line = {
             "metric": "images/sec MCM-scored (CLIP-B/16, 1000 prompts)",
@@ -699,37 +404,20 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"MCM scoring, CLIP-{args.ckpt} ({geo.v_layers}L vision tower, "
-                                   f"random-init weights), K={K} prompts pre-encoded, batch {B}/GPU, "
-                                   f"fp32 NCHW pixels resident in HBM → [B] scores",
+            "config": {"workload": f"MCM scoring, CLIP-{args.ckpt} ({geo.v_layers}L vision tower, random-init weights), "
+                                   f"K={K} prompts pre-encoded, batch {B}/GPU, fp32 NCHW pixels resident in HBM -> [B] scores",
                        "batch_per_gpu": B, "prompts": K, "parallelism": f"image-sharded x{ws}"},
             "gflop_per_image": nominal,
             "weights": {"regime": args.weights_regime, "gemm_weight_elements_not_operand_numbers": net.weights_inexact,
                         "split_weight_gemms": net.split_weights},
         }
-        if args.qkv_chunks > 1:
-            line["harness_qkv_chunks"] = args.qkv_chunks
-        if args.gemm_dbg:
-            line["harness_gemm_dbg"] = args.gemm_dbg
-        if args.attn_variant >= 0:
-            line["harness_attn_variant"] = args.attn_variant
-        if args.ln_fold >= 0:
-            line["harness_ln_fold"] = args.ln_fold
-        if args.ln_tail >= 0:
-            line["harness_ln_tail"] = args.ln_tail
-        if args.nsplit > 1:
-            line["harness_nsplit"] = args.nsplit
-        if args.group_n > 0:
-            line["harness_group_n"] = args.group_n
-        if args.patch_fold >= 0:
-            line["harness_patch_fold"] = args.patch_fold
+        if args.harness_kv:
+            line["harness"] = f"libmcm_hip_harness.so with {args.harness} forced: an A/B run, not the shipped policy"
         if args.graph:
             line["hip_graph"] = "every step is one replay of a captured hipGraph (mcm_amd.engine.GraphedScorer)"
         if args.idle_ms >= 0:
             line["idle_ms_between_steps"] = args.idle_ms
             line["note"] = "measurement run with an idle device between steps: `value` is not a throughput figure"
-        if args.gemm_variant >= 0:
-            line["harness"] = f"libmcm_hip_harness.so, GEMM variant {args.gemm_variant} forced (A/B run, not the shipped policy)"
         if coll:
             line["collective"] = ("gloo: %d ranks share %d device(s), RCCL refuses duplicate devices — logic "
                                   "check, not a scaling number" % (ws, ndev)) if shared else \
@@ -744,18 +432,17 @@ def main():
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            traffic, traffic_src, traffic_shapes = pmc_traffic("gemm") if B == 512 else (None, None, None)
             line["roofline"] = {
-                "bound": "mfma", "kernel": "persistent 256x256 GEMM family: gemm_pp_kernel + gemm_p256_kernel (all GEMM launches of a step)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak if ach else None,
-                "traffic": traffic, "traffic_source": traffic_src,
+                "bound": "mfma", "kernel": "GEMM family (gemm_pp + gemm_p256 + tile kernels: every GEMM launch of a step)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if ach else None, "traffic": None,
                 "traffic_unit": "L2<->fabric bytes per launch (L2 misses + write-backs, Infinity-Cache hits included: an "
-                                "upper bound on HBM bytes) = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC, profiles/",
-                "traffic_per_shape": traffic_shapes,
+                                "upper bound on HBM bytes) = (2*FETCH_SIZE+WRITE_SIZE)*1024, rocprofv3 PMC",
                 "avg_launch_us": 1e3 * g["ms"] / g["launches"] if g["launches"] else None,
                 "flop_per_launch": g["flops"] / g["launches"] if g["launches"] else None,
             }
+            if side and B == 512:
+                tr, src, shapes = bl.pmc_traffic("gemm")
+                line["roofline"].update(traffic=tr, traffic_source=src, traffic_per_shape=shapes)
             if sustained and "sclk_mhz_mean" in sustained:
                 # the part runs this kernel family at its package power limit: the clock it sustains, not the
                 # 2.4 GHz the 2.5 PF/s peak assumes, is what `frac` is achieved at
@@ -763,47 +450,43 @@ def main():
                 line["roofline"]["sustained_power_w"] = sustained["power_w_mean"]
                 line["roofline"]["frac_of_peak_at_sustained_clock"] = \
                     (ach / (peak * sustained["sclk_mhz_mean"] / 2400.0)) if ach else None
-            # the two HBM-bound kernel families of the step against the HBM roof (north_star: "rocprof HBM GB/s ...
-            # against peak"): ALGORITHMIC bytes of one step / HIP-event time of that family in one step
-            M, D, L, es = B * geo.v_tokens, geo.v_width, geo.v_layers, 2 if args.precision != "fp32" else 4
-            ln_bytes = ((2 * (L - 1) + 1) * M * D * (4 + es)      # layer_norm1/2 of the full layers + the last layer_norm1
-                        + B * D * (4 + es)                          # the last layer's layer_norm2: CLS rows only
-                        + M * D * 4)                                # the fused pre_layrnorm pass also rewrites x in fp32
-            at_bytes = (L - 1) * M * 4 * D * es + (M * 2 * D * es + 2 * B * D * es)   # qkv in + out; last layer: K, V + CLS
-            hbm = {}
-            for name, nbytes in (("layernorm", ln_bytes), ("attention", at_bytes)):
-                ms = prof[name]["ms"] / n_prof
-                if ms > 0:
-                    gbs = nbytes / (ms * 1e-3) / 1e9
-                    hbm[name] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                                 "frac_of_measured_copy_rate": gbs / 6290.0, "algorithmic_bytes_per_step": nbytes,
-                                 "ms_per_step": ms}
-            line["roofline_hbm_kernels"] = hbm
-            tot = sum(v["ms"] for v in prof.values())
-            executed = sum(v["flops"] for v in prof.values()) / n_prof / B / 1e9
+            line["roofline_hbm_kernels"] = hbm_kernels(prof, n_prof, geo, B, args.precision)
+            fam = {k: v for k, v in prof.items() if not k.startswith("gemm_")}   # gemm_<shape> entries are subsets of "gemm"
+            tot = sum(v["ms"] for v in fam.values())
+            executed = sum(v["flops"] for v in fam.values()) / n_prof / B / 1e9
             line["kernel_ms_per_step"] = {k: round(v["ms"] / n_prof, 4) for k, v in prof.items()}
             line["profiled_steps"] = n_prof
-            line["kernel_time_frac"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if tot}
+            line["kernel_time_frac"] = {k: round(v["ms"] / tot, 4) for k, v in fam.items() if tot}
             # effective: nominal tower FLOP per image over wall time.  The last layer runs its MLP / out-proj
             # for the CLS row only (identical results), so the FLOP actually executed are lower:
             line["end_to_end_mfma_frac_effective"] = value * nominal / 1e3 / ws / peak
             line["gflop_per_image_executed"] = executed
             line["end_to_end_mfma_frac_executed"] = value * executed / 1e3 / ws / peak
-        if ws == 1 and args.cpu_seconds > 0:
+        leg_done("line")
+        if side and args.cpu_seconds > 0:
             pxs = [b[:nb_cpu].cpu() for b in bufs]  # the batches the native run scored (bufs[0] first)
             native = first_scores.cpu().numpy() if args.steps >= 1 else None
-            leg_done("line")
             try:
-                line["cpu_baseline"] = cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
+                line["cpu_baseline"] = bl.cpu_baseline(geo, sd, ids, mask, K, pxs, args.cpu_seconds, native)
             except Exception as e:
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             leg_done("cpu_baseline")
+    px0 = bufs[0]
+    del bufs, scores
+    if side and not args.no_refined and args.precision != "fp32":
+        # throughput AT PARITY: config 3's sizes scored by this arm and threshold-refined, wall clock, same handle
+        try:
+            line["refined"] = bl.refined_leg(net, geo, sd, txt, ids, mask, B, K, local)
+        except Exception as e:
+            line["refined"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            torch.cuda.synchronize()
+        leg_done("refined")
     net.close()
-    if rank == 0 and ws == 1 and line.get("roofline") and not args.no_live_traffic and not args.no_profile:
+    if side and line.get("roofline") and not args.no_live_traffic and not args.no_profile:
         # roofline.traffic witnessed by this very run (the handle is closed: the children have the device to themselves)
         torch.cuda.empty_cache()
         try:
-            fam, per, note = live_pmc_traffic(args)
+            fam, per, note = bl.live_pmc_traffic(args)
         except Exception as e:
             fam, per, note = None, None, f"{type(e).__name__}: {e}"[:200]
         if fam is not None:
@@ -811,23 +494,21 @@ def main():
         else:
             line["roofline"]["traffic_source"] = f"{line['roofline'].get('traffic_source')} (committed record; live PMC pass unavailable: {note})"
         leg_done("live_pmc_traffic")
-    px0 = bufs[0]
-    del bufs, scores
-    if rank == 0 and ws == 1 and not args.no_arms:
+    if side and not args.no_arms:
         # The other arms on the same workload, witnessed by the same run (3 timed steps each): the exact-fp32 arm (the
         # reference's own precision: fp32 everywhere), bf16 (the dtype BASELINE.md names), and the split-weight fp16 arm on
         # fp32-VALUED seeded weights (what a checkpoint that is not fp16-exact runs, include/mcm.h MCM_WEIGHTS_*)
         arms = {}
         for name, prec, regime, wo in (("fp32", "fp32", args.weights_regime, "auto"),
-                                       ("bf16", "bf16", args.weights_regime, "auto"),       # fp16 values are not bf16 numbers: split
                                        ("bf16_single_operand", "bf16", args.weights_regime, "single"),  # BASELINE.md's dtype, rounded weights
+                                       ("bf16_split", "bf16", args.weights_regime, "auto"),       # fp16 values are not bf16 numbers: split
                                        ("fp16_split_weights", "fp16", "fp32", "split")):
             if prec == args.precision and wo == args.weight_operands and regime == args.weights_regime:
                 continue
             torch.cuda.empty_cache()
             try:
-                arms[name] = arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
-                                     ids, px0, local)
+                arms[name] = bl.arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
+                                        ids, px0, local)
             except Exception as e:
                 arms[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             arms[name]["weights_regime"] = regime
@@ -835,15 +516,31 @@ def main():
         leg_done("arms")
     del px0
     torch.cuda.empty_cache()
+    if side and not args.no_configs:
+        # BASELINE configs 4 and 2 on this device (3 timed steps each): ViT-L/14 fp16 batch 256, K = 1000; B/16 K = 100 bf16 / fp16
+        line["configs"] = bl.config_legs(local)
+        leg_done("configs")
     if rank == 0:
-        if ws == 1 and not args.no_drift and args.precision != "fp32":
+        if side and not args.no_drift and args.precision != "fp32":
             try:
-                line["parity"] = parity_leg(args, K, B, local)
+                line["parity"] = bl.parity_leg(args, K, B, local)
             except Exception as e:
                 line["parity"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             leg_done("parity")
         line["leg_seconds"] = legs
-        print(json.dumps(line), flush=True)
+        written = []
+        for path in dict.fromkeys([args.detail] + ([os.path.join(ROOT, "gpurun_out", "bench_detail.json")]
+                                                    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])):
+            try:
+                with open(path, "w") as fh:
+                    json.dump(line, fh, indent=1)
+                written.append(os.path.relpath(path, ROOT))
+            except OSError:
+                pass
+        line["detail_file"] = written[0] if written else None
+        out = json.dumps(short_line(line), separators=(",", ":"))
+        assert len(out) <= LINE_LIMIT, len(out)
+        print(out, flush=True)
     if coll:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -82,9 +82,10 @@ def process_args(argv=None):
     p.add_argument("--tokenizer-dir", default=None, help="directory with the checkpoint's vocab.json + merges.txt")
     p.add_argument("--data-dir", default="data", help="the reference's data/ directory (class-name files)")
     p.add_argument("--decoder", default=None, choices=["device", "pillow"],
-                   help="how image files under --root-dir are decoded: device (default; JPEG entropy decoding on host threads, "
-                        "the rest of libjpeg's work + Resize + CenterCrop on the GPU, Pillow only for files that are not Huffman "
-                        "YCbCr / grayscale JPEGs) or pillow (Pillow in worker processes, the reference's route); same pixels either way")
+                   help="how image files under --root-dir are decoded: pillow (default: Pillow in worker processes — the reference's "
+                        "decoder, utils/train_eval_util.py:96-146 through torchvision's ImageFolder) or device (opt-in: JPEG entropy "
+                        "decoding on host threads, the rest of libjpeg's work + Resize + CenterCrop on the GPU, Pillow for files that "
+                        "are not Huffman YCbCr / grayscale JPEGs); same pixels either way")
     args = p.parse_args(argv)
     if args.decoder:
         os.environ["MCM_GPU_JPEG"] = "1" if args.decoder == "device" else "0"

@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define MCM_ABI_VERSION 2 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
+#define MCM_ABI_VERSION 3 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
                           * arm and mcm_weights_operand_exact; mcm_op_linear_ex / mcm_op_split_weight; the round-2
-                          * mcm_debug_* exports live in libmcm_hip_harness.so only */
+                          * mcm_debug_* exports live in libmcm_hip_harness.so only
+                          * 3: MCM_KC_COUNT 7 -> 11 (per-shape GEMM classes: mcm_profile_read's arrays grew) */
 
 /* error codes */
 #define MCM_OK 0
@@ -304,7 +305,12 @@ int mcm_tokenizer_encode(mcm_tokenizer* t, const char* const* texts, int32_t n, 
 #define MCM_KC_POOL_PROJECT 4
 #define MCM_KC_SCORE 5
 #define MCM_KC_EMBED 6
-#define MCM_KC_COUNT 7
+/* sub-classes of MCM_KC_GEMM (ABI 3): the whole-batch GEMM shapes of an encoder layer, counted in MCM_KC_GEMM as well */
+#define MCM_KC_GEMM_QKV 7
+#define MCM_KC_GEMM_OUTPROJ 8
+#define MCM_KC_GEMM_FC1 9
+#define MCM_KC_GEMM_FC2 10
+#define MCM_KC_COUNT 11
 int mcm_profile_enable(mcm_handle* h, int32_t on);
 /* ms_out[MCM_KC_COUNT], launches_out[MCM_KC_COUNT], flops_out[MCM_KC_COUNT] (algorithmic
  * FLOP issued by that class since the last read; GEMM counts 2*M*N*K of the *logical*

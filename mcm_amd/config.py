@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass, asdict, replace
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2

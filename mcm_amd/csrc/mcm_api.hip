@@ -48,7 +48,7 @@ struct Tower {
 
 struct EvPair {
   hipEvent_t a, b;
-  int kc;
+  int kc, kc2;  // kc2: a sub-class of kc that also gets this launch (MCM_KC_GEMM_*), -1 = none
 };
 
 }  // namespace
@@ -159,7 +159,7 @@ struct Scope {
   hipStream_t s;
   int kc;
   EvPair* ev = nullptr;
-  Scope(mcm_handle* h_, hipStream_t s_, int kc_, double fl) : h(h_), s(s_), kc(kc_) {
+  Scope(mcm_handle* h_, hipStream_t s_, int kc_, double fl, int kc2 = -1) : h(h_), s(s_), kc(kc_) {
     if (!h->prof) return;
     if (h->ev_used == h->ev_pool.size()) {
       EvPair e;
@@ -169,8 +169,13 @@ struct Scope {
     }
     ev = &h->ev_pool[h->ev_used++];
     ev->kc = kc;
+    ev->kc2 = kc2;
     h->launches[kc] += 1;
     h->flops[kc] += fl;
+    if (kc2 >= 0) {
+      h->launches[kc2] += 1;
+      h->flops[kc2] += fl;
+    }
     (void)hipEventRecord(ev->a, s);
   }
   ~Scope() {
@@ -224,7 +229,13 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
 #endif
   a.rev = next_dir(h) ? 1 : 0;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
-  Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K);  // algorithmic FLOP: the logical K, split or not
+  // the four whole-batch shapes of an encoder layer also get a class of their own (out-proj is the HBM-bound one:
+  // bench.py roofline_hbm_kernels); small launches (CLS-only last layer, short prompt banks) count in MCM_KC_GEMM only
+  int shape = -1;
+  if (a.M > 4096)
+    shape = epi == EPI_STORE ? MCM_KC_GEMM_QKV : epi == EPI_GELU ? MCM_KC_GEMM_FC1
+          : epi == EPI_RESID ? (a.N == a.K ? MCM_KC_GEMM_OUTPROJ : MCM_KC_GEMM_FC2) : -1;
+  Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K, shape);  // algorithmic FLOP: the logical K, split or not
   // Row padding into the workspace: the ping-pong kernel takes problems made of whole 256-row tiles only, so a
   // dense activation GEMM whose M is not a multiple of 256 is run on M rounded up.  The extra rows exist (every
   // activation buffer is allocated in whole 256-row tiles and zeroed once), every output row depends on its own
@@ -1172,6 +1183,7 @@ int mcm_profile_read(mcm_handle* h, double* ms_out, int64_t* launches_out, doubl
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
     h->ms_acc[h->ev_pool[i].kc] += ms;
+    if (h->ev_pool[i].kc2 >= 0) h->ms_acc[h->ev_pool[i].kc2] += ms;
   }
   h->ev_used = 0;
   for (int k = 0; k < MCM_KC_COUNT; ++k) {

@@ -30,7 +30,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcm_hip.so")
 # the same sources built with -DMCM_HARNESS: A/B kernel arms + mcm_debug_* switches; tests and tools only
 HARNESS_LIB_PATH = os.path.join(_HERE, "libmcm_hip_harness.so")
-KERNEL_CLASSES = ["patchify", "gemm", "layernorm", "attention", "pool_project", "score", "embed"]
+KERNEL_CLASSES = ["patchify", "gemm", "layernorm", "attention", "pool_project", "score", "embed",
+                  "gemm_qkv", "gemm_outproj", "gemm_fc1", "gemm_fc2"]  # gemm_*: sub-classes of "gemm" (MCM_KC_GEMM_*)
 
 _libs = {}
 

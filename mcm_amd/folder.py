@@ -92,7 +92,7 @@ class ImageFolderU8:
         import torch
 
         paths = [self.dataset.samples[int(i)][0] for i in indices]
-        if os.environ.get("MCM_GPU_JPEG", "1") != "0" and len(paths) >= 8:  # the default route, as in __iter__
+        if os.environ.get("MCM_GPU_JPEG", "0") == "1" and len(paths) >= 8:  # the opt-in device route, as in __iter__
             out = [b.clone() for b in self._jpeg_stream(paths[k:k + self.batch_size] for k in range(0, len(paths), self.batch_size))]
             return out[0] if len(out) == 1 else torch.cat(out)
         if self.workers <= 1 or len(paths) < 32:
@@ -166,10 +166,11 @@ class ImageFolderU8:
             yield dev_batch, torch.tensor([t for _, t in chunk_of(starts[i])], dtype=torch.long)
 
     def __iter__(self) -> Iterator:
-        """Default (MCM_GPU_JPEG unset or 1): `_iter_jpeg`.  MCM_GPU_JPEG=0: decode pool (Pillow in worker processes) → ONE
+        """Default (MCM_GPU_JPEG unset or 0; the CLI's `--decoder pillow`): decode pool (Pillow in worker processes, the
+        reference's decoder) → ONE
         packed pinned buffer per batch → ONE asynchronous copy on a copy stream → Resize + CenterCrop on the device
         (mcm_amd.ingest.PackedImagePipe): batch i+1 is decoded, packed and copied while batch i is scored."""
-        if os.environ.get("MCM_GPU_JPEG", "1") != "0":
+        if os.environ.get("MCM_GPU_JPEG", "0") == "1":
             yield from self._iter_jpeg()
             return
         from .ingest import PackedImagePipe

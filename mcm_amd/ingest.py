@@ -270,7 +270,7 @@ class JpegFilePipe:
         # decoding; this thread waiting for the producer / preparing and launching a batch
         self.stats = {"batches": 0, "producer_wait_slot_s": 0.0, "producer_decode_s": 0.0, "consumer_wait_s": 0.0, "consumer_launch_s": 0.0}
 
-    def _produce(self, batches, q, stop):
+    def _produce(self, batches, q, stop, free):
         import ctypes
         import os
         import time
@@ -288,6 +288,11 @@ class JpegFilePipe:
                     raise ValueError(f"{n} files exceed max_batch {self.max_batch}")
                 s = self.slots[i % len(self.slots)]
                 t0 = time.perf_counter()
+                # the slot is this thread's only once the consumer has handed it back (after its `consumed` event is recorded:
+                # ADVICE r4 — with the queue alone a 2-slot pipe re-entered slot 0 while batch 0 was still being uploaded)
+                while not free[i % len(self.slots)].acquire(timeout=0.2):
+                    if stop.is_set():
+                        return
                 if s.used:
                     s.consumed.synchronize()
                     s.copied.synchronize()
@@ -339,9 +344,13 @@ class JpegFilePipe:
 
         import torch
 
-        q = queue.Queue(maxsize=max(1, len(self.slots) - 2))
+        if getattr(self, "_streaming", False):
+            raise RuntimeError("JpegFilePipe.stream: the previous pass over this pipe is still open (close its generator first)")
+        self._streaming = True
+        q = queue.Queue(maxsize=len(self.slots))
         stop = threading.Event()
-        th = threading.Thread(target=self._produce, args=(iter(batches), q, stop), daemon=True)
+        free = [threading.Semaphore(1) for _ in self.slots]  # slot k may be (re)filled by the producer
+        th = threading.Thread(target=self._produce, args=(iter(batches), q, stop, free), daemon=True)
         th.start()
         try:
             while True:
@@ -384,7 +393,17 @@ class JpegFilePipe:
                     self.net.jpeg_reconstruct(s.dev, s.meta, s.quant, n, s.rgb, offs)
                 out = self.net.resize_crop_packed(s.rgb, offs, hs, ws, out=self.out[i % len(self.slots)][:n])
                 self.stats["consumer_launch_s"] += time.perf_counter() - tg
-                yield out
-                s.consumed.record(torch.cuda.current_stream(self.device))
+                try:
+                    yield out
+                finally:  # also when the generator is closed at the yield: the slot's last reader is recorded either way
+                    s.consumed.record(torch.cuda.current_stream(self.device))
+                    free[i % len(self.slots)].release()
         finally:
             stop.set()
+            try:  # a producer blocked in q.put() sees `stop` within its timeout; one blocked on a slot within 0.2 s
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=30.0)
+            self._streaming = False

@@ -1,0 +1,134 @@
+"""bench.py prints ONE short JSON line (<= 4 KB) and puts everything else into bench_detail.json (a 33.6 KB line
+left the driver's record with `parsed: null`).  CPU-only: `short_line` is pure Python over the full record."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+PI = 3.141592653589793
+
+
+def _delta(per_set=True):
+    d = {"d_auroc": PI * 1e-5, "d_aupr": PI * 1e-6, "d_fpr95": PI * 1e-5, "max_abs_dscore": PI * 1e-8, "rms_dscore": PI * 1e-9,
+         "max_set": {"d_auroc": PI * 1e-5, "d_aupr": PI * 1e-6, "d_fpr95": 2e-4, "d_fpr95_images": 2}}
+    if per_set:
+        d["per_set"] = {n: dict(d["max_set"]) for n in ("iNaturalist", "SUN", "places365", "dtd")}
+    return d
+
+
+def full_record():
+    """A record with every leg present and every string at its longest: what a default N = 1 run collects."""
+    arms = ("fp32_arm", "fp16", "bf16", "fp16+refine", "fp16x2", "fp16:single")
+    regime = {"auroc_fp32_arm": PI / 10, "fpr95_fp32_arm": PI / 4, "seconds": 82.06547983596101,
+              "vs_fp32_arm": {a: _delta() for a in arms}, "vs_hf": {a: _delta() for a in arms},
+              "refine": {"fp16+refine": {"rescored": {n: 123 for n in ("id", "iNaturalist", "SUN", "places365", "dtd")}}}}
+    kernels = ("patchify", "gemm", "layernorm", "attention", "pool_project", "score", "embed", "gemm_qkv", "gemm_outproj",
+               "gemm_fc1", "gemm_fc2")
+    leg = {"images_per_sec": 26355.5597435004, "ms_per_step": 19.42664109519683, "steps": 3, "gemm_tflops": 1053.2809451795,
+           "peak_tflops": 2500.0, "frac": 0.42131237807179994, "split_weight_gemms": False, "finite": True,
+           "weights_regime": "fp16-exact"}
+    return {
+        "metric": "images/sec MCM-scored (CLIP-B/16, 1000 prompts)", "value": 26355.5597435004, "unit": "images/sec", "n_gpus": 1,
+        "steps": 20, "warmup": 5, "ms_per_step": 19.42664109519683, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": "MCM scoring, CLIP-ViT-B/16 (12L vision tower, random-init weights), K=1000 prompts pre-encoded, "
+                               "batch 512/GPU, fp32 NCHW pixels resident in HBM -> [B] scores",
+                   "batch_per_gpu": 512, "prompts": 1000, "parallelism": "image-sharded x1"},
+        "collective": "nccl (RCCL) all_gather_into_tensor of the score shards (device tensors, no host bounce), inside the timed region",
+        "gflop_per_image": 35.13, "weights": {"regime": "fp16-exact"},
+        "refined": {"images_per_sec": 25123.123456, "images": 85640, "seconds": 3.4087654321, "seconds_scoring": 3.26,
+                    "seconds_refine": 0.14876543, "rescored": 879, "rescored_exact": 23,
+                    "rescorer": "split-activation fp16 arm of the same handle, exact-fp32 arm for the inner window",
+                    "fpr95_images_vs_fp32_arm_max_set": 0, "vs_fp32_arm": {n: {"fpr95_images": 0} for n in "abcd"}},
+        "ingest": {"host_u8": dict(leg, source="x" * 300), "host_raw": dict(leg, source="x" * 300),
+                   "host_jpeg": {"error": "RuntimeError: " + "y" * 380}},
+        "sustained_images_per_sec": 26012.123456789, "sustained": {"steps": 300, "sclk_mhz_mean": 1893.123456, "power_w_mean": 1342.98765},
+        "roofline": {"bound": "mfma", "kernel": "GEMM family (gemm_pp + gemm_p256 + tile kernels: every GEMM launch of a step)",
+                     "achieved": 1015.123456789, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.4060493827, "traffic": 1080123456.789,
+                     "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes",
+                     "traffic_unit": "z" * 200, "traffic_per_shape": {f"gemm_{i}": {"l2_fabric_bytes": 1e9, "ratio": 1.38} for i in range(8)},
+                     "avg_launch_us": 321.123456, "flop_per_launch": 3.2e11, "sustained_sclk_mhz": 1893.123456,
+                     "sustained_power_w": 1342.9, "frac_of_peak_at_sustained_clock": 0.5148},
+        "roofline_hbm_kernels": {k: {"bound": "hbm", "achieved": 4371.123456, "peak": 8000.0, "unit": "GB/s", "frac": 0.546390432,
+                                     "frac_of_measured_copy_rate": 0.69, "algorithmic_bytes_per_step": 7.13e9, "ms_per_step": 1.63,
+                                     "avg_launch_us": 134.7123} for k in ("layernorm", "attention", "outproj")},
+        "kernel_ms_per_step": {k: 15.819345 for k in kernels}, "profiled_steps": 5,
+        "kernel_time_frac": {k: 0.8123 for k in kernels},
+        "cpu_baseline": {"cores": 16, "host_cpus": 256, "cpu_quota_cores": 16.0, "torch_default_threads": 128, "unit": "images/sec",
+                         "value": 8.612345678, "value_hoisted": 13.512345678, "kind": "reference",
+                         "seconds": {"warmup_batch": 7.1, "image_part": 19.0, "text_part": 10.7},
+                         "sample": "256 images, batch 64 (K=1000 prompts; value: bank re-encoded per batch as the reference does, "
+                                   "value_hoisted: bank encoded once) after a warm-up (bank + 8 images) of 7.1 s; same seeded weights",
+                         "parity_max_abs_dscore_vs_native": 2.4330802261829376e-08, "parity_images": 64},
+        "arms": {n: dict(leg) for n in ("fp32", "bf16_single_operand", "bf16_split", "fp16_split_weights", "fp16x2_split_activations")},
+        "configs": {n: dict(leg) for n in ("c4_L14_fp16_b256", "c2_B16_K100_bf16", "c2_B16_K100_fp16")},
+        "parity": {"config": "c" * 250, "bar": "b" * 180, "vs": "HF CLIPModel fp32 on this device",
+                   "fp16_exact_weights": regime, "fp32_valued_weights": regime,
+                   "meets_1e-4": {w: {a: False for a in arms} for w in ("fp16_exact_weights", "fp32_valued_weights")},
+                   "operating_point_auroc_0.9": {"arms": {a: {"d_auroc": PI * 1e-6, "d_fpr95": 2.5e-4, "d_fpr95_images": 9}
+                                                          for a in arms[1:]}, "seconds": 18.2}},
+        "leg_seconds": {k: 37.63 for k in ("setup_and_warmup", "timed_steps", "sustained", "ingest", "line", "cpu_baseline",
+                                           "refined", "live_pmc_traffic", "arms", "configs", "parity")},
+        "detail_file": "bench_detail.json",
+    }
+
+
+def test_short_line_stays_under_4_kb_with_every_leg_present():
+    rec = full_record()
+    assert len(json.dumps(rec)) > 12000  # the record itself is the size that broke round 4's parse
+    line = bench.short_line(rec)
+    out = json.dumps(line, separators=(",", ":"))
+    assert len(out) <= bench.LINE_LIMIT, len(out)
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT  # also with json's default separators
+    back = json.loads(out)
+    # the contract keys, verbatim
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert back[k] == rec[k], k
+    assert abs(back["value"] - rec["value"]) < 1e-2 and abs(back["ms_per_step"] - rec["ms_per_step"]) < 1e-4
+    assert back["config"]["workload"] == rec["config"]["workload"] and "model" not in back["config"]
+    ro = back["roofline"]
+    assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-4
+    assert ro["traffic"] and ro["traffic_source"] == "live rocprofv3 --pmc"
+    cb = back["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["cores"] == 16 and cb["unit"] == "images/sec" and cb["sample"] and cb["value"] > 0
+    assert set(back["roofline_hbm"]) == {"layernorm", "attention", "outproj"}
+    assert back["value_refined"] > 0 and back["refined"]["fpr95_images_vs_fp32_arm_max_set"] == 0
+    assert back["parity"]["max_set"]["fp16_exact_weights"]["fp16"] == [3.14e-05, 2]
+    assert back["ingest"]["host_u8"] > 0 and isinstance(back["ingest"]["host_jpeg"], str)
+    assert back["detail"] == "bench_detail.json"
+
+
+def test_short_line_of_a_quick_multi_gpu_record():
+    rec = {k: v for k, v in full_record().items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                          "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                                                          "collective", "roofline", "leg_seconds")}
+    rec["n_gpus"] = 8
+    line = bench.short_line(rec)
+    assert line["n_gpus"] == 8 and "cpu_baseline" not in line and "parity" not in line and line["collective"].startswith("nccl")
+    assert len(json.dumps(line)) < 2048
+
+
+def test_failed_legs_are_said_in_the_line_not_dropped():
+    rec = full_record()
+    rec["parity"] = {"error": "RuntimeError: " + "x" * 600}
+    rec["cpu_baseline"] = {"error": "ImportError: " + "x" * 600}
+    rec["refined"] = {"error": "OutOfMemoryError: " + "x" * 600}
+    rec["arms"]["fp32"] = {"error": "e" * 400}
+    line = bench.short_line(rec)
+    assert "error" in line["parity"] and "error" in line["cpu_baseline"] and "error" in line["refined"]
+    assert "error" in line["arms"]["fp32"] and line["value_refined"] is None
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
+
+
+def test_harness_switches_are_one_option_and_quick_turns_every_leg_off():
+    a = bench.parse_args(["--harness", "gemm_variant=3,ln_tail=1", "--quick"])
+    assert a.harness_kv == {"gemm_variant": 3, "ln_tail": 1}
+    assert a.cpu_seconds == 0 and a.sustain_seconds == 0 and a.ingest == "none"
+    assert a.no_drift and a.no_arms and a.no_configs and a.no_refined and a.no_live_traffic
+    d = bench.parse_args([])
+    assert d.gpus == 1 and d.steps == 20 and d.batch == 512 and d.prompts == 1000 and d.ckpt == "ViT-B/16" and d.precision == "fp16"
+    assert "host-jpeg" not in d.ingest and d.parity_regimes == "fp16-exact"

@@ -105,6 +105,35 @@ def test_file_pipe_equals_the_pillow_route_with_fallbacks_and_errors(net, tmp_pa
     np.testing.assert_array_equal(got, want[:5])
 
 
+def test_two_slot_pipe_never_refills_a_slot_the_consumer_still_reads(net, tmp_path):
+    """with depth 2 the queue alone let the producer re-enter slot 0 while batch 0 was still being uploaded /
+    reconstructed.  Slots are now handed back explicitly after the consumer's last use: 9 small batches through a 2-slot pipe
+    with a slow consumer give Pillow's crops, and a pass abandoned at its first batch leaves the pipe usable."""
+    import time
+
+    from mcm_amd.ingest import JpegFilePipe
+    from oracle import oracle as orc
+
+    paths = []
+    for k in range(36):
+        p = str(tmp_path / f"s{k:02d}.jpg")
+        Image.fromarray(_photo(230 + 7 * (k % 5), 240 + 11 * (k % 7), 300 + k)).save(p, quality=60 + k)
+        paths.append(p)
+    want = np.stack([orc.resize_crop_u8(_pil(p), 224) for p in paths])
+    pipe = JpegFilePipe(net, 4, depth=2, threads=2)
+    assert len(pipe.slots) == 2
+    got = []
+    for b in pipe.stream([paths[i:i + 4] for i in range(0, 36, 4)]):
+        time.sleep(0.02)              # the producer is ahead of the consumer the whole pass
+        got.append(b.clone())
+    np.testing.assert_array_equal(torch.cat(got).cpu().numpy(), want)
+    g = pipe.stream([paths[i:i + 4] for i in range(0, 36, 4)])
+    next(g)
+    g.close()                         # abandoned mid-pass: producer joined, the slot in flight recorded
+    got = torch.cat([b.clone() for b in pipe.stream([paths[i:i + 4] for i in range(0, 36, 4)])]).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
 def test_reconstruction_with_an_odd_max_batch(tmp_path):
     """The staging ring of mcm_jpeg_reconstruct keeps the quantisation tables behind max_batch records; the kernel reads them
     in 16-byte rows, so their offset must be aligned whatever max_batch is (7 records end on an odd multiple of 8 bytes)."""
