@@ -32,7 +32,8 @@ extern "C" {
 #define MCM_ABI_VERSION 3 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
                           * arm and mcm_weights_operand_exact; mcm_op_linear_ex / mcm_op_split_weight; the round-2
                           * mcm_debug_* exports live in libmcm_hip_harness.so only
-                          * 3: MCM_KC_COUNT 7 -> 11 (per-shape GEMM classes: mcm_profile_read's arrays grew) */
+                          * 3: MCM_KC_COUNT 7 -> 11 (per-shape GEMM classes: mcm_profile_read's arrays grew); the
+                          * split-activation arm (mcm_score_x2 ...) and the MCM_LINEAR_SPLIT_X / _OUT flags */
 
 /* error codes */
 #define MCM_OK 0
@@ -178,6 +179,22 @@ int mcm_score(mcm_handle* h, const float* pixels_dev, int32_t B, const float* te
 int mcm_encode_image_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, float* out_dev,
                         void* stream);
 int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const float* text_feat_dev,
+                 int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
+
+/* ---- split-activation arm (ABI 3): the re-scorer of threshold refinement ------------------------------------------
+ * The same image tower on the same weights and the same workspace, fp16 handles only, with every activation that feeds
+ * an MFMA carried as a split pair x = hi + lo of fp16 numbers (~22 significand bits; hi = round(x), lo = round(x - hi))
+ * and every GEMM run as X_hi W^T + X_lo W^T in one fp32 accumulator chain — the mirror image of the split-WEIGHT form
+ * (MCM_WEIGHTS_SPLIT; with split weights as well: four passes per K-step); attention as three MFMA passes per product.
+ * Scores agree with the exact-fp32 arm (MCM_PREC_F32) to fp32 round-off at about half the fp16 arm's throughput, where
+ * the fp32 arm runs at a tenth of it: what mcm_amd/refine.py re-scores the images near the FPR95 threshold with
+ * (reference utils/detection_util.py:66-106: FPR95 is a count at one threshold).  No second handle, no extra weights:
+ * the activation buffers hold rows of twice the width, so B <= mcm_x2_max_batch(h) (about cfg.max_batch / 2; 0 = this
+ * handle is not fp16).  pixel_format: MCM_PIXELS_*.  Asynchronous on `stream`, no allocation, like mcm_score. */
+int mcm_x2_max_batch(const mcm_handle* h);
+int mcm_encode_image_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, int32_t normalize,
+                        float* out_dev, void* stream);
+int mcm_score_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, const float* text_feat_dev,
                  int32_t K, float T, int32_t kind, float* scores_dev, void* stream);
 
 /* Resize(S) + CenterCrop(S), S = cfg.image_size, on the device: the first two
@@ -334,6 +351,12 @@ int mcm_op_linear(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_
 /* mcm_op_linear with flags: bit 0 = w_dev is the split image [N, 2K] written by mcm_op_split_weight (16-bit modes;
  * K % 64 == 0): y = x (W_hi + W_lo)^T, both products in one fp32 accumulator chain. */
 #define MCM_LINEAR_SPLIT_W 1
+/* bit 1 (fp16 mode, K % 64 == 0): x_dev is the SPLIT image [M, 2K] of a logical [M, K] activation — per 64 columns
+ * hi[64] = round(x) then lo[64] = round(x - hi), the layout mcm_op_split_weight writes for M rows — y = (X_hi + X_lo) W^T;
+ * bit 2 (fp16 mode, epilogues 0 / 1, N % 64 == 0): y_dev is written as a split image [M, 2N] (QuickGELU in its exact form).
+ * Together they are the GEMMs of the split-activation arm (mcm_score_x2). */
+#define MCM_LINEAR_SPLIT_X 2
+#define MCM_LINEAR_SPLIT_OUT 4
 int mcm_op_linear_ex(mcm_handle* h, int32_t prec, const void* x_dev, const void* w_dev,
                      const float* bias_dev, void* y_dev, float* resid_dev, int32_t M, int32_t N,
                      int32_t K, int32_t epi, int32_t flags, void* stream);
@@ -345,6 +368,12 @@ int mcm_op_split_weight(mcm_handle* h, int32_t prec, const float* w_dev, int32_t
 int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const float* gamma_dev,
                      const float* beta_dev, void* y_dev, int32_t M, int32_t D, float eps,
                      int32_t out_f32, void* stream);
+/* The split-activation arm's LayerNorm and attention (fp16): y [M, 2D] / out [rows, 2 heads 64] are split images (per 64
+ * columns hi[64] then lo[64]); mcm_op_attention_split reads qkv as a split image [rows, 6 heads 64]. */
+int mcm_op_layernorm_split(mcm_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                           void* y_dev, int32_t M, int32_t D, float eps, void* stream);
+int mcm_op_attention_split(mcm_handle* h, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,
+                           int32_t heads, void* stream);
 /* Multi-head SDPA (modeling_clip.py:259-277,313-331): qkv [nseq*seq_len, 3*heads*64]
  * packed as [q | k | v], head_dim 64, scale 0.125; causal != 0 for the text tower;
  * seq_len ≤ 288.  out [nseq*seq_len, heads*64]. */

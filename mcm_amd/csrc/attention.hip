@@ -258,10 +258,18 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
 
 // PRIO (harness A/B only; 0 = shipped): 1 = s_setprio 1 around the softmax VALU block, 2 = around the MFMA blocks,
 // 3 = static priority 1 for the upper half of the waves
-template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0>
+// X2 (fp16; the split-activation arm): qkv and out are SPLIT images — [rows][6 D] in, [rows][2 D] out,
+// per 64 columns (= one head of q, k or v) hi[64] then lo[64] — and every product runs as three fp16 MFMAs on the hi / lo
+// pairs: S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi, O = V_lo P_hi + V_hi P_lo + V_hi P_hi (the lo x lo terms are below fp32
+// round-off), P itself split AFTER a scale of 2^12 (exp2 of s - max + 12: probabilities of 1 / 197 would otherwise put
+// their lo half into fp16's subnormals; the scale cancels in O / rowsum).  ~22 significand bits on both operands of both
+// GEMMs, the same softmax arithmetic as the 16-bit kernel.  K and V hi AND lo stay in LDS (4 images, 104 KiB at 197 tokens):
+// one workgroup per CU — the arm re-scores a few hundred images per data set.
+template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0, bool X2 = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
                                                                          uint16_t* __restrict__ out, int L,
                                                                          int heads, int qrows, int rev, int hm) {
+  static_assert(!X2 || (PREC == MCM_PREC_F16 && PRIO == 0), "split activations: fp16, the shipped one-pass form");
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP = NT * 16;           // padded keys
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   constexpr uint32_t ONE2 = PREC == MCM_PREC_F16 ? 0x3c003c00u : 0x3f803f80u;  // two 1.0 operands
   char* Ks = smem;               // [LP][128 B], GEMM-style pair/XOR image
   char* Vs = smem + LP * 128;    // [LP][128 B], 32-B segment s stored at s ^ ((key >> 1) & 3)
+  constexpr int LO = 2 * LP * 128;  // X2: the lo images of K and V follow the hi images, same layouts
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -292,35 +301,44 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   // qkv layout.  Row-major (hm = 0): [rows][3 D], a head's q / k / v are 128-B segments of 4.6-KB rows.  Head-major
   // (hm = rows of the array, what the QKV projection writes in the model): [3 heads][hm][64] — this workgroup's Q, K
   // and V are three runs of L x 128 consecutive bytes.  rs: row stride, KO / VO: from a q row to the k / v row (elements)
-  const size_t rs = MCM_HM(hm) ? (size_t)64 : (size_t)3 * D;
-  const size_t KO = MCM_HM(hm) ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
-  const uint16_t* base = MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
+  const size_t rs = X2 ? (size_t)6 * D : MCM_HM(hm) ? (size_t)64 : (size_t)3 * D;
+  const size_t KO = X2 ? (size_t)2 * D : MCM_HM(hm) ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
+  const uint16_t* base = X2 ? qkv + (size_t)seq * L * rs + h * 128
+                            : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
 
   // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
   const int nqb = (qrows + 15) / 16;
   uint4 qf[MAXQB][2];
+  uint4 ql[X2 ? MAXQB : 1][2];  // X2: the lo halves (64 elements further on in the row)
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
     const int qr = min((wq + NW * i) * 16 + fr, L - 1);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
       qf[i][kk] = (wq + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
                                        : make_uint4(0, 0, 0, 0);
+      if constexpr (X2)
+        ql[i][kk] = (wq + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + 64 + (kk * 4 + g) * 8)
+                                         : make_uint4(0, 0, 0, 0);
+    }
   }
   for (int blk = wave; blk < LP / 8; blk += NW) {  // 1-KiB pieces: 8 key rows each
-    {
-      const int p = blk * 4 + (lane >> 4), s = lane & 15;
-      const int row = min(2 * p + (s >> 3), L - 1);
-      const int chunk = (s & 7) ^ (p & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + KO + chunk * 8),
-                                       (lptr_t)(Ks + blk * 1024), 16, 0, 0);
-    }
-    {
-      const int row = blk * 8 + (lane >> 3), pc = lane & 7;
-      const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);  // logical 16-B chunk of this slot
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)min(row, L - 1) * rs + VO + lc * 8),
-                                       (lptr_t)(Vs + blk * 1024), 16, 0, 0);
+#pragma unroll
+    for (int part = 0; part < (X2 ? 2 : 1); ++part) {  // hi image, (X2) lo image
+      {
+        const int p = blk * 4 + (lane >> 4), s = lane & 15;
+        const int row = min(2 * p + (s >> 3), L - 1);
+        const int chunk = (s & 7) ^ (p & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)row * rs + KO + part * 64 + chunk * 8),
+                                         (lptr_t)(Ks + part * LO + blk * 1024), 16, 0, 0);
+      }
+      {
+        const int row = blk * 8 + (lane >> 3), pc = lane & 7;
+        const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);  // logical 16-B chunk of this slot
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)min(row, L - 1) * rs + VO + part * 64 + lc * 8),
+                                         (lptr_t)(Vs + part * LO + blk * 1024), 16, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,8 +445,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
         kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
       }
-      s[t] = mfma_keep<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-      s[t] = mfma_keep<PREC>(k1, q1, s[t]);
+      if constexpr (X2) {  // the two cross terms first (small), then the leading one: one fp32 accumulator chain
+        const uint4 kl0 = *(const uint4*)(Ks + LO + t * 2048 + koff[0]), kl1 = *(const uint4*)(Ks + LO + t * 2048 + koff[1]);
+        s[t] = mfma_keep<PREC>(kl0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        s[t] = mfma_keep<PREC>(kl1, q1, s[t]);
+        s[t] = mfma_keep<PREC>(k0, ql[i][0], s[t]);
+        s[t] = mfma_keep<PREC>(k1, ql[i][1], s[t]);
+        s[t] = mfma_keep<PREC>(k0, q0, s[t]);
+        s[t] = mfma_keep<PREC>(k1, q1, s[t]);
+      } else {
+        s[t] = mfma_keep<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        s[t] = mfma_keep<PREC>(k1, q1, s[t]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
@@ -441,15 +469,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float msc = m * SC;
+    const float msc = X2 ? m * SC - 12.0f : m * SC;  // X2: P scaled by 2^12 (see the kernel's header); cancels in O / rowsum
     // P = exp2(s*SC - m*SC) in MFMA operand order; the row sum is taken on the matrix pipe below
     uint2 pt[NT];
+    uint2 pl[X2 ? NT : 1];  // X2: the lo halves of P
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], SC, -msc));
-      pt[t] = make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
+      if constexpr (X2) {
+        split2<PREC>(e[0], e[1], pt[t].x, pl[t].x);
+        split2<PREC>(e[2], e[3], pt[t].y, pl[t].y);
+      } else {
+        pt[t] = make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
+      }
     }
     // key step u: tiles 2u, 2u+1 (the last step of an odd tile count has a zero upper half).  Kept a macro:
     // through a lambda the (never taken) pt[NT] index of the last step sent the whole array to scratch.
@@ -462,18 +496,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     // O^T = V^T · P^T for the four 16-dim blocks and the row sum (all-ones A operand), key step by key step: five
     // independent accumulator chains in flight, so no MFMA waits for the one just issued (dim-block-outer order
     // made each of the 7 steps of a chain wait out the previous step's latency)
+#define MCM_PLSTEP(u)                                                                            \
+  ((2 * (u) + 1 < NT) ? make_uint4(pl[2 * (u)].x, pl[2 * (u)].y, pl[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
+                                   pl[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
+                      : make_uint4(pl[2 * (u)].x, pl[2 * (u)].y, 0u, 0u))
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const uint4 pu = MCM_PSTEP(u);
+      uint4 plu = make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (X2) {
+        plu = MCM_PLSTEP(u);
+        lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), plu, lacc);
+      }
       lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), pu, lacc);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const char* vp = vlane[dt];
         const uint2 lo = tr_read16(vp + (2 * u) * 2048);
         const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
+        if constexpr (X2) {  // V_lo P_hi and V_hi P_lo first, then the leading term
+          const uint2 llo = tr_read16(vp + LO + (2 * u) * 2048);
+          const uint2 lhi = (2 * u + 1 < NT) ? tr_read16(vp + LO + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
+          o[dt] = mfma_keep<PREC>(make_uint4(llo.x, llo.y, lhi.x, lhi.y), pu, o[dt]);
+          o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), plu, o[dt]);
+        }
         o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pu, o[dt]);
       }
     }
+#undef MCM_PLSTEP
 #undef MCM_PSTEP
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     }
@@ -482,24 +532,38 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     // block of each pair by v_permlane16_swap, after which a lane owns 8 consecutive dims (16 B) of ONE block:
     // two 16-byte stores per lane and q-block instead of four 8-byte ones, 64 contiguous bytes per row and store.
     uint32_t pk[4][2];
+    uint32_t pkl[X2 ? 4 : 1][2];  // X2: the lo halves of the output
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      pk[dt][0] = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
-      pk[dt][1] = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
+      if constexpr (X2) {
+        split2<PREC>(o[dt][0] * rl, o[dt][1] * rl, pk[dt][0], pkl[dt][0]);
+        split2<PREC>(o[dt][2] * rl, o[dt][3] * rl, pk[dt][1], pkl[dt][1]);
+      } else {
+        pk[dt][0] = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
+        pk[dt][1] = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
+      }
     }
     uint4 wide[2];
+    uint4 widel[X2 ? 2 : 1];
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       // vdst = block 2pr, src = block 2pr+1: the odd rows of vdst and the even rows of src change places
       const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
       const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
       wide[pr] = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+      if constexpr (X2) {
+        const auto l0 = __builtin_amdgcn_permlane16_swap(pkl[2 * pr][0], pkl[2 * pr + 1][0], false, false);
+        const auto l1 = __builtin_amdgcn_permlane16_swap(pkl[2 * pr][1], pkl[2 * pr + 1][1], false, false);
+        widel[pr] = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+      }
     }
     if (q < L) {
-      uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64;
+      uint16_t* orow = X2 ? out + ((size_t)seq * L + q) * 2 * D + h * 128 : out + ((size_t)seq * L + q) * D + h * 64;
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr)  // even g: block 2pr, dims g*4 .. g*4+7; odd g: block 2pr+1, dims (g-1)*4 ..
+      for (int pr = 0; pr < 2; ++pr) {  // even g: block 2pr, dims g*4 .. g*4+7; odd g: block 2pr+1, dims (g-1)*4 ..
         *(uint4*)(orow + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = wide[pr];
+        if constexpr (X2) *(uint4*)(orow + 64 + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = widel[pr];
+      }
     }
   }
 }
@@ -586,20 +650,28 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
 int g_attn_variant = 1;  // 1 = attn_tr_kernel (shipped), 0 = attn_bf16_kernel (round 1), 2/3/4 = s_setprio A/B arms
 #endif
 
-template <int PREC, int NT, int NW, int OCC, int PRIO = 0>
+template <int PREC, int NT, int NW, int OCC, int PRIO = 0, bool X2 = false>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                      hipStream_t s, int rev, int hm) {
-  constexpr int lds = NT * 16 * 128 * 2;
+  constexpr int lds = NT * 16 * 128 * (X2 ? 4 : 2);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, X2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (!X2) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO, X2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  if constexpr (X2) {  // (the vision tower only: no causal form)
+    if (causal) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, true>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+                       (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
+    return hipGetLastError();
+  } else {
   if (causal)
     hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
@@ -607,6 +679,18 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
     hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   return hipGetLastError();
+  }
+}
+
+// split-activation arm (fp16): key tiles of the three checkpoint geometries (B/32: 50 tokens = 4 tiles; B/16: 197 = 13;
+// L/14: 257 = 17) plus the small test towers
+hipError_t launch_tr_x2(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev) {
+  const int nt = (L + 15) / 16;
+#define MCM_TRX(N, W) \
+  if (nt <= N) return launch_tr<MCM_PREC_F16, N, W, 1, 0, true>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0)
+  MCM_TRX(2, 4); MCM_TRX(4, 4); MCM_TRX(8, 4); MCM_TRX(13, 8); MCM_TRX(17, 8); MCM_TRX(18, 8);
+#undef MCM_TRX
+  return hipErrorInvalidValue;
 }
 
 
@@ -653,9 +737,13 @@ void attention_set_variant(int v) { g_attn_variant = v; }
 #endif
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse, int hm) {
+                            bool causal, int qrows, hipStream_t s, bool reverse, int hm, bool split) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
+  if (split) {  // split images in and out (GemmArgs::xsplit): fp16, bidirectional, row-major
+    if (prec != MCM_PREC_F16 || causal || hm) return hipErrorInvalidValue;
+    return launch_tr_x2(qkv, out, nseq, L, heads, qrows, s, reverse ? 1 : 0);
+  }
   if (hm && (prec == MCM_PREC_F32 || (int64_t)hm < (int64_t)nseq * L)) return hipErrorInvalidValue;
 #ifndef MCM_HARNESS
   if (hm) return hipErrorInvalidValue;  // head-major qkv: harness library only

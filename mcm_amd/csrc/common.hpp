@@ -166,6 +166,26 @@ __device__ __forceinline__ float fold_apply(float acc, float rstd, float mrstd, 
   return __builtin_fmaf(acc, rstd, __builtin_fmaf(-mrstd, c, b));
 }
 
+// split pair of a 16-bit operand dtype (split weights / split activations): hi = round(v), lo = round(v - hi); v - hi is
+// exact in fp32 (hi is v's own leading bits)
+template <int PREC>
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack2<PREC>(a, b);
+  float ha, hb;
+  if constexpr (PREC == MCM_PREC_F16) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = __builtin_bit_cast(h2_t, hi);
+    ha = (float)h[0];
+    hb = (float)h[1];
+  } else {
+    ha = __builtin_bit_cast(float, hi << 16);
+    hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  }
+  lo = pack2<PREC>(a - ha, b - hb);
+}
+// element offset of logical column n inside a split row (per 64 columns: hi[64] then lo[64]); the lo element is 64 further
+__host__ __device__ constexpr size_t split_col(int n) { return (size_t)(n >> 6) * 128 + (n & 63); }
+
 // element size in bytes of the MFMA operand dtype of a precision mode
 __host__ __device__ constexpr int prec_esize(int prec) { return prec == MCM_PREC_F32 ? 4 : 2; }
 
@@ -176,7 +196,14 @@ enum GemmEpi : int {
   EPI_GELU = 1,    // out = QuickGELU(acc + bias)
   EPI_RESID = 2,   // resid[M,N] (fp32) += acc + bias
   EPI_PATCH = 3,   // x[b*(np+1)+1+p, :] (fp32) = acc + pos[1+p, :]   (m = b*np + p)
+  // split-activation arm (fp16 only; GemmArgs::xsplit): the store epilogues with the output written as a SPLIT image,
+  // the next GEMM's X operand — out[M, 2N]: per 64 columns hi[64] = round(v) then lo[64] = round(v - hi)
+  EPI_STORE_X2 = 4,
+  EPI_GELU_X2 = 5,  // QuickGELU in its exact form (the fp32 arm's), then split
 };
+__host__ __device__ constexpr bool epi_x2(int e) { return e == EPI_STORE_X2 || e == EPI_GELU_X2; }
+__host__ __device__ constexpr bool epi_store16(int e) { return e <= EPI_GELU || epi_x2(e); }  // 16-bit [M, N] / [M, 2N] outputs
+__host__ __device__ constexpr bool epi_gelu(int e) { return e == EPI_GELU || e == EPI_GELU_X2; }
 
 struct GemmArgs {
   const void* x;      // [M, K] operand dtype, row stride ldx elements
@@ -200,6 +227,14 @@ struct GemmArgs {
   // rounding W_lo of the remainder — and `x` is the logical [M, K/2] operand (ldx counts its elements): K-steps 2s and
   // 2s+1 of W meet K-step s of X, so acc = X W_hi^T + X W_lo^T in one fp32 accumulator chain.  0 = plain operands.
   int ksplit;
+  // Split activations (fp16 mode; the re-scoring arm): 1 = `x` is the SPLIT image of a logical [M, K]
+  // activation — [M, 2K], per 128-byte K-step X_hi[64] = round(x) followed by X_lo[64] = round(x - X_hi), written by the
+  // producing kernel (LayerNorm, attention, the *_X2 GEMM epilogues, patchify) — and ldx counts the image's elements.
+  // K-steps 2s (hi) and 2s+1 (lo) of X meet K-step s of W: acc = X_hi W^T + X_lo W^T, ~22 significand bits of the
+  // activation against an exact fp16 weight, in the unchanged K loop.  With ksplit as well: X (hi, lo) x W (hi, lo), four
+  // passes per logical K-step.  The kernels' K index: t = kt >> (ksplit + xsplit); X step (t << xsplit) | (kt & xsplit),
+  // W step (t << ksplit) | ((kt >> xsplit) & ksplit).
+  int xsplit;
   // LayerNorm fold (16-bit modes, ping-pong kernel, gemm.hip "LayerNorm fold"): the LayerNorm between a residual GEMM
   // and the GEMM that consumes its output is not launched; both sides are set or null together per GEMM.
   void* fold_z;           // EPI_RESID (producer): [M, N] operand dtype, z = gamma o (new residual row)
@@ -262,26 +297,28 @@ void attention_set_variant(int v);  // 1 = transpose-read kernel (the shipped on
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s,
                             size_t x_stride = 0, size_t y_stride = 0, bool reverse = false,
-                            unsigned int* sat = nullptr);
+                            unsigned int* sat = nullptr, bool split = false);
 
 // pre_layrnorm (in place, fp32) + layer 0's layer_norm1 (operand dtype of `prec`, to y) in one pass; with cls != null
 // row 0 of every ntok-row image is taken as cls + pos0 (class_embedding + position_embedding[0]) instead of read
 hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
                                 const float* b1, void* y, int M, int D, float eps, hipStream_t s,
                                 bool reverse = false, unsigned int* sat = nullptr, const float* cls = nullptr,
-                                const float* pos0 = nullptr, int ntok = 0);
+                                const float* pos0 = nullptr, int ntok = 0, bool split = false);
 
 // qrows: number of leading query rows per sequence to compute (0 / L = all)
 // hm: 0 = qkv is [rows][3 D] row-major; > 0 = head-major as GemmArgs::hm writes it ([3 heads][hm rows][64], 16-bit
 // modes only; `qkv` is then the base of the whole array and the launch covers sequences from row 0)
+// split: qkv [rows][6 D] and out [rows][2 D] are split images (fp16, not causal; attention.hip attn_tr_kernel<X2>)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse = false, int hm = 0);
+                            bool causal, int qrows, hipStream_t s, bool reverse = false, int hm = 0, bool split = false);
 
+// split: the patch matrix as a split image [B*np, 2 kpad] (fp16; GemmArgs::xsplit)
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
-                           int patch, int kpad, hipStream_t s);
+                           int patch, int kpad, hipStream_t s, bool split = false);
 hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, int B, int image,
                               int patch, int kpad, const float* mean, const float* stdv,
-                              hipStream_t s);
+                              hipStream_t s, bool split = false);
 hipError_t launch_bank_reduce(const float* feats, int K, int T, int P, float* bank, hipStream_t s);
 hipError_t launch_text_embed(const int32_t* ids, const float* tok, const float* pos, float* x,
                              int K, int S, int D, hipStream_t s);

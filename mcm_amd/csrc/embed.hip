@@ -17,7 +17,8 @@
 namespace {
 
 // generic form (any patch size, e.g. 14): one output element per thread iteration
-template <int OUT>
+// X2 (fp16): the patch matrix as a split image [B*np, 2 kpad] (GemmArgs::xsplit) — the split-activation arm's operand
+template <int OUT, bool X2 = false>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ px, void* out,
                                                        int B, int S, int P, int kpad) {
   const int g = S / P, np = g * g, kreal = 3 * P * P;
@@ -33,6 +34,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       const int c = k / (P * P), rem = k % (P * P), py = rem / P, pxx = rem % P;
       v = px[(((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + pxx];
     }
+    if constexpr (X2) {
+      const _Float16 hi = (_Float16)v;
+      _Float16* dst = (_Float16*)out + m * 2 * kpad + split_col(k);
+      dst[0] = hi;
+      dst[64] = (_Float16)(v - (float)hi);
+    } else
     if constexpr (OUT == MCM_PREC_BF16) ((uint16_t*)out)[i] = f2bf(v);
     else if constexpr (OUT == MCM_PREC_F16) ((_Float16*)out)[i] = (_Float16)v;
     else ((float*)out)[i] = v;
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict_
 // Normalize ((x-mean)/std, reference utils/train_eval_util.py:27-33) into the operand gather, so
 // the H2D feed is 150 KB/image instead of 602 KB.  One thread = one pixel = its 3 channel values
 // scattered to the 3 channel planes of the patch row vector k = (c, py, px).
-template <int OUT>
+template <int OUT, bool X2 = false>
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ px, void* out,
                                                           int B, int S, int P, int kpad, float m0,
                                                           float m1, float m2, float s0, float s1,
@@ -88,6 +95,12 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
       // same operation order as torchvision: ToTensor = u8 / 255, Normalize = (t - mean) / std
       const float v = ((float)px[i * 3 + c] / 255.0f - mean[c]) / stdv[c];
       const size_t o = row + (size_t)(c * P + py) * P + pxx;
+      if constexpr (X2) {
+        const _Float16 hi = (_Float16)v;
+        _Float16* dst = (_Float16*)out + 2 * row + split_col((c * P + py) * P + pxx);
+        dst[0] = hi;
+        dst[64] = (_Float16)(v - (float)hi);
+      } else
       if constexpr (OUT == MCM_PREC_BF16) ((uint16_t*)out)[o] = f2bf(v);
       else if constexpr (OUT == MCM_PREC_F16) ((_Float16*)out)[o] = (_Float16)v;
       else ((float*)out)[o] = v;
@@ -255,8 +268,14 @@ inline int grid_for(size_t total) {
 }  // namespace
 
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,
-                           int patch, int kpad, hipStream_t s) {
+                           int patch, int kpad, hipStream_t s, bool split) {
   const int g = image / patch;
+  if (split) {
+    if (prec != MCM_PREC_F16 || kpad % 64) return hipErrorInvalidValue;
+    const size_t n = (size_t)B * g * g * kpad;
+    hipLaunchKernelGGL((patchify_kernel<MCM_PREC_F16, true>), dim3(grid_for(n)), dim3(256), 0, s, pixels, patches, B, image, patch, kpad);
+    return hipGetLastError();
+  }
   const bool vec = patch % 8 == 0 && kpad == 3 * patch * patch && image % 4 == 0;
   const size_t total = (size_t)B * g * g * (vec ? kpad / 8 : kpad);
   const dim3 grid(grid_for(total)), block(256);
@@ -273,13 +292,19 @@ hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, 
 
 hipError_t launch_patchify_u8(int prec, const uint8_t* pixels, void* patches, int B, int image,
                               int patch, int kpad, const float* mean, const float* stdv,
-                              hipStream_t s) {
+                              hipStream_t s, bool split) {
   const size_t total = (size_t)B * image * image;
   const dim3 grid(grid_for(total)), block(256);
+  if (split && (prec != MCM_PREC_F16 || kpad % 64)) return hipErrorInvalidValue;
   if (kpad != 3 * patch * patch) {  // padded K (L/14): the pad columns must be zero
     hipError_t e = hipMemsetAsync(patches, 0, (size_t)B * (image / patch) * (image / patch) * kpad *
-                                                   prec_esize(prec), s);
+                                                   prec_esize(prec) * (split ? 2 : 1), s);
     if (e != hipSuccess) return e;
+  }
+  if (split) {
+    hipLaunchKernelGGL((patchify_u8_kernel<MCM_PREC_F16, true>), grid, block, 0, s, pixels, patches, B, image, patch, kpad,
+                       mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    return hipGetLastError();
   }
   MCM_LAUNCH_BY_PREC(patchify_u8_kernel, pixels, patches, B, image, patch, kpad, mean[0], mean[1],
                      mean[2], stdv[0], stdv[1], stdv[2]);

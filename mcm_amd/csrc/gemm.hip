@@ -55,6 +55,19 @@ namespace {
 
 constexpr int ROWB = 128;  // bytes of K per row per K-step
 
+// K-step kt of a kernel's loop -> byte offsets of the X and W K-steps it stages (GemmArgs::ksplit, xsplit: common.hpp).
+// Plain operands: both kt.  Split weights: X step kt / 2 against W steps kt (hi, lo interleaved).  Split activations: the
+// mirror image.  Both: four passes per logical step t = kt / 4 — (X_hi, W_hi), (X_lo, W_hi), (X_hi, W_lo), (X_lo, W_lo).
+// All scalar (kt is uniform).
+__device__ __forceinline__ void kstep_off(const GemmArgs& a, int kt, size_t& kox, size_t& kow) {
+  const int t = kt >> (a.ksplit + a.xsplit);
+  kox = (size_t)((t << a.xsplit) | (kt & a.xsplit)) * ROWB;
+  kow = (size_t)((t << a.ksplit) | ((kt >> a.xsplit) & a.ksplit)) * ROWB;
+}
+// K-steps of the loop: the W image's steps (a.K counts its columns, hi and lo of a split weight included), twice that for a
+// split X
+__device__ __forceinline__ int ksteps(const GemmArgs& a, int es) { return ((a.K * es) / ROWB) << a.xsplit; }
+
 #if defined(MCM_HARNESS) || defined(MCM_LN_FOLD) || defined(MCM_LN_TAIL)
 #define MCM_ARMS 1  // A/B builds: gemm_arms.hpp is compiled in (below, in front of the launch section)
 #endif
@@ -123,13 +136,27 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, const f32x4_t (
 #pragma unroll
     for (int fj = 0; fj < 4; ++fj) {
       v[fj] = acc[fj][fi] + bv[fj];
-      if constexpr (EPI == EPI_GELU) {  // same form in every kernel variant: results must not
-#pragma unroll                          // depend on which variant the size heuristic picks
+      if constexpr (epi_gelu(EPI)) {  // same form in every kernel variant: results must not
+#pragma unroll                        // depend on which variant the size heuristic picks
         for (int t = 0; t < 4; ++t)
-          v[fj][t] = PREC != MCM_PREC_F32 ? quick_gelu_fast(v[fj][t]) : quick_gelu(v[fj][t]);
+          v[fj][t] = (PREC != MCM_PREC_F32 && !epi_x2(EPI)) ? quick_gelu_fast(v[fj][t]) : quick_gelu(v[fj][t]);
       }
     }
-    if constexpr (EPI == EPI_RESID) {
+    if constexpr (epi_x2(EPI)) {  // split image: the lane's 16 columns as hi[16] at split_col(n), lo[16] 64 elements on
+      uint32_t hi[8], lo[8];
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        sat_track<PREC>(amax, v[fj][0], v[fj][1]);
+        sat_track<PREC>(amax, v[fj][2], v[fj][3]);
+        split2<PREC>(v[fj][0], v[fj][1], hi[2 * fj], lo[2 * fj]);
+        split2<PREC>(v[fj][2], v[fj][3], hi[2 * fj + 1], lo[2 * fj + 1]);
+      }
+      uint4* dst = (uint4*)((uint16_t*)a.out + (size_t)m * a.ldo + split_col(n));
+      dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      dst[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+      dst[8] = make_uint4(lo[0], lo[1], lo[2], lo[3]);   // + 64 elements = 8 x 16 B
+      dst[9] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    } else if constexpr (EPI == EPI_RESID) {
       f32x4_t* dst = (f32x4_t*)(a.resid + (size_t)m * a.ldo + n);
       f32x4_t r[4];
 #pragma unroll
@@ -197,7 +224,46 @@ __device__ __forceinline__ void wave_epilogue_lds(const GemmArgs& a, const f32x4
                                                   const f32x4_t (&bv)[4], int mw, int nw, int lane,
                                                   char* scratch, float& amax) {
   const int fr = lane & 15, g = lane >> 4;
-  if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
+  if constexpr (PREC != MCM_PREC_F32 && epi_x2(EPI)) {
+    // Split outputs (the re-scoring arm): per 16-row unit the hi image goes through the window's first 2-KiB half and the
+    // lo image through the second, then both are read back and stored as whole 128-B segments — hi at split_col(nw), lo
+    // right behind it (the wave's 64 columns are exactly one K-step of the consumer).  No overlap between units: this arm
+    // re-scores a few hundred images, the store pattern matters, the last 10 % of the epilogue do not.
+    const int rrow = lane >> 3, c8 = lane & 7;
+    const int sw = fr & 7;
+#pragma unroll
+    for (int u = 0; u < MF; ++u) {
+      uint32_t hi[8], lo[8];
+#pragma unroll
+      for (int fj = 0; fj < 4; ++fj) {
+        f32x4_t v = acc[fj][u] + bv[fj];
+        if constexpr (epi_gelu(EPI)) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = quick_gelu(v[t]);
+        }
+        sat_track<PREC>(amax, v[0], v[1]);
+        sat_track<PREC>(amax, v[2], v[3]);
+        split2<PREC>(v[0], v[1], hi[2 * fj], lo[2 * fj]);
+        split2<PREC>(v[2], v[3], hi[2 * fj + 1], lo[2 * fj + 1]);
+      }
+      char* w = scratch + fr * 128;
+      *(uint4*)(w + (((g * 2) ^ sw) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      *(uint4*)(w + (((g * 2 + 1) ^ sw) << 4)) = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+      *(uint4*)(w + 2048 + (((g * 2) ^ sw) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      *(uint4*)(w + 2048 + (((g * 2 + 1) ^ sw) << 4)) = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = t * 8 + rrow, m = mw + u * 16 + row;
+        const uint4 rh = *(const uint4*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const uint4 rl = *(const uint4*)(scratch + 2048 + row * 128 + ((c8 ^ (row & 7)) << 4));
+        if (INTERIOR || (m < a.M && nw + c8 * 8 < a.N)) {
+          uint16_t* dst = (uint16_t*)a.out + (size_t)m * a.ldo + split_col(nw) + c8 * 8;
+          store16_stream(dst, rh);
+          store16_stream(dst + 64, rl);
+        }
+      }
+    }
+  } else if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) {
     // 16-row units ping-pong between the two 2-KiB halves of the window: unit u is converted and
     // written while unit u-1 is read back and stored, so the LDS round trip and the store issue
     // (a 1-KiB store blocks its wave like an LDS-DMA piece does) overlap the next unit's VALU work.
@@ -409,12 +475,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   const uint32_t lds0 = lds_addr(smem);
   auto stage = [&](int st, int kt) {
     const uint32_t base = lds0 + st * STAGE_BYTES;
+    size_t kox, kow;
+    kstep_off(a, kt, kox, kow);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int blk = i * 4 + wave;
-      glds16(gx[i] + (size_t)(kt >> a.ksplit) * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
-      glds16(gw[i] + (size_t)kt * ROWB,
-             __builtin_amdgcn_readfirstlane(base + TILE_BYTES + blk * 1024));
+      glds16(gx[i] + kox, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+      glds16(gw[i] + kow, __builtin_amdgcn_readfirstlane(base + TILE_BYTES + blk * 1024));
     }
   };
 
@@ -426,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
 
   f32x4_t acc[4][4];
   zero_acc(acc);
-  const int nk = (a.K * ES) / ROWB;
+  const int nk = ksteps(a, ES);
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -491,11 +558,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tile64_kernel(const GemmArgs a) {
   const uint32_t lds0 = lds_addr(smem);
   auto stage = [&](int st, int kt) {
     const uint32_t base = lds0 + st * STAGE_BYTES;
+    size_t kox, kow;
+    kstep_off(a, kt, kox, kow);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int blk = i * 4 + wave;
-      if (i < 2) glds16(gx[i] + (size_t)(kt >> a.ksplit) * ROWB, __builtin_amdgcn_readfirstlane(base + blk * 1024));
-      glds16(gw[i] + (size_t)kt * ROWB, __builtin_amdgcn_readfirstlane(base + X_BYTES + blk * 1024));
+      if (i < 2) glds16(gx[i] + kox, __builtin_amdgcn_readfirstlane(base + blk * 1024));
+      glds16(gw[i] + kow, __builtin_amdgcn_readfirstlane(base + X_BYTES + blk * 1024));
     }
   };
   const int wr = wave >> 1, wc = wave & 1;
@@ -505,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile64_kernel(const GemmArgs a) {
   const int wbase = X_BYTES + wc * 64 * ROWB;
   f32x4_t acc[4][2];
   zero_acc(acc);
-  const int nk = (a.K * ES) / ROWB;
+  const int nk = ksteps(a, ES);
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = prec_esize(PREC);
   // store instructions per wave per full tile: 8 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 16 : 32;
+  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 16 : 32;  // (*_X2: 32 as well)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
 
@@ -618,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   const int ntl_x = nmt_x * nbn;
   const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
   if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
+  const int nk = ksteps(a, ES);
   const int total = ntl * nk;
 
   const int r0 = wave * 8 + (lane >> 4) * 2 + ((lane & 15) >> 3);
@@ -702,7 +771,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p256_kernel(const GemmArgs a) {
   };
   auto issue = [&](int st) {
     const uint32_t base = lds0 + st * STAGE_BYTES;
-    const size_t ko = (size_t)kti * ROWB, kox = (size_t)(kti >> a.ksplit) * ROWB;
+    size_t ko, kox;
+    kstep_off(a, kti, kox, ko);
     if constexpr (PXF) {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -936,7 +1006,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const int ntl_x = nmt_x * nbn;
   const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
   if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
+  const int nk = ksteps(a, ES);
   const int total = ntl * nk;
 
   const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
@@ -980,9 +1050,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   const uint32_t lds0 = lds_addr(smem);
   auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
     const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
-    const size_t ko = (size_t)kti * ROWB;
+    size_t ko, kox;  // split weights: X K-step s / 2 meets W' K-steps s (hi), s + 1 (lo); split activations: the mirror image
+    kstep_off(a, kti, kox, ko);
     if (i < 4) {
-      const size_t kox = (size_t)(kti >> a.ksplit) * ROWB;  // split weights: X K-step s / 2 meets W' K-steps s (hi), s + 1 (lo)
       glds16s(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
       const int q = i - 4;
@@ -1068,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
     }
     char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-    if constexpr (PREC != MCM_PREC_F32 && EPI <= EPI_GELU)
+    if constexpr (PREC != MCM_PREC_F32 && epi_store16(EPI))
       wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
     else
       wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
@@ -1175,7 +1245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   if (pend) epilogue();
-  if constexpr (EPI <= EPI_GELU) sat_report<PREC>(amax, a.sat);
+  if constexpr (epi_store16(EPI)) sat_report<PREC>(amax, a.sat);
 }
 
 #ifdef MCM_ARMS
@@ -1320,9 +1390,27 @@ hipError_t launch_one(const GemmArgs& a, hipStream_t s) {
   return launch_p256<PREC, EPI, false>(a, s);
 }
 
+// the split-output epilogues (EPI_*_X2; fp16 only): the shipped kernels under the shipped size policy, never an A/B arm
+template <int PREC, int EPI>
+hipError_t launch_one_x2(const GemmArgs& a, hipStream_t s) {
+  if constexpr (PREC != MCM_PREC_F16) {
+    return hipErrorInvalidValue;
+  } else {
+    const int v = size_policy(a.M, a.N);
+    if (v == 0 || v == 11) {
+      const bool few = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 2L * persistent_grid();
+      return few ? launch_tile64<PREC, EPI>(a, s) : launch_tile<PREC, EPI>(a, s);
+    }
+    if (a.M % p256::BM == 0 && a.N % p256::BN == 0) return launch_pp<PREC, EPI>(a, s);
+    return launch_p256<PREC, EPI, false>(a, s);
+  }
+}
+
 template <int PREC>
 hipError_t launch_prec(int epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
+    case EPI_STORE_X2: return launch_one_x2<PREC, EPI_STORE_X2>(a, s);
+    case EPI_GELU_X2: return launch_one_x2<PREC, EPI_GELU_X2>(a, s);
     case EPI_STORE: return launch_one<PREC, EPI_STORE>(a, s);
     case EPI_GELU: return launch_one<PREC, EPI_GELU>(a, s);
     case EPI_RESID: return launch_one<PREC, EPI_RESID>(a, s);
@@ -1401,6 +1489,13 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
   // split weights: 16-bit modes, an even number of K-steps (hi, lo pairs); the shipped kernels only
   if (a.ksplit && (a.ksplit != 1 || prec == MCM_PREC_F32 || ((a.K * es) / ROWB) % 2 || a.fold_z || a.fold_rs || a.ln_y))
     return hipErrorInvalidValue;
+  // split activations / split outputs: fp16, the shipped kernels, rows of whole 64-column blocks; the pixel-gathering patch
+  // GEMM reads fp32 pixels, not a split image (the caller runs patchify)
+  if ((a.xsplit || epi_x2(epi)) && (prec != MCM_PREC_F16 || (a.xsplit != 0 && a.xsplit != 1) || a.fold_z || a.fold_rs || a.ln_y ||
+                                    a.hm || a.px || variant() >= 0))
+    return hipErrorInvalidValue;
+  if (a.xsplit && a.ldx % 128) return hipErrorInvalidValue;
+  if (epi_x2(epi) && (a.N % 64 || a.ldo % 128)) return hipErrorInvalidValue;
 #ifdef MCM_HARNESS
   if (a.ksplit && (variant() == 1 || variant() == 2 || variant() == 6)) return hipErrorInvalidValue;  // (arms without the split staging)
 #endif

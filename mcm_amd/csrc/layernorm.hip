@@ -12,7 +12,7 @@ namespace {
 
 constexpr int MAXV = LN_MAXV;  // float4 per lane: D <= 64*4*4 = 1024
 
-template <int OUT>  // OUT = MCM_PREC_F32: fp32 rows; BF16 / F16: packed 16-bit rows
+template <int OUT, bool X2 = false>  // OUT = MCM_PREC_F32: fp32 rows; BF16 / F16: packed 16-bit rows (X2: split rows, ys counts their elements)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b, void* y,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
   }
   ln_row_apply(v, g, b, D, eps, lane);
   float amax = 0.f;
-  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT>(v, (uint16_t*)y + (size_t)row * ys, D, lane, amax);
+  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT, 0, X2>(v, (uint16_t*)y + (size_t)row * ys, D, lane, amax);
   else ln_row_store<OUT>(v, (float*)y + (size_t)row * ys, D, lane, amax);
   sat_report<OUT>(amax, sat);
 }
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,
 // the first LayerNorm is written back in place (it is the residual stream) AND, still in registers, normalised again
 // into the first QKV GEMM's operand.  Same arithmetic as the two launches (the second LayerNorm sees exactly the fp32
 // values the first one stores), one 310-MB read of x less.
-template <int OUT>
+template <int OUT, bool X2 = false>
 __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const float* __restrict__ g0,
                                                             const float* __restrict__ b0,
                                                             const float* __restrict__ g1,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_pre_kernel(float* x, const floa
   ln_row_apply(v, g0, b0, D, eps, lane);       // pre_layrnorm: the residual stream, written back in fp32
   ln_row_store<MCM_PREC_F32>(v, xr, D, lane, amax);
   ln_row_apply(v, g1, b1, D, eps, lane);       // layer 0's layer_norm1 of exactly those fp32 values
-  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT>(v, (uint16_t*)y + (size_t)row * D, D, lane, amax);
+  if constexpr (OUT != MCM_PREC_F32) ln_row_store<OUT, 0, X2>(v, (uint16_t*)y + (size_t)row * D * (X2 ? 2 : 1), D, lane, amax);
   else ln_row_store<OUT>(v, (float*)y + (size_t)row * D, D, lane, amax);
   sat_report<OUT>(amax, sat);
 }
@@ -165,10 +165,15 @@ __global__ __launch_bounds__(256) void fold_stats_kernel(const float2* __restric
 
 hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float* b0, const float* g1,
                                 const float* b1, void* y, int M, int D, float eps, hipStream_t s,
-                                bool reverse, unsigned int* sat, const float* cls, const float* pos0, int ntok) {
+                                bool reverse, unsigned int* sat, const float* cls, const float* pos0, int ntok, bool split) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
   const int rev = reverse ? 1 : 0;
+  if (split) {  // split rows: fp16 only, whole 64-column blocks
+    if (prec != MCM_PREC_F16 || D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((layernorm_pre_kernel<MCM_PREC_F16, true>), grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat, cls, pos0, ntok > 0 ? ntok : 1);
+    return hipGetLastError();
+  }
   if (prec == MCM_PREC_BF16)
     hipLaunchKernelGGL(layernorm_pre_kernel<MCM_PREC_BF16>, grid, block, 0, s, x, g0, b0, g1, b1, y, M, D, eps, rev, sat, cls, pos0, ntok > 0 ? ntok : 1);
   else if (prec == MCM_PREC_F16)
@@ -180,10 +185,16 @@ hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float
 
 hipError_t launch_layernorm(int prec, const float* x, const float* g, const float* b, void* y,
                             int M, int D, float eps, bool out_f32, hipStream_t s, size_t x_stride,
-                            size_t y_stride, bool reverse, unsigned int* sat) {
+                            size_t y_stride, bool reverse, unsigned int* sat, bool split) {
   if (M <= 0 || D <= 0 || D % 4 || D > 64 * 4 * MAXV) return hipErrorInvalidValue;
-  const size_t xs = x_stride ? x_stride : (size_t)D, ys = y_stride ? y_stride : (size_t)D;
+  const size_t xs = x_stride ? x_stride : (size_t)D, ys = y_stride ? y_stride : (size_t)D * (split ? 2 : 1);
   if (xs % 4 || ys % 4) return hipErrorInvalidValue;
+  if (split) {  // split rows (y_stride counts the split row's elements): fp16 only, whole 64-column blocks
+    if (prec != MCM_PREC_F16 || out_f32 || D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((layernorm_kernel<MCM_PREC_F16, true>), dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, M, D, eps, xs, ys,
+                       reverse ? 1 : 0, 1, sat);
+    return hipGetLastError();
+  }
   const dim3 grid((M + 3) / 4), block(256);
   const int rev = reverse ? 1 : 0;
   // x is streamed with the non-temporal hint: the 310-MB residual read would otherwise push the

@@ -76,14 +76,24 @@ __device__ __forceinline__ void ln_row_apply(float4 (&v)[LN_MAXV], const float* 
   ln_scale<NVU>(v, rstd, g, b, D, lane);
 }
 
-// the row in the operand dtype OUT (fp32: as it is) to yrow
-template <int OUT, int NVU = 0>
+// the row in the operand dtype OUT (fp32: as it is) to yrow; X2 (16-bit OUT): as a split image of 2 D elements, per 64
+// columns hi[64] then lo[64] (GemmArgs::xsplit)
+template <int OUT, int NVU = 0, bool X2 = false>
 __device__ __forceinline__ void ln_row_store(const float4 (&v)[LN_MAXV], void* yrow, int D, int lane, float& amax) {
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int d = (i * 64 + lane) * 4;
     if (ln_has<NVU>(i, lane, D)) {
-      if constexpr (OUT != MCM_PREC_F32) {
+      if constexpr (OUT != MCM_PREC_F32 && X2) {
+        uint2 hi, lo;
+        split2<OUT>(v[i].x, v[i].y, hi.x, lo.x);
+        split2<OUT>(v[i].z, v[i].w, hi.y, lo.y);
+        sat_track<OUT>(amax, v[i].x, v[i].y);
+        sat_track<OUT>(amax, v[i].z, v[i].w);
+        uint16_t* dst = (uint16_t*)yrow + split_col(d);
+        *(uint2*)dst = hi;
+        *(uint2*)(dst + 64) = lo;
+      } else if constexpr (OUT != MCM_PREC_F32) {
         uint2 pk;
         pk.x = pack2<OUT>(v[i].x, v[i].y);
         pk.y = pack2<OUT>(v[i].z, v[i].w);

@@ -83,6 +83,8 @@ struct mcm_handle {
   hipEvent_t prep_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
   unsigned prep_next = 0;
   int64_t max_rows = 0;
+  int row_scale = 1;   // 2 while a split-activation call runs: its rows are twice as wide, so half as many fit (padded_rows)
+  int x2_batch = 0;    // largest batch of the split-activation arm on this workspace (0: not an fp16 handle)
   size_t hbuf_bytes = 0;
   std::vector<void*> owned;       // every hipMalloc'd pointer
   // profiling
@@ -233,7 +235,7 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
   // bench.py roofline_hbm_kernels); small launches (CLS-only last layer, short prompt banks) count in MCM_KC_GEMM only
   int shape = -1;
   if (a.M > 4096)
-    shape = epi == EPI_STORE ? MCM_KC_GEMM_QKV : epi == EPI_GELU ? MCM_KC_GEMM_FC1
+    shape = (epi == EPI_STORE || epi == EPI_STORE_X2) ? MCM_KC_GEMM_QKV : epi_gelu(epi) ? MCM_KC_GEMM_FC1
           : epi == EPI_RESID ? (a.N == a.K ? MCM_KC_GEMM_OUTPROJ : MCM_KC_GEMM_FC2) : -1;
   Scope sc(h, s, MCM_KC_GEMM, 2.0 * a.M * (double)a.N * a.K, shape);  // algorithmic FLOP: the logical K, split or not
   // Row padding into the workspace: the ping-pong kernel takes problems made of whole 256-row tiles only, so a
@@ -244,14 +246,19 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
   const bool from_row0 = a.x == h->ln || a.x == h->att || a.x == h->hbuf;  // not a chunk that starts mid-buffer
   if (epi != EPI_PATCH && from_row0 && a.M % 256 != 0 && a.N % 256 == 0 && a.ldx == a.K && a.ldo == a.N) {
     const int64_t mp = ((int64_t)a.M + 255) / 256 * 256;
-    if (mp <= h->max_rows) a.M = (int)mp;
+    if (mp <= h->max_rows / h->row_scale) a.M = (int)mp;
   }
   if (a.ksplit) a.K *= 2;  // the callers describe the logical problem; the split image has 2 K columns per row
+  if (a.xsplit) a.ldx *= 2;           // ... and so have the rows of a split X
+  if (epi_x2(epi)) a.ldo *= 2;        // ... and of a split output
   return launch_gemm(prec, epi, a, s);
 }
 hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b,
-                 void* y, int M, int D, bool out_f32) {
+                 void* y, int M, int D, bool out_f32, bool split = false) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
+  if (split)
+    return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, false, s, 0, 0, next_dir(h),
+                            h->sat_on ? h->sat_dev : nullptr, true);
 #ifdef MCM_HARNESS
   // timing experiment (results are garbage): what a tower without its big LayerNorm launches would cost.
   // MCM_ABL_SKIP_LN=1: nothing in their place; =2: a write of the 16-bit output's size (the extra epilogue store
@@ -267,9 +274,10 @@ hipError_t lnorm(mcm_handle* h, hipStream_t s, int prec, const float* x, const f
 }
 // seq0: first sequence of the launch (a chunk of the batch starts there)
 hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int heads, bool causal,
-                int qrows = 0, int seq0 = 0, int hm = 0) {
+                int qrows = 0, int seq0 = 0, int hm = 0, bool split = false) {
   const int q = qrows > 0 ? qrows : L;
   Scope sc(h, s, MCM_KC_ATTENTION, 4.0 * nseq * heads * (double)q * L * 64 * (causal ? 0.5 : 1.0));
+  if (split) return launch_attention(prec, h->qkv, h->att, nseq, L, heads, causal, qrows, s, next_dir(h), 0, true);
   const size_t es = prec_esize(prec), D = (size_t)heads * 64, row0 = (size_t)seq0 * L;
   return launch_attention(prec, (const char*)h->qkv + row0 * 3 * D * es, (char*)h->att + row0 * D * es, nseq, L,
                           heads, causal, qrows, s, next_dir(h), hm);
@@ -296,17 +304,17 @@ constexpr int g_ln_fold = 0;
 // rows of a dense activation GEMM as gemm() runs it (whole 256-row tiles when the workspace has them)
 int64_t padded_rows(const mcm_handle* h, int M) {
   const int64_t mp = ((int64_t)M + 255) / 256 * 256;
-  return mp <= h->max_rows ? mp : M;
+  return mp <= h->max_rows / h->row_scale ? mp : M;
 }
 hipError_t fold_stats(mcm_handle* h, hipStream_t s, int Mp, int D) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 4.0 * Mp * (D / 64));
   return launch_fold_stats(h->fold_part, D / 64, Mp, D, h->cfg.ln_eps, h->fold_rs, s);
 }
 hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x, const float* g,
-                         const float* b, void* y, int M, int D, size_t xs, size_t ys) {
+                         const float* b, void* y, int M, int D, size_t xs, size_t ys, bool split = false) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * M * D);
   return launch_layernorm(prec, x, g, b, y, M, D, h->cfg.ln_eps, false, s, xs, ys, false,
-                          h->sat_on ? h->sat_dev : nullptr);
+                          h->sat_on ? h->sat_dev : nullptr, split);
 }
 
 // LayerNorm in the tail of the residual GEMMs (gemm.hip "LayerNorm in the tail"): 1 = the LayerNorm that follows a
@@ -361,12 +369,18 @@ bool xcd_round_robin(mcm_handle* h, int grid) {
 // where the LayerNorm output would have gone) and the row moments, fold_stats turns those into (rstd, mean rstd) per
 // row, and the consumer's epilogue normalises (gemm.hip, "LayerNorm fold").  Not for the layer the caller pools row 0 of
 // (its LayerNorms see other rows / strides) and not for layer 0's layer_norm1 (fused with pre_layrnorm by the caller).
+// x2 (fp16 vision tower; the split-activation arm, mcm_score_x2): every activation that feeds an MFMA — LayerNorm outputs,
+// q / k / v, the attention output, the QuickGELU output — is carried as a split image (hi + lo, twice the columns) and every
+// GEMM runs GemmArgs::xsplit; the residual stream, LayerNorm statistics and softmax are fp32 as always.
 int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bool causal,
-               bool pooled_row0, bool ln1_of_layer0_done = false, bool fold_ok = false) {
+               bool pooled_row0, bool ln1_of_layer0_done = false, bool fold_ok = false, bool x2 = false) {
   const int M = nseq * L, D = t.D, P = t.prec;
   const int es = prec_esize(P);
   const int Mp = (int)padded_rows(h, M);
   const int ks = t.split ? 1 : 0;
+  const int xs = x2 ? 1 : 0;
+  const int epi_store = x2 ? EPI_STORE_X2 : EPI_STORE, epi_act = x2 ? EPI_GELU_X2 : EPI_GELU;
+  if (x2) fold_ok = false;
   const size_t wrow = (size_t)D * es * (t.split ? 2 : 1);  // bytes per row of a [*, D] weight image
   // producer form: 1 = fused into the residual GEMM's epilogue (ping-pong kernel), 2 = plain residual GEMM + fold_rows
   // (tile kernel: small batches) - bit-identical; the consumers need a fold epilogue in whichever kernel they take
@@ -385,7 +399,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   };
   bool ln1_folded = false;  // h->ln holds gamma1 o x and h->fold_rs the row statistics of this layer's layer_norm1
   // LayerNorm in the tail: the residual GEMMs of whole-batch layers also produce the LayerNorm that follows them
-  const bool tail_ok = g_ln_tail && !can_fold && !t.split && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
+  const bool tail_ok = g_ln_tail && !x2 && !can_fold && !t.split && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
                        gemm_ln_tail_ok(P, Mp, D);
   auto with_tail = [&](GemmArgs& g, const float* gamma, const float* beta) {
     g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
@@ -396,42 +410,42 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     const LayerW& w = t.L[l];
     const bool cls = pooled_row0 && l == t.layers - 1 && L > 1;
     if (!(l == 0 && ln1_of_layer0_done) && !ln1_folded && !ln1_by_tail)
-      HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false));
+      HIP_TRY(h, lnorm(h, s, P, h->x, w.ln1w, w.ln1b, h->ln, M, D, false, x2));
     ln1_by_tail = false;
     if (!cls) {
-      const int nch = (g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
+      const int nch = (!x2 && g_qkv_chunks > 1 && nseq % g_qkv_chunks == 0) ? g_qkv_chunks : 1;
       for (int c = 0; c < nch; ++c) {
         const int sq = nseq / nch, r0 = c * sq * L;
         GemmArgs a{};
         a.x = (const char*)h->ln + (size_t)r0 * D * es; a.w = w.wqkv; a.bias = w.bqkv;
         a.out = (char*)h->qkv + (size_t)r0 * 3 * D * es;
-        a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D; a.ksplit = ks;
+        a.M = sq * L; a.N = 3 * D; a.K = D; a.ldx = D; a.ldo = 3 * D; a.ksplit = ks; a.xsplit = xs;
         if (ln1_folded) { a.bias = w.bqkvf; a.fold_rs = h->fold_rs; a.fold_c = w.cqkv; }
         // whole-batch launches of a 16-bit tower hand q / k / v over head-major (same bytes in h->qkv, other order;
         // the row-0-only layer below and the fp32 towers keep [rows][3 D])
-        const int hm = (g_qkv_head_major && nch == 1 && P != MCM_PREC_F32 && t.heads * 64 == D) ? Mp : 0;
+        const int hm = (g_qkv_head_major && !x2 && nch == 1 && P != MCM_PREC_F32 && t.heads * 64 == D) ? Mp : 0;
         a.hm = hm;
-        HIP_TRY(h, gemm(h, s, P, EPI_STORE, a));
-        HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq, hm));
+        HIP_TRY(h, gemm(h, s, P, epi_store, a));
+        HIP_TRY(h, attn(h, s, P, sq, L, t.heads, causal, 0, c * sq, hm, x2));
       }
     } else {
       GemmArgs kv{};  // K and V of every token: weight rows [D, 3D), output columns [D, 3D)
       kv.x = h->ln; kv.w = (const char*)w.wqkv + (size_t)D * wrow; kv.bias = w.bqkv + D;
-      kv.out = (char*)h->qkv + (size_t)D * es;
-      kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D; kv.ksplit = ks;
-      HIP_TRY(h, gemm(h, s, P, EPI_STORE, kv));
+      kv.out = (char*)h->qkv + (size_t)D * es * (1 + xs);  // (split rows: D logical columns are 2 D elements)
+      kv.M = M; kv.N = 2 * D; kv.K = D; kv.ldx = D; kv.ldo = 3 * D; kv.ksplit = ks; kv.xsplit = xs;
+      HIP_TRY(h, gemm(h, s, P, epi_store, kv));
       GemmArgs q{};   // Q of row 0 of every sequence (row stride L*D in, L*3D out)
       q.x = h->ln; q.w = w.wqkv; q.bias = w.bqkv; q.out = h->qkv;
-      q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D; q.ksplit = ks;
-      HIP_TRY(h, gemm(h, s, P, EPI_STORE, q));
-      HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal, 1));
+      q.M = nseq; q.N = D; q.K = D; q.ldx = L * D; q.ldo = L * 3 * D; q.ksplit = ks; q.xsplit = xs;
+      HIP_TRY(h, gemm(h, s, P, epi_store, q));
+      HIP_TRY(h, attn(h, s, P, nseq, L, t.heads, causal, 1, 0, 0, x2));
     }
     const int Mr = cls ? nseq : M;            // rows that continue
     const int rs = cls ? L * D : D;           // their stride in x / att
     const bool fold2 = can_fold && !cls;      // layer_norm2 folded into out-proj / fc1
     GemmArgs o{};
     o.x = h->att; o.w = w.wo; o.bias = w.bo; o.resid = h->x;
-    o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs; o.ksplit = ks;
+    o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs; o.ksplit = ks; o.xsplit = xs;
     if (fold2) {
       HIP_TRY(h, produce(o, w.ln2w));
     } else if (tail_ok && !cls) {
@@ -439,19 +453,19 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
     } else {
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
-      if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false));
-      else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D));
+      if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false, x2));
+      else HIP_TRY(h, lnorm_strided(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, Mr, D, (size_t)rs, (size_t)D * (1 + xs), x2));
     }
     GemmArgs f1{};
     f1.x = h->ln; f1.w = w.w1; f1.bias = w.b1; f1.out = h->hbuf;
-    f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff; f1.ksplit = ks;
+    f1.M = Mr; f1.N = t.ff; f1.K = D; f1.ldx = D; f1.ldo = t.ff; f1.ksplit = ks; f1.xsplit = xs;
     if (fold2) { f1.bias = w.b1f; f1.fold_rs = h->fold_rs; f1.fold_c = w.c1; }
-    HIP_TRY(h, gemm(h, s, P, EPI_GELU, f1));
+    HIP_TRY(h, gemm(h, s, P, epi_act, f1));
     // the next layer's layer_norm1 folded into fc2 / the next QKV projection (not into the row-0-only layer)
     ln1_folded = fold2 && l + 1 < t.layers && !(pooled_row0 && l + 1 == t.layers - 1 && L > 1);
     GemmArgs f2{};
     f2.x = h->hbuf; f2.w = w.w2; f2.bias = w.b2; f2.resid = h->x;
-    f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs; f2.ksplit = ks;
+    f2.M = Mr; f2.N = D; f2.K = t.ff; f2.ldx = t.ff; f2.ldo = rs; f2.ksplit = ks; f2.xsplit = xs;
     if (ln1_folded) {
       HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
     } else {
@@ -606,6 +620,12 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->ln, lnb);
   if (!rc) rc = dev_alloc(h, &h->qkv, qkvb);
   if (!rc) rc = dev_alloc(h, &h->att, attb);
+  // split-activation arm (fp16 handles): the same buffers hold rows of twice the width, so half the rows — and half the
+  // patch matrix
+  if (c.precision == MCM_PREC_F16) {
+    const int64_t by_rows = (mv / 2 / 256 * 256) / h->ntok;
+    h->x2_batch = (int)(by_rows < c.max_batch / 2 ? by_rows : c.max_batch / 2);
+  }
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
   // zeroed once (a ragged vision batch zeroes its pad rows again: encode_image_impl, "Pad rows")
@@ -785,34 +805,45 @@ namespace {
 const float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
 const float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
+struct RowScale {  // the activation rows of a split-activation call are twice as wide (padded_rows, gemm)
+  mcm_handle* h;
+  RowScale(mcm_handle* h_, int k) : h(h_) { h->row_scale = k; }
+  ~RowScale() { h->row_scale = 1; }
+};
+
+// x2: the split-activation arm (include/mcm.h mcm_score_x2) — same weights, same workspace, B <= h->x2_batch
 int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B, float* out_dev,
-                      void* stream, bool normalize = true) {
+                      void* stream, bool normalize = true, bool x2 = false) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
-  if (B <= 0 || B > h->cfg.max_batch) return fail(h, MCM_ERANGE, "batch exceeds cfg.max_batch");
+  if (x2 && h->x2_batch <= 0) return fail(h, MCM_EINVAL, "the split-activation arm needs an fp16 handle (max_batch >= 2)");
+  if (B <= 0 || B > (x2 ? h->x2_batch : h->cfg.max_batch))
+    return fail(h, MCM_ERANGE, x2 ? "batch exceeds mcm_x2_max_batch" : "batch exceeds cfg.max_batch");
   hipStream_t s = (hipStream_t)stream;
   const mcm_config& c = h->cfg;
   const int D = c.v_width;
+  RowScale scale(h, x2 ? 2 : 1);
   // fp32 NCHW pixels: the patch GEMM gathers its A operand from the image itself (gemm_p256_kernel, GemmArgs::px) when the
   // geometry allows (B/16, B/32 at batches the persistent kernel takes); otherwise — uint8 ingest, L/14's padded K, small
   // batches — patchify writes the patch matrix first
-  const bool from_px = !u8 && g_patch_fold &&
+  const bool from_px = !u8 && !x2 && g_patch_fold &&
                        gemm_patch_takes_pixels(c.precision, B * h->np, D, h->kpad, c.patch_size, c.image_size);
   if (!from_px) {
     Scope sc(h, s, MCM_KC_PATCHIFY, 0.0);
     if (u8)
       HIP_TRY(h, launch_patchify_u8(c.precision, (const uint8_t*)pixels_dev, h->patches, B, c.image_size,
-                                    c.patch_size, h->kpad, kClipMean, kClipStd, s));
+                                    c.patch_size, h->kpad, kClipMean, kClipStd, s, x2));
     else
       HIP_TRY(h, launch_patchify(c.precision, (const float*)pixels_dev, h->patches, B, c.image_size,
-                                 c.patch_size, h->kpad, s));
+                                 c.patch_size, h->kpad, s, x2));
   }
   GemmArgs a{};
   a.px = from_px ? (const float*)pixels_dev : nullptr; a.img = c.image_size; a.patch = c.patch_size;
   a.x = h->patches; a.w = h->wpatch; a.bias = nullptr; a.out = h->x;
   a.pos = W(h, "vision_model.embeddings.position_embedding.weight");
   a.M = B * h->np; a.N = D; a.K = h->kpad; a.ldx = h->kpad; a.ldo = D; a.np = h->np; a.ksplit = h->vis.split ? 1 : 0;
+  a.xsplit = x2 ? 1 : 0;
   HIP_TRY(h, gemm(h, s, c.precision, EPI_PATCH, a));
   {  // Pad rows.  gemm() runs the dense activation GEMMs on whole 256-row tiles; the rows between B * ntok and the next
      // multiple of 256 are computed and never read.  The buffers they live in are shared with the fp32 text tower, so
@@ -820,7 +851,7 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
      // watch): a ragged batch zeroes them first, and they then only ever carry bias-only values.
     const int64_t M = (int64_t)B * h->ntok, mp = padded_rows(h, (int)M);
     if (mp > M) {
-      const size_t es = (size_t)prec_esize(c.precision), pad = (size_t)(mp - M);
+      const size_t es = (size_t)prec_esize(c.precision) * (x2 ? 2 : 1), pad = (size_t)(mp - M);
       HIP_TRY(h, hipMemsetAsync(h->x + M * D, 0, pad * D * sizeof(float), s));
       HIP_TRY(h, hipMemsetAsync((char*)h->ln + (size_t)M * D * es, 0, pad * D * es, s));
       HIP_TRY(h, hipMemsetAsync((char*)h->att + (size_t)M * D * es, 0, pad * D * es, s));
@@ -836,9 +867,9 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
                                     W(h, "vision_model.pre_layrnorm.bias"), h->vis.L[0].ln1w, h->vis.L[0].ln1b,
                                     h->ln, B * h->ntok, D, c.ln_eps, s, next_dir(h),
                                     h->sat_on ? h->sat_dev : nullptr,
-                                    W(h, "vision_model.embeddings.class_embedding"), a.pos, h->ntok));
+                                    W(h, "vision_model.embeddings.class_embedding"), a.pos, h->ntok, x2));
   }
-  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true, true))) return rc;
+  if ((rc = run_layers(h, s, h->vis, B, h->ntok, false, true, true, true, x2))) return rc;
   {
     Scope sc(h, s, MCM_KC_POOL_PROJECT, 2.0 * B * D * c.proj_dim);
     HIP_TRY(h, launch_pool_project(h->x, nullptr, h->ntok, B, D,
@@ -866,6 +897,22 @@ int mcm_encode_image_ex(mcm_handle* h, const void* pixels_dev, int32_t pixel_for
     return fail(h, MCM_EINVAL, "unknown pixel_format");
   return encode_image_impl(h, pixels_dev, pixel_format == MCM_PIXELS_U8_NHWC, B, out_dev, stream,
                            normalize != 0);
+}
+
+int mcm_x2_max_batch(const mcm_handle* h) { return h ? h->x2_batch : 0; }
+
+int mcm_encode_image_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, int32_t normalize,
+                        float* out_dev, void* stream) {
+  if (pixel_format != MCM_PIXELS_F32_NCHW && pixel_format != MCM_PIXELS_U8_NHWC)
+    return fail(h, MCM_EINVAL, "unknown pixel_format");
+  return encode_image_impl(h, pixels_dev, pixel_format == MCM_PIXELS_U8_NHWC, B, out_dev, stream, normalize != 0, true);
+}
+
+int mcm_score_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, const float* text_feat_dev,
+                 int32_t K, float T, int32_t kind, float* scores_dev, void* stream) {
+  int rc = mcm_encode_image_x2(h, pixels_dev, pixel_format, B, 1, h ? h->feat : nullptr, stream);
+  if (rc) return rc;
+  return mcm_score_features(h, h->feat, B, text_feat_dev, K, T, kind, scores_dev, stream);
 }
 
 int mcm_maha_prepare(mcm_handle* h, const float* means_dev, const float* prec_dev, int32_t C,
@@ -1210,12 +1257,16 @@ int mcm_op_linear_ex(mcm_handle* h, int32_t prec, const void* x_dev, const void*
                      void* stream) {
   if (!h) return MCM_EINVAL;
   if (epi < EPI_STORE || epi > EPI_RESID) return fail(h, MCM_EINVAL, "bad epilogue");
-  const bool split = (flags & MCM_LINEAR_SPLIT_W) != 0;
-  if ((flags & ~MCM_LINEAR_SPLIT_W) || (split && (prec == MCM_PREC_F32 || K % 64)))
+  const bool split = (flags & MCM_LINEAR_SPLIT_W) != 0, xs = (flags & MCM_LINEAR_SPLIT_X) != 0, os = (flags & MCM_LINEAR_SPLIT_OUT) != 0;
+  if ((flags & ~(MCM_LINEAR_SPLIT_W | MCM_LINEAR_SPLIT_X | MCM_LINEAR_SPLIT_OUT)) || (split && (prec == MCM_PREC_F32 || K % 64)))
     return fail(h, MCM_EINVAL, "bad flags (split weights: 16-bit modes, K % 64 == 0)");
+  if ((xs || os) && (prec != MCM_PREC_F16 || K % 64 || (os && (epi > EPI_GELU || N % 64))))
+    return fail(h, MCM_EINVAL, "bad flags (split activations / outputs: fp16 mode, K % 64 == 0; outputs: epilogues 0 / 1, N % 64 == 0)");
   GemmArgs a{};
   a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.out = y_dev; a.resid = resid_dev;
-  a.M = M; a.N = N; a.K = split ? 2 * K : K; a.ldx = K; a.ldo = N; a.ksplit = split ? 1 : 0;
+  a.M = M; a.N = N; a.K = split ? 2 * K : K; a.ldx = xs ? 2 * K : K; a.ldo = os ? 2 * N : N; a.ksplit = split ? 1 : 0;
+  a.xsplit = xs ? 1 : 0;
+  if (os) epi = epi == EPI_STORE ? EPI_STORE_X2 : EPI_GELU_X2;
   a.sat = h->sat_on ? h->sat_dev : nullptr;
   HIP_TRY(h, launch_gemm(prec, epi, a, (hipStream_t)stream));
   return MCM_OK;
@@ -1236,6 +1287,21 @@ int mcm_op_layernorm(mcm_handle* h, int32_t prec, const float* x_dev, const floa
   if (!h) return MCM_EINVAL;
   HIP_TRY(h, launch_layernorm(prec, x_dev, gamma_dev, beta_dev, y_dev, M, D, eps, out_f32 != 0,
                               (hipStream_t)stream, 0, 0, false, h->sat_on ? h->sat_dev : nullptr));
+  return MCM_OK;
+}
+
+int mcm_op_layernorm_split(mcm_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                           void* y_dev, int32_t M, int32_t D, float eps, void* stream) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, launch_layernorm(MCM_PREC_F16, x_dev, gamma_dev, beta_dev, y_dev, M, D, eps, false, (hipStream_t)stream, 0, 0,
+                              false, h->sat_on ? h->sat_dev : nullptr, true));
+  return MCM_OK;
+}
+
+int mcm_op_attention_split(mcm_handle* h, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,
+                           int32_t heads, void* stream) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, launch_attention(MCM_PREC_F16, qkv_dev, out_dev, nseq, seq_len, heads, false, 0, (hipStream_t)stream, false, 0, true));
   return MCM_OK;
 }
 

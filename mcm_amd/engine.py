@@ -82,6 +82,12 @@ def load_library(harness: bool = False):
     L.mcm_op_split_weight.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.mcm_op_layernorm.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp]
     L.mcm_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    L.mcm_op_layernorm_split.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    L.mcm_op_attention_split.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.mcm_x2_max_batch.argtypes = [vp]
+    L.mcm_x2_max_batch.restype = i32
+    L.mcm_encode_image_x2.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.mcm_score_x2.argtypes = [vp, vp, i32, i32, vp, i32, f32, i32, vp, vp]
     if harness:
         L.mcm_debug_gemm_variant.argtypes = [i32]
         L.mcm_debug_attention_variant.argtypes = [i32]
@@ -141,6 +147,7 @@ EXPORTED_SYMBOLS = [
     "mcm_saturation_check", "mcm_saturation_count",
     "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight", "mcm_pack_u8",
     "mcm_jpeg_entropy_decode", "mcm_jpeg_reconstruct",
+    "mcm_x2_max_batch", "mcm_encode_image_x2", "mcm_score_x2", "mcm_op_layernorm_split", "mcm_op_attention_split",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
@@ -344,6 +351,52 @@ class NativeCLIP:
                            SCORE_KINDS[score], out[s:s + n].data_ptr(), _stream_ptr()))
         return out
 
+    # -- split-activation arm: the re-scorer of threshold refinement (include/mcm.h mcm_score_x2) ----------------------
+    @property
+    def x2_max_batch(self) -> int:
+        """Largest batch of the split-activation arm on this handle's workspace (0: not an fp16 handle)."""
+        return int(self._lib.mcm_x2_max_batch(self._h))
+
+    def score_images_x2(self, pixel_values, text_features, T: float = 1.0, score: str = "MCM", out=None):
+        """`score_images` through the split-activation arm: the same weights and workspace, every MFMA operand activation as a
+        hi + lo pair of fp16 numbers — scores that agree with the exact-fp32 arm to fp32 round-off, at several times its
+        speed.  Any number of images (chunks of `x2_max_batch`)."""
+        import torch
+
+        nb = self.x2_max_batch
+        if nb <= 0:
+            raise RuntimeError("the split-activation arm needs an fp16 handle with max_batch >= 2")
+        px = self._pixels(pixel_values)
+        fmt = 1 if px.dtype == torch.uint8 else 0  # MCM_PIXELS_U8_NHWC / MCM_PIXELS_F32_NCHW
+        t = self._bank(text_features)
+        if out is None:
+            out = torch.empty(px.shape[0], device=self.device, dtype=torch.float32)
+        for s in range(0, px.shape[0], nb):
+            n = min(nb, px.shape[0] - s)
+            self._check(self._lib.mcm_score_x2(self._h, px[s:s + n].data_ptr(), fmt, n, t.data_ptr(), t.shape[0], float(T),
+                                               SCORE_KINDS[score], out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def get_image_features_x2(self, pixel_values, normalize: bool = False):
+        """`get_image_features` through the split-activation arm (raw projected features unless `normalize`)."""
+        import torch
+
+        nb = self.x2_max_batch
+        if nb <= 0:
+            raise RuntimeError("the split-activation arm needs an fp16 handle with max_batch >= 2")
+        px = self._pixels(pixel_values)
+        fmt = 1 if px.dtype == torch.uint8 else 0
+        out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
+        for s in range(0, px.shape[0], nb):
+            n = min(nb, px.shape[0] - s)
+            self._check(self._lib.mcm_encode_image_x2(self._h, px[s:s + n].data_ptr(), fmt, n, int(bool(normalize)),
+                                                      out[s:s + n].data_ptr(), _stream_ptr()))
+        return out
+
+    def x2_scorer(self):
+        """An object with this scorer's `score_images` signature that runs the split-activation arm (mcm_amd.refine.Rescorer)."""
+        return _X2Scorer(self)
+
     def reduce_bank(self, text_features, K: int, T: int):
         """[K*T,P] unit-norm template features (class-major) → [K,P] ensemble bank."""
         import torch
@@ -458,6 +511,20 @@ class NativeCLIP:
         self._check(self._lib.mcm_profile_read(self._h, ms, cnt, fl))
         return {k: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i]}
                 for i, k in enumerate(KERNEL_CLASSES)}
+
+
+class _X2Scorer:
+    """`NativeCLIP.x2_scorer()`: the split-activation arm behind the `score_images` / `max_batch` / `device` surface
+    mcm_amd.refine.Rescorer drives."""
+
+    label = "split-activation fp16 arm of the same handle (mcm_score_x2)"
+
+    def __init__(self, net):
+        self.net, self.device, self.geo = net, net.device, net.geo
+        self.max_batch = net.x2_max_batch
+
+    def score_images(self, pixel_values, text_features, T: float = 1.0, score: str = "MCM", out=None):
+        return self.net.score_images_x2(pixel_values, text_features, T, score, out=out)
 
 
 class GraphedScorer:
