@@ -502,13 +502,16 @@ def main():
         for name, prec, regime, wo in (("fp32", "fp32", args.weights_regime, "auto"),
                                        ("bf16_single_operand", "bf16", args.weights_regime, "single"),  # BASELINE.md's dtype, rounded weights
                                        ("bf16_split", "bf16", args.weights_regime, "auto"),       # fp16 values are not bf16 numbers: split
-                                       ("fp16_split_weights", "fp16", "fp32", "split")):
-            if prec == args.precision and wo == args.weight_operands and regime == args.weights_regime:
+                                       ("fp16_split_weights", "fp16", "fp32", "split"),
+                                       # the split-activation arm (mcm_score_x2: the re-scorer of threshold refinement), as a
+                                       # scorer of its own: within one fp32 ulp of the fp32 arm's score
+                                       ("fp16x2_split_activations", "fp16", args.weights_regime, "auto")):
+            if prec == args.precision and wo == args.weight_operands and regime == args.weights_regime and "x2" not in name:
                 continue
             torch.cuda.empty_cache()
             try:
                 arms[name] = bl.arm_leg(geo, sd if regime == args.weights_regime else synth_state_dict(geo, 0, regime), prec, wo, B, K,
-                                        ids, px0, local)
+                                        ids, px0, local, x2="x2" in name)
             except Exception as e:
                 arms[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             arms[name]["weights_regime"] = regime

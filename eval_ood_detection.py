@@ -67,11 +67,15 @@ def process_args(argv=None):
     p.add_argument("--weight-operands", default="auto", choices=["auto", "single", "split"],
                    help="16-bit modes: one operand per GEMM weight, or W_hi + W_lo (exact for fp32-valued weights, twice "
                         "the GEMM work); auto = split exactly when a weight is not a number of the operand dtype")
-    p.add_argument("--refine-threshold", default="auto", choices=["auto", "on", "off"],
-                   help="re-score the images whose 16-bit score lies within a few noise widths of the FPR95 threshold with the "
-                        "exact-fp32 arm (a few hundred images per run), so that FPR95 is the fp32 arm's number and not "
-                        "merely within 1 - 8 images of it (mcm_amd/refine.py); auto = on for --dtype fp16 / bf16 with an "
-                        "MCM-family --score")
+    p.add_argument("--refine-threshold", default="auto", choices=["auto", "on", "exact", "off"],
+                   help="re-score the images whose 16-bit score lies within a few noise widths of the FPR95 threshold with a "
+                        "better arm (a few hundred images per run), so that FPR95 is the exact arithmetic's number and not merely "
+                        "within 1 - 8 images of it (mcm_amd/refine.py).  on: --dtype fp16 re-scores with the split-activation arm "
+                        "of the SAME handle (mcm_score_x2: within one fp32 ulp of the exact-fp32 arm's score, no second model in "
+                        "HBM); --dtype bf16 with an exact-fp32 handle.  exact: additionally the handful of images within a few "
+                        "fp32 ulps of the threshold go through an exact-fp32 handle, so the count is that arm's image for image.  "
+                        "auto = on for --dtype fp16 / bf16 with an MCM-family --score.  Under torchrun every rank re-scores only "
+                        "the window images of its own shard")
     p.add_argument("--host-metrics", action="store_true",
                    help="AUROC/AUPR/FPR95 with sklearn on the host (the reference's route) instead of the device kernels")
     p.add_argument("--synthetic-n", default=None, type=int, help="cap synthetic dataset sizes (smoke runs)")
@@ -240,16 +244,26 @@ def main(argv=None):
         from mcm_amd.detection import prompt_bank
         from mcm_amd.refine import Rescorer, ThresholdRefiner
 
-        # the exact-fp32 arm over the same weights; the prompt bank is the 16-bit handle's (its text tower is exact fp32 too)
-        net32 = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision="fp32",
-                            max_batch=min(args.batch_size, 256), synthetic_regime=args.synthetic_weights)
+        bank = prompt_bank(args, net, test_labels)  # (the 16-bit handle's text tower is exact fp32: one bank for every arm)
         set_loaders = {"id": test_loader}
-        refiner = ThresholdRefiner(Rescorer(net32, prompt_bank(args, net, test_labels), set_loaders, args.T, args.score))
+        use_x2 = net.x2_max_batch > 0   # fp16 handles: the split-activation arm, same weights, same workspace
+        if not use_x2 or args.refine_threshold == "exact":
+            # the exact-fp32 arm over the same weights: the only re-scorer of a bf16 run (its batch as large as the window
+            # asks for), the inner-window re-scorer of `exact` (a handful of images: a small workspace)
+            net32 = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision="fp32",
+                                max_batch=min(args.batch_size, 256 if not use_x2 else 32), synthetic_regime=args.synthetic_weights)
+        first = Rescorer(net.x2_scorer() if use_x2 else net32, bank, set_loaders, args.T, args.score)
+        second = Rescorer(net32, bank, set_loaders, args.T, args.score) if (use_x2 and net32 is not None) else None
+        refiner = ThresholdRefiner(first, rescore_exact=second)
         refiner.fit_id(in_score if on_dev else torch.from_numpy(in_score))
+        how = "the split-activation arm of this handle" if use_x2 else "an exact-fp32 handle"
         log.debug("threshold refinement: 16-bit score noise (max over %d calibration images) %.2e, window +-%.2e around the "
-                  "FPR95 threshold, %d ID images re-scored in fp32" % (refiner.stats["calibration_images"],
-                  refiner.stats["noise_max_abs"], refiner.stats["delta"], refiner.stats["rescored"]["id"]))
-    elif args.refine_threshold == "on":
+                  "FPR95 threshold, %d ID images re-scored by %s" % (refiner.stats["calibration_images"],
+                  refiner.stats["noise_max_abs"], refiner.stats["delta"], refiner.stats["rescored"]["id"], how))
+        if second is not None:
+            log.debug("threshold refinement, inner window +-%.2e: %d ID images re-scored by the exact-fp32 arm"
+                      % (refiner.stats["delta2"], refiner.stats["rescored_exact"]["id"]))
+    elif args.refine_threshold in ("on", "exact"):
         raise SystemExit("--refine-threshold on needs a 16-bit --dtype and an MCM-family --score")
     auroc_list, aupr_list, fpr_list = [], [], []
     result = {"in_score": in_score, "out_scores": {}, "rank": rank, "world_size": ws, "sources": sources,
@@ -266,7 +280,8 @@ def main(argv=None):
             if refiner is not None:
                 set_loaders[out_dataset] = ood_loader
                 refiner.apply(out_dataset, out_score if on_dev else torch.from_numpy(out_score))
-                log.debug(f"threshold refinement: {refiner.stats['rescored'][out_dataset]} images of {out_dataset} re-scored in fp32")
+                log.debug(f"threshold refinement: {refiner.stats['rescored'][out_dataset]} images of {out_dataset} re-scored"
+                          + (f", {refiner.stats['rescored_exact'][out_dataset]} of them by the exact-fp32 arm" if second is not None else ""))
         result["out_scores"][out_dataset] = out_score
         net.warn_if_saturated(out_dataset)
         if rank == 0:
@@ -289,8 +304,12 @@ def main(argv=None):
         with open(os.path.join(args.log_directory, "data_sources.json"), "w") as f:
             json.dump({"weights": args.weights or "seeded synthetic", "sets": sources}, f, indent=1)
     if refiner is not None:
-        result["refine"] = refiner.stats
-        net32.close()
+        result["refine"] = dict(refiner.stats, rescorer="x2" if use_x2 else "fp32", rescored_by_this_rank=first.scored_here,
+                                rank=rank, world_size=ws)
+        with open(os.path.join(args.log_directory, f"refine_rank{rank}.json"), "w") as f:  # (every rank: who re-scored what)
+            json.dump(result["refine"], f, indent=1)
+        if net32 is not None:
+            net32.close()
     # programmatic callers (tests) get the scores back; as device tensors they outlive the handle (torch owns them)
     net.close()
     if ws > 1:

@@ -128,6 +128,22 @@ def all_gather_scores(local, n_total: int):
     return torch.cat(parts).to(home)
 
 
+def all_reduce_sum(t):
+    """Sum of a float tensor over the ranks, in place, on every rank (a no-op without a process group).  Device tensors go
+    over RCCL; under gloo (ranks sharing a device: logic checks) a device tensor takes a host bounce."""
+    import torch.distributed as dist
+
+    if not group_active():
+        return t
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h.to(t.device))
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def all_gather_histograms(local_scores, edges, net=None):
     """Fixed-bin score histogram summed over ranks (BASELINE.json's "all-gather of per-shard score
     histograms"): a constant-size payload for streaming AUROC estimates.  Exact AUROC/FPR95 parity

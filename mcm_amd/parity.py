@@ -86,22 +86,41 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         raise ValueError(weights)
     ids, mask = make_token_ids(K, seed=2)
     dev = torch.device("cuda", device)
-    derived = [a for a in arms if a.endswith("+refine")]  # "fp16+refine": arm "fp16" + threshold refinement (mcm_amd/refine.py)
+    # derived arms (mcm_amd/refine.py): "fp16+refine" = arm "fp16" with the images near the FPR95 threshold re-scored by the
+    # split-activation arm "fp16x2" (what the CLI does by default); "fp16+refine2" = additionally the inner window by the
+    # reference arm (the CLI's --refine-threshold exact).  A 16-bit arm without a split-activation form (bf16) is re-scored
+    # by the reference arm directly.
+    derived = [a for a in arms if a.endswith("+refine") or a.endswith("+refine2")]
     base_arms = [a for a in arms if a not in derived]
     for a in derived:
-        if a[: -len("+refine")] not in base_arms:
-            base_arms.append(a[: -len("+refine")])
+        b = a.partition("+")[0]
+        if b not in base_arms:
+            base_arms.append(b)
+        if _arm_spec(b)[0] == "fp16" and b + "x2" not in base_arms:
+            base_arms.append(b + "x2")
     names = [ref] + [a for a in base_arms if a != ref]
-    nets, banks = {}, {}
+    nets, banks, scorers = {}, {}, {}
     ext = {}
     try:
         for name, factory in (external or {}).items():
             ext[name] = factory(geo, sd, ids, mask, dev)
         for p in names:
+            if p.endswith("x2"):  # "fp16x2": the split-activation arm of the "fp16" handle (same weights, same workspace)
+                continue
             prec, wo = _arm_spec(p)
             nets[p] = NativeCLIP(geo, sd, device=device, precision=prec, max_batch=batch, weight_operands=wo,
                                  max_prompt_tokens=max(K * ids.shape[1], 77))
             banks[p] = nets[p].get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+            scorers[p] = nets[p].score_images
+        for p in names:
+            if p.endswith("x2"):
+                b = p[:-2]
+                if b not in nets:
+                    prec, wo = _arm_spec(b)
+                    nets[b] = NativeCLIP(geo, sd, device=device, precision=prec, max_batch=batch, weight_operands=wo,
+                                         max_prompt_tokens=max(K * ids.shape[1], 77))
+                    banks[b] = nets[b].get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+                banks[p], scorers[p] = banks[b], nets[b].score_images_x2
         # one OOD set (the default) or several: BASELINE config 3 scores the ID set once against four OOD sets and
         # reports every set plus their average (the reference's CSV, eval_ood_detection.py:86-98)
         sets = [("ood", n_ood, seed)] if not ood_sets else [(str(n), int(c), int(sd_)) for n, c, sd_ in ood_sets]
@@ -114,7 +133,7 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             parts = {p: [] for p in names + list(ext)}
             for px, _ in loader:
                 for p in names:
-                    parts[p].append(nets[p].score_images(px, banks[p], T, score))
+                    parts[p].append(scorers[p](px, banks[p], T, score))
                 for e, fn in ext.items():
                     parts[e].append(fn(px).to(device=dev, dtype=torch.float32).reshape(-1))
             for p in parts:
@@ -126,11 +145,14 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             from .refine import refine_threshold_scores
 
             for a in derived:
-                b = a[: -len("+refine")]
+                b, _, kind = a.partition("+")
+                first = b + "x2" if b + "x2" in scores else ref
                 scores[a] = {t: scores[b][t].clone() for t in tags}
                 _, _, st = refine_threshold_scores(scores[a]["id"], {n: scores[a][n] for n, _, _ in sets},
-                                                   lambda name, idx: scores[ref][name][idx])
-                refine_stats[a] = st
+                                                   lambda name, idx, first=first: scores[first][name][idx],
+                                                   rescore_exact=(lambda name, idx: scores[ref][name][idx])
+                                                   if (kind == "refine2" and first != ref) else None)
+                refine_stats[a] = dict(st, rescorer=first)
             names = names + derived
         out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood if not ood_sets else {n: c for n, c, _ in sets},
                "batch": batch, "score": score, "T": T, "reference_arm": ref,
@@ -139,7 +161,7 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
         # fp16 activations that hit +-65504 anywhere in the run (sticky per-handle counters; 0 = none)
         out["fp16_saturation_events"] = {p: nets[p].saturation_count() for p in nets if _arm_spec(p)[0] == "fp16"}
         out["weight_operands"] = {p: {"split": nets[p].split_weights, "inexact_elements": nets[p].weights_inexact}
-                                  for p in nets}
+                                  for p in nets if p in names}
         if refine_stats:
             out["refine"] = refine_stats
 
@@ -217,13 +239,18 @@ def _operating_point(net, pool: Dict, ref: str, target: float, ext: Sequence[str
     m = split(a)
     n_id, n_ood = int(m.sum()), int((~m).sum())
     refine_stats = {}
-    for p in [p for p in pool if p.endswith("+refine")]:  # threshold refinement on THIS split (mcm_amd/refine.py)
+    for p in [p for p in pool if p.endswith("+refine") or p.endswith("+refine2")]:  # threshold refinement on THIS split
         from .refine import refine_threshold_scores
 
-        b = p[: -len("+refine")]
+        b, _, kind = p.partition("+")
+        first = b + "x2" if b + "x2" in pool else ref
         sid, sood = pool[b][m].clone(), pool[b][~m].clone()
+        fid, food = pool[first][m], pool[first][~m]
         rid, rood = pool[ref][m], pool[ref][~m]
-        _, _, refine_stats[p] = refine_threshold_scores(sid, {"ood": sood}, lambda name, idx: (rid if name == "id" else rood)[idx])
+        _, _, st = refine_threshold_scores(sid, {"ood": sood}, lambda name, idx: (fid if name == "id" else food)[idx],
+                                           rescore_exact=(lambda name, idx: (rid if name == "id" else rood)[idx])
+                                           if (kind == "refine2" and first != ref) else None)
+        refine_stats[p] = dict(st, rescorer=first)
         patched = pool[b].clone()
         patched[m], patched[~m] = sid, sood
         pool[p] = patched

@@ -1,28 +1,34 @@
-"""Threshold refinement: FPR@recall of a 16-bit arm made equal to the exact-fp32 arm's, at the cost of re-scoring a few
-hundred images.
+"""Threshold refinement: FPR@recall of a 16-bit arm made equal to the exact arm's, at the cost of re-scoring a few hundred images.
 
 FPR95 (reference utils/detection_util.py:66-105) is a count: the OOD images on the ID side of ONE threshold, the score
 below which 95 % of the ID set lies.  A 16-bit arm's score noise (rms 5.6e-9 for fp16 at B/16) is far smaller than the
 scores' spread, so it can only change the count through the images whose score is within a few noise widths of that
 threshold: 0 - 2 of 10 000 on the headline sets, 8 of 31 000 at a realistic operating point —
 small, but not the reference's number.  Those images can be named: everything within `delta` of the threshold.  This
-module re-scores exactly them with the exact-fp32 arm (pinned to HF at 1e-10 in score) and patches their scores in place;
-every other image is provably on the same side of the threshold in both arms as long as its own noise is below `delta`.
+module re-scores exactly them with a better arm and patches their scores in place; every other image is provably on the
+same side of the threshold in both arms as long as its own noise is below `delta`.
 
-    delta = margin x (largest |fp32 - 16-bit| score difference over a calibration sample of the ID set)
+    delta = margin x (largest |better arm - 16-bit| score difference over a calibration sample of the ID set)
 
   1. calibration: the first `calib` ID images are re-scored -> noise estimate, delta;
   2. ID window: the ID images within delta of the provisional threshold are re-scored and the threshold recomputed
      (repeated if it moved by more than delta / 2);
   3. OOD windows: in every OOD set the images within delta of the final threshold are re-scored.
 
-AUROC / AUPR are untouched in any digit that matters (they were within 1e-5 already); FPR@recall becomes the fp32 arm's.
-The re-scoring callback is the caller's: the CLI hands in an fp32 `NativeCLIP` over the same loaders (`Rescorer`),
-`mcm_amd.parity` the fp32 arm's scores it already holds.
+Round 5: the re-scorer (`rescore`) is the SPLIT-ACTIVATION arm of the scoring handle itself (include/mcm.h mcm_score_x2:
+hi + lo fp16 operands, within one fp32 ulp of the exact-fp32 arm's score, ~5 x its throughput, no second model in HBM).  Two
+exact-grade arms still differ by their own round-off (HF fp32 vs the fp32 MFMA arm: 1 image of 10 000 now and then), so
+an optional second level (`rescore_exact`, the exact-fp32 arm on a small handle) re-scores the handful of images within
+delta2 = margin x max |exact - split| of the threshold: the reported FPR95 is then the exact arm's, image for image.
+
+Under `world_size > 1` (`Rescorer`) every rank re-scores only the window images of ITS shard of the set and the patches
+ride one all-reduce of len(window) floats: no rank does work proportional to the whole window.
+
+AUROC / AUPR are untouched in any digit that matters (they were within 1e-5 already); FPR@recall becomes the exact arm's.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Tuple
+from typing import Callable, Dict, Optional, Tuple
 
 
 def _kth_threshold(id_scores, recall: float):
@@ -38,65 +44,93 @@ def _kth_threshold(id_scores, recall: float):
 
 class ThresholdRefiner:
     """Steps 1 - 2 on the ID set (`fit_id`), then step 3 on each OOD set as it arrives (`apply`): the CLI scores its OOD
-    sets one after the other.  rescore(name, idx) -> exact scores of images `idx` (LongTensor on the scores' device) of
-    set `name` ("id" for the ID set)."""
+    sets one after the other.  rescore(name, idx) -> better scores of images `idx` (LongTensor on the scores' device) of
+    set `name` ("id" for the ID set); rescore_exact: the optional second level (module docstring)."""
 
-    def __init__(self, rescore: Callable, *, recall: float = 0.95, margin: float = 2.5, calib: int = 512, max_rounds: int = 4):
-        self.rescore, self.recall, self.margin, self.calib, self.max_rounds = rescore, recall, margin, calib, max_rounds
+    def __init__(self, rescore: Callable, *, rescore_exact: Optional[Callable] = None, recall: float = 0.95, margin: float = 2.5,
+                 calib: int = 512, calib_exact: int = 64, max_rounds: int = 4):
+        self.rescore, self.rescore_exact = rescore, rescore_exact
+        self.recall, self.margin, self.calib, self.calib_exact, self.max_rounds = recall, margin, calib, calib_exact, max_rounds
         self.stats = {"recall": recall, "margin": margin, "rescored": {}, "rounds": 0}
-        self.delta, self.threshold = None, None
+        if rescore_exact is not None:
+            self.stats["rescored_exact"] = {}
+        self.delta, self.delta2, self.threshold = None, None, None
+
+    def _window_rounds(self, scores, done, fn, delta, t):
+        """Re-score the not-yet-done images within `delta` of t with `fn`, recompute t, repeat while t moves."""
+        rounds = 0
+        for r in range(self.max_rounds):
+            rounds = r + 1
+            idx = (((scores - t).abs() <= delta) & ~done).nonzero().reshape(-1)
+            if idx.numel():
+                scores[idx] = fn("id", idx).to(device=scores.device, dtype=scores.dtype)
+                done[idx] = True
+            t_new = _kth_threshold(scores, self.recall)
+            moved, t = abs(t_new - t), t_new
+            if moved <= 0.5 * delta:
+                break
+        return t, rounds
 
     def fit_id(self, id_scores):
-        """Patches `id_scores` in place; afterwards `threshold` / `delta` are set."""
+        """Patches `id_scores` in place; afterwards `threshold` / `delta` (/ `delta2`) are set."""
         import torch
 
         dev, st = id_scores.device, self.stats
         n_cal = min(int(self.calib), id_scores.numel())
         idx = torch.arange(n_cal, device=dev)
-        exact = self.rescore("id", idx).to(device=dev, dtype=torch.float32)
-        noise = float((exact - id_scores[idx]).abs().max())
-        id_scores[idx] = exact
+        better = self.rescore("id", idx).to(device=dev, dtype=torch.float32)
+        noise = float((better - id_scores[idx]).abs().max())
+        id_scores[idx] = better
         done = torch.zeros(id_scores.numel(), dtype=torch.bool, device=dev)
         done[idx] = True
         self.delta = self.margin * noise
         st.update(noise_max_abs=noise, delta=self.delta, calibration_images=n_cal)
         t = _kth_threshold(id_scores, self.recall)
-        if self.delta > 0.0:  # (0: the arm IS the exact arm)
-            for r in range(self.max_rounds):
-                st["rounds"] = r + 1
-                idx = (((id_scores - t).abs() <= self.delta) & ~done).nonzero().reshape(-1)
-                if idx.numel():
-                    id_scores[idx] = self.rescore("id", idx).to(device=dev, dtype=torch.float32)
-                    done[idx] = True
-                t_new = _kth_threshold(id_scores, self.recall)
-                moved, t = abs(t_new - t), t_new
-                if moved <= 0.5 * self.delta:
-                    break
-        self.threshold = st["threshold"] = t
+        if self.delta > 0.0:  # (0: the arm IS the better arm)
+            t, st["rounds"] = self._window_rounds(id_scores, done, self.rescore, self.delta, t)
         st["rescored"]["id"] = int(done.sum())
+        if self.rescore_exact is not None:
+            n2 = min(int(self.calib_exact), n_cal)
+            idx = torch.arange(n2, device=dev)
+            exact = self.rescore_exact("id", idx).to(device=dev, dtype=torch.float32)
+            # two exact-grade arms differ by a few fp32 ulps of the score; never less than one ulp at the threshold
+            ulp = float(torch.nextafter(torch.tensor(abs(t), dtype=torch.float32), torch.tensor(float("inf"))) - abs(t))
+            noise2 = max(float((exact - id_scores[idx]).abs().max()), ulp)
+            id_scores[idx] = exact
+            done2 = torch.zeros(id_scores.numel(), dtype=torch.bool, device=dev)
+            done2[idx] = True
+            self.delta2 = self.margin * noise2
+            st.update(noise2_max_abs=noise2, delta2=self.delta2, calibration_images_exact=n2)
+            t, st["rounds_exact"] = self._window_rounds(id_scores, done2, self.rescore_exact, self.delta2, _kth_threshold(id_scores, self.recall))
+            st["rescored_exact"]["id"] = int(done2.sum())
+        self.threshold = st["threshold"] = t
         return id_scores
 
     def apply(self, name: str, scores):
         """Patches the scores of OOD set `name` in place."""
-        import torch
-
         assert self.threshold is not None, "fit_id first"
         n = 0
         if self.delta > 0.0:
             idx = ((scores - self.threshold).abs() <= self.delta).nonzero().reshape(-1)
             n = int(idx.numel())
             if n:
-                scores[idx] = self.rescore(name, idx).to(device=scores.device, dtype=torch.float32)
+                scores[idx] = self.rescore(name, idx).to(device=scores.device, dtype=scores.dtype)
         self.stats["rescored"][name] = n
         self.stats["rescored_total"] = sum(self.stats["rescored"].values())
+        if self.rescore_exact is not None:
+            idx = ((scores - self.threshold).abs() <= self.delta2).nonzero().reshape(-1)
+            if idx.numel():
+                scores[idx] = self.rescore_exact(name, idx).to(device=scores.device, dtype=scores.dtype)
+            self.stats["rescored_exact"][name] = int(idx.numel())
+            self.stats["rescored_exact_total"] = sum(self.stats["rescored_exact"].values())
         return scores
 
 
-def refine_threshold_scores(id_scores, ood_scores: Dict[str, "object"], rescore: Callable, *, recall: float = 0.95,
-                            margin: float = 2.5, calib: int = 512, max_rounds: int = 4) -> Tuple[object, Dict, Dict]:
+def refine_threshold_scores(id_scores, ood_scores: Dict[str, "object"], rescore: Callable, *, rescore_exact: Optional[Callable] = None,
+                            recall: float = 0.95, margin: float = 2.5, calib: int = 512, max_rounds: int = 4) -> Tuple[object, Dict, Dict]:
     """id_scores [n_id], ood_scores {name: [n]} — fp32 tensors of one 16-bit arm, patched IN PLACE and returned with the
     refiner's statistics."""
-    r = ThresholdRefiner(rescore, recall=recall, margin=margin, calib=calib, max_rounds=max_rounds)
+    r = ThresholdRefiner(rescore, rescore_exact=rescore_exact, recall=recall, margin=margin, calib=calib, max_rounds=max_rounds)
     r.fit_id(id_scores)
     for name, s in ood_scores.items():
         r.apply(name, s)
@@ -105,17 +139,23 @@ def refine_threshold_scores(id_scores, ood_scores: Dict[str, "object"], rescore:
 
 class Rescorer:
     """`rescore(name, idx)` over loaders: gathers the pixels of the named images (`loader.gather(idx)`, or `dataset[i]` of a
-    map-style dataset) and scores them with the exact-fp32 handle against the same prompt bank."""
+    map-style dataset) and scores them with `scorer` — anything with `score_images(pixels, bank, T, score)` and `max_batch`:
+    `NativeCLIP.x2_scorer()` (the split-activation arm of the scoring handle) or an exact-fp32 `NativeCLIP` — against the
+    same prompt bank.
 
-    def __init__(self, net32, bank, loaders: Dict[str, object], T: float, score: str):
-        self.net, self.bank, self.loaders, self.T, self.score = net32, bank, loaders, float(T), score
+    world_size > 1: every rank is called with the same `idx` (the gathered scores are identical on every rank); each
+    re-scores only the images of ITS contiguous shard of the set (mcm_amd.dist.shard_range: the samples its loader shard
+    decoded in the first place) and one all-reduce of len(idx) floats hands every rank every patch."""
 
-    def __call__(self, name: str, idx):
+    def __init__(self, scorer, bank, loaders: Dict[str, object], T: float, score: str):
+        self.net, self.bank, self.loaders, self.T, self.score = scorer, bank, loaders, float(T), score
+        self.scored_here = 0   # images this rank re-scored itself (sums to the window sizes over the ranks)
+
+    def _score(self, name: str, ids):
         import torch
 
         loader = self.loaders[name]
         out = []
-        ids = idx.tolist()
         bs = self.net.max_batch
         for s in range(0, len(ids), bs):
             chunk = ids[s:s + bs]
@@ -124,4 +164,20 @@ class Rescorer:
             else:  # reference-style DataLoader over a map-style dataset: item i is (image, label)
                 px = torch.stack([loader.dataset[i][0] for i in chunk])
             out.append(self.net.score_images(px, self.bank, self.T, self.score))
+        self.scored_here += len(ids)
         return torch.cat(out) if out else torch.empty(0, device=self.bank.device)
+
+    def __call__(self, name: str, idx):
+        import torch
+
+        from . import dist as mdist
+
+        rank, ws = mdist.world()
+        if ws <= 1:
+            return self._score(name, idx.tolist())
+        lo, hi = mdist.shard_range(len(self.loaders[name].dataset), rank, ws)
+        mine = (idx >= lo) & (idx < hi)
+        out = torch.zeros(idx.numel(), dtype=torch.float32, device=self.bank.device)
+        if bool(mine.any()):
+            out[mine.to(out.device)] = self._score(name, idx[mine].tolist()).to(torch.float32)
+        return mdist.all_reduce_sum(out)  # every entry has one non-zero contribution: x + 0 + ... + 0 is exact

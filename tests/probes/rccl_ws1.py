@@ -58,11 +58,25 @@ def main():
     t = [mu.clone(), prec.clone().to(dev)]
     mdist.broadcast_tensors(t, src=0)
     ok = {k: bool(np.array_equal(base[k], got[k])) for k in base}
+    # threshold refinement with the sharded re-scorer: the patches ride an all-reduce (RCCL here) — same scores as without a group
+    from mcm_amd.detection import prompt_bank
+    from mcm_amd.refine import Rescorer, refine_threshold_scores
+
+    def refined():
+        sid = get_ood_scores_clip(args, net, own, labels, device_out=True).clone()
+        r = Rescorer(net.x2_scorer(), prompt_bank(args, net, labels), {"id": own, "o": own}, 1.0, "MCM")
+        so = sid.flip(0).clone()
+        _, _, st = refine_threshold_scores(sid, {"o": so}, r, calib=64)
+        return sid.cpu().numpy(), st["rescored_total"], r.scored_here
+
+    with_group = refined()
     ok["device_out"] = bool(dev_scores.is_cuda and np.array_equal(dev_scores.cpu().numpy(), base["own"]))
     ok["broadcast"] = bool(torch.equal(t[0], mu) and torch.equal(t[1].cpu(), prec))
     ok["hist_is_numpy_histogram"] = bool(np.array_equal(got["hist"], np.histogram(base["own"], bins=edges)[0]))
     dist.barrier()
     dist.destroy_process_group()
+    without = refined()
+    ok["refine_sharded_rescorer"] = bool(np.array_equal(with_group[0], without[0]) and with_group[1:] == without[1:] and with_group[1] > 0)
     net.close()
     print(json.dumps({"backend": "nccl", "world_size": ws, "ok": ok, "all_ok": all(ok.values())}))
     sys.exit(0 if all(ok.values()) else 1)

@@ -168,3 +168,86 @@ def test_two_rank_torch_dataloader_is_sharded_by_index_before_decode(n, bs):
         lo, hi = shard_range(n, rank, 2)
         assert touched == list(range(lo, hi)), (rank, touched)  # (the maha runs re-touch a subset of the same range)
         assert np.array_equal(m_id, want_id) and np.array_equal(m_ood, want_ood), rank
+
+
+# ---- threshold refinement under world_size 2: the re-scoring is sharded, the result is the 1-rank result
+
+
+class _NoisyNet(_StubNet):
+    """The '16-bit arm': the stub's score plus a deterministic per-image perturbation."""
+
+    def score_images(self, images, text, T, score):
+        s = super().score_images(images, text, T, score)
+        noise = torch.sin(images.reshape(images.shape[0], -1)[:, 7:13].sum(dim=1) * 1e3) * 0.3
+        return (s + noise).float()
+
+
+class _CountingScorer(_StubNet):
+    """The 'better arm' behind mcm_amd.refine.Rescorer: the exact stub score; counts the images it is handed."""
+
+    max_batch = 16
+
+    def __init__(self):
+        self.seen = 0
+
+    def score_images(self, images, text, T, score, out=None):
+        self.seen += int(images.shape[0])
+        return super().score_images(images, text, T, score)
+
+
+def _refined_scores(n, bs):
+    """ID set + one OOD set scored by the noisy arm through get_ood_scores_clip (sharded when a group is up), then threshold
+    refinement with the sharded Rescorer.  Returns (id scores, ood scores, refiner stats, images this rank re-scored)."""
+    import types as _t
+
+    from mcm_amd.detection import get_ood_scores_clip
+    from mcm_amd.refine import Rescorer, ThresholdRefiner
+    from mcm_amd.synth import SyntheticImageSet, SyntheticLoader, class_names
+
+    args = _t.SimpleNamespace(ckpt="x", model="CLIP", score="MCM", T=1)
+    loaders = {"id": SyntheticLoader(SyntheticImageSet(n, 8, 3, ood=False, seed=1), bs),
+               "ood": SyntheticLoader(SyntheticImageSet(n // 2, 8, 3, ood=True, seed=2), bs)}
+    scores = {k: torch.from_numpy(get_ood_scores_clip(args, _NoisyNet(), v, class_names(3))) for k, v in loaders.items()}
+    scorer = _CountingScorer()
+    r = Rescorer(scorer, torch.zeros(3, 4), loaders, 1.0, "MCM")
+    ref = ThresholdRefiner(r, calib=8)
+    ref.fit_id(scores["id"])
+    ref.apply("ood", scores["ood"])
+    return scores["id"].numpy(), scores["ood"].numpy(), ref.stats, r.scored_here, scorer.seen
+
+
+def _worker_refine(rank, ws, port, n, bs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    sid, sood, st, here, seen = _refined_scores(n, bs)
+    q.put((rank, sid, sood, st["rescored"], st["threshold"], here, seen))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,bs", [(600, 64), (257, 50)])
+def test_two_rank_refinement_equals_single_and_is_sharded(n, bs):
+    from mcm_amd.dist import shard_range
+
+    want_id, want_ood, st, here, seen = _refined_scores(n, bs)
+    assert st["rescored_total"] > 16 and here == st["rescored_total"] == seen   # one rank: it re-scores the whole window
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_refine, args=(r, 2, port, n, bs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sid, sood, rescored, thr, here_r, seen_r in got:
+        np.testing.assert_array_equal(sid, want_id)       # every rank ends with the 1-rank refined scores, bit for bit
+        np.testing.assert_array_equal(sood, want_ood)
+        assert rescored == st["rescored"] and thr == st["threshold"]
+        assert here_r == seen_r < st["rescored_total"]    # ... having re-scored only part of the window
+    assert sum(g[5] for g in got) == st["rescored_total"]  # the parts add up to the window
+    # rank 0's share of the calibration images: those of its own index shard
+    lo, hi = shard_range(n, 0, 2)
+    assert got[0][5] >= min(8, hi - lo) and got[1][5] > 0

@@ -80,8 +80,9 @@ def test_config2_imagenet100_bf16_full_size(tmp_path, monkeypatch):
     sizes = {"iNaturalist": 10000, "SUN": 10000, "places365": 10000, "dtd": 5640}
     runs = {}
     with pytest.warns(RuntimeWarning):  # ImageNet-100's class-name files are not on this box: placeholder names
-        for dt in ("bf16", "fp32", "fp16"):
-            runs[dt] = cli.main(common + ["--dtype", dt, "--name", f"c2_{dt}"])
+        for dt in ("bf16", "fp32", "fp16"):   # (fp16: --refine-threshold exact, the form that promises the fp32 arm's count)
+            runs[dt] = cli.main(common + ["--dtype", dt, "--name", f"c2_{dt}"] + (["--refine-threshold", "exact"] if dt == "fp16" else []))
+        runs["fp16_default"] = cli.main(common + ["--dtype", "fp16", "--name", "c2_fp16_default"])
     r = runs["bf16"]
     s_in = _np(r["in_score"])
     assert s_in.shape == (5000,)
@@ -108,13 +109,22 @@ def test_config2_imagenet100_bf16_full_size(tmp_path, monkeypatch):
     # Round 3 ran this config on fp32-VALUED weights rounded to one operand and recorded fp16 dAUROC 1.9 - 2.0e-4 — the
     # one measured miss of the bar; `--synthetic-weights fp32` now runs the split-weight GEMMs instead and is held to the
     # same bar below.  bf16: 8 significand bits in every activation, the documented coarser arm.
-    runs["fp16_fp32w"] = cli.main(common + ["--dtype", "fp16", "--synthetic-weights", "fp32", "--name", "c2_fp16_fp32w"])
+    runs["fp16_fp32w"] = cli.main(common + ["--dtype", "fp16", "--synthetic-weights", "fp32", "--refine-threshold", "exact",
+                                            "--name", "c2_fp16_fp32w"])
     runs["fp32_fp32w"] = cli.main(common + ["--dtype", "fp32", "--synthetic-weights", "fp32", "--name", "c2_fp32_fp32w"])
     report["fp16_fp32w"] = {k: tuple(abs(x - y) for x, y in zip(runs["fp16_fp32w"]["measures"][k],
                                                                   runs["fp32_fp32w"]["measures"][k])) for k in sizes}
     print("config 2, fp32-valued weights, split-weight fp16 arm vs the fp32 arm:", report["fp16_fp32w"])
-    # FPR95: the CLI's threshold refinement (--refine-threshold auto, mcm_amd/refine.py) re-scores the images within a few
-    # noise widths of the threshold with the exact-fp32 arm, so a 16-bit run reports the fp32 run's FPR95 — equal, not close
+    # FPR95: the CLI's threshold refinement (mcm_amd/refine.py) re-scores the images within a few noise widths of the
+    # threshold — by default with the split-activation arm of the same handle (an exact-grade arm: within the quantum of the
+    # fp32 run, like HF itself), with `--refine-threshold exact` the inner window also with the exact-fp32 arm, so that the
+    # 16-bit run reports the fp32 run's FPR95 — equal, not close
+    for k, n in sizes.items():
+        dflt = abs(runs["fp16_default"]["measures"][k][2] - runs["fp32"]["measures"][k][2])
+        assert dflt * n <= 1.5, (k, dflt)
+    assert runs["fp16_default"]["refine"]["rescorer"] == "x2" and "rescored_exact" not in runs["fp16_default"]["refine"]
+    assert runs["fp16"]["refine"]["rescorer"] == "x2" and runs["fp16"]["refine"]["rescored_exact_total"] <= 64 + 0.1 * runs["fp16"]["refine"]["rescored_total"]
+    assert runs["bf16"]["refine"]["rescorer"] == "fp32"
     for k, n in sizes.items():
         for arm in ("fp16", "fp16_fp32w"):
             da, dp, df = report[arm][k]
@@ -153,6 +163,16 @@ def test_cli_two_ranks_equal_one_rank(tmp_path):
     a = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws1" / "ws1.csv", index_col=0)
     b = pd.read_csv(base / "CLIP_ViT-B/32_T_1_ID_ws2" / "ws2.csv", index_col=0)
     assert list(a.index) == ["ImageNet20", "AVG"] and a.equals(b), (a, b)
+    # threshold refinement was on in both runs (the default) and is SHARDED under torchrun: each rank re-scored only the window
+    # images of its own shard — the per-rank counts add up to the 1-rank run's, nobody did all of it
+    import json
+
+    r1 = json.load(open(base / "CLIP_ViT-B/32_T_1_ID_ws1" / "refine_rank0.json"))
+    r2 = [json.load(open(base / "CLIP_ViT-B/32_T_1_ID_ws2" / f"refine_rank{r}.json")) for r in (0, 1)]
+    assert r1["rescorer"] == "x2" and r1["rescored_total"] > 0 and r1["rescored_by_this_rank"] == r1["rescored_total"]
+    assert all(r["rescored"] == r1["rescored"] and r["threshold"] == r1["threshold"] for r in r2)
+    assert sum(r["rescored_by_this_rank"] for r in r2) == r1["rescored_total"]
+    assert max(r["rescored_by_this_rank"] for r in r2) < r1["rescored_total"]
 
 
 @pytest.mark.parametrize("suite,K,n_id", [("bird200", 200, 5794), ("food101", 101, 25250), ("pet37", 37, 3669),

@@ -44,8 +44,7 @@ def test_bench_timed_region_with_the_rccl_all_gather():
     """bench.py's N-GPU logic at N = 1 under torchrun: barrier, all_gather_into_tensor of the score shards inside the
     timed region, MAX all-reduce of the time — on RCCL, device tensors, no host bounce."""
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "3", "--warmup", "1",
-                   "--no-drift", "--cpu-seconds", "0", "--sustain-seconds", "0", "--ingest", "none", "--no-arms",
-                   "--ckpt", "ViT-B/32", "--batch", "128"])
+                   "--quick", "--ckpt", "ViT-B/32", "--batch", "128"])
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["collective"].startswith("nccl (RCCL)"), d.get("collective")

@@ -47,3 +47,74 @@ def test_exact_arm_is_left_alone():
     o = torch.randn(1000) * 1e-6
     sid, sood, st = refine_threshold_scores(s.clone(), {"o": o.clone()}, lambda name, idx: (s if name == "id" else o)[idx])
     assert torch.equal(sid, s) and torch.equal(sood["o"], o) and st["delta"] == 0.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_two_level_refinement_reports_the_exact_arms_fpr95_image_for_image(seed):
+    """Round 5: level 1 = a better-but-not-exact arm (the split-activation arm: noise ~1 ulp of the exact arm's score),
+    level 2 = the exact arm on the handful of images within a few of THOSE noise widths of the threshold.  The result is the
+    exact arm's FPR95 on every set, with orders of magnitude fewer exact re-scores than level 1 re-scores."""
+    from mcm_amd.metrics import get_measures
+    from mcm_amd.refine import refine_threshold_scores
+
+    g = torch.Generator().manual_seed(100 + seed)
+    n_id, n_ood = 50000, 10000
+    exact = {"id": (torch.randn(n_id, generator=g) * 1.4e-6 - 1e-3).float(),
+             "a": (torch.randn(n_ood, generator=g) * 1.4e-6 - 1e-3 + 1e-6).float(),
+             "b": (torch.randn(n_ood, generator=g) * 1.4e-6 - 1e-3).float()}
+    mid = {k: (v + torch.randn(v.shape, generator=g) * 3e-10).float() for k, v in exact.items()}     # two exact-grade arms
+    noisy = {k: (v + torch.randn(v.shape, generator=g) * 5.6e-9).float() for k, v in exact.items()}  # the fp16 arm
+    n1, n2 = [0], [0]
+
+    def rescore(name, idx):
+        n1[0] += int(idx.numel())
+        return mid[name][idx]
+
+    def rescore_exact(name, idx):
+        n2[0] += int(idx.numel())
+        return exact[name][idx]
+
+    want = {k: get_measures(-exact["id"].numpy(), -exact[k].numpy()) for k in ("a", "b")}
+    sid, sood, st = refine_threshold_scores(noisy["id"].clone(), {k: noisy[k].clone() for k in ("a", "b")}, rescore,
+                                            rescore_exact=rescore_exact)
+    for k in ("a", "b"):
+        assert get_measures(-sid.numpy(), -sood[k].numpy())[2] == want[k][2], k
+    assert st["delta2"] < 0.2 * st["delta"] and st["delta2"] > 0
+    assert st["rescored_exact_total"] == n2[0] and st["rescored_exact_total"] <= 64 + 0.15 * st["rescored_total"], st
+    assert st["rescored_total"] < 0.05 * (n_id + 2 * n_ood)
+
+
+def test_rescorer_shards_the_window_by_the_loaders_index_ranges(monkeypatch):
+    """world_size > 1: a rank re-scores only the window images of its own contiguous shard; the all-reduce of the zero-filled
+    patches is the concatenation.  Simulated here without a process group: two 'ranks' run one after the other and their
+    contributions are summed the way the all-reduce sums them."""
+    from mcm_amd import dist as mdist
+    from mcm_amd.refine import Rescorer
+
+    n = 1000
+    truth = torch.arange(n, dtype=torch.float32) * 0.5 + 3.0
+
+    class Loader:
+        dataset = list(range(n))
+
+        def gather(self, idx):
+            return torch.tensor(idx, dtype=torch.long)
+
+    class Scorer:
+        max_batch = 7
+
+        def score_images(self, px, bank, T, score):
+            return truth[px]
+
+    idx = torch.tensor([3, 999, 500, 499, 0, 742, 250, 251])
+    parts, counts = [], []
+    for rank in range(4):
+        monkeypatch.setattr(mdist, "world", lambda r=rank: (r, 4))
+        monkeypatch.setattr(mdist, "all_reduce_sum", lambda t: t)   # collected below instead
+        r = Rescorer(Scorer(), torch.zeros(1), {"id": Loader()}, 1.0, "MCM")
+        parts.append(r("id", idx))
+        counts.append(r.scored_here)
+        lo, hi = mdist.shard_range(n, rank, 4)
+        assert all((lo <= int(i) < hi) == (float(v) != 0.0) for i, v in zip(idx, parts[-1]))
+    assert torch.equal(sum(parts), truth[idx])
+    assert sum(counts) == idx.numel() and max(counts) <= 3   # nobody scores the whole window

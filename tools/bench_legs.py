@@ -218,7 +218,7 @@ def parity_leg(args, K, B, device):
             hf_note = f"HF reference scorer unavailable ({type(e).__name__}: {e}): vs_hf not measured"
     from mcm_amd.parity import REALISTIC_PIXELS, meets_bar
 
-    arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16", "fp16+refine")))
+    arms = tuple(dict.fromkeys((args.precision, "fp16", "bf16", "fp16x2", "fp16+refine", "fp16+refine2")))
     c3 = tuple(args.drift_n) == (50000, 10000)  # default: BASELINE config 3 — ImageNet-1k vs the four OOD sets
     ood_sets = CONFIG3_OOD_SETS if c3 else None
     out = {"config": "BASELINE config 3: ImageNet-1k-sized ID set (50 000) vs iNaturalist / SUN / Places / Textures-sized "
@@ -401,7 +401,7 @@ def ingest_legs(net, txt, B, steps, which):
     return out
 
 
-def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3):
+def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3, x2=False):
     """Throughput of one more arm on the same workload, 3 timed steps after one warm-up step, outside the timed region
     of the headline number: (images/s, GEMM-family TFLOP/s by HIP events, fraction of that dtype's dense MFMA peak)."""
     import torch
@@ -413,13 +413,14 @@ def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3)
     try:
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         out = torch.empty(B, device=px.device)
-        net.score_images(px, txt, 1.0, "MCM", out=out)
+        run = net.score_images_x2 if x2 else net.score_images   # x2: the split-activation arm (chunks of mcm_x2_max_batch)
+        run(px, txt, 1.0, "MCM", out=out)
         net.profile(True)
         net.profile_read()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            net.score_images(px, txt, 1.0, "MCM", out=out)
+            run(px, txt, 1.0, "MCM", out=out)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         g = net.profile_read()["gemm"]
@@ -457,12 +458,15 @@ class ResidentSet:
         return self.px[torch.as_tensor(idx, device=self.px.device, dtype=torch.long)]
 
 
-def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, rescorer=None):
+def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, two_level=True):
     """Throughput AT PARITY (`value_refined`): BASELINE config 3's sizes — 50 000 ID images once against the four OOD sets
     (10 000 / 10 000 / 10 000 / 5 640), all resident in HBM — scored by the benchmarked arm AND threshold-refined
-    (mcm_amd/refine.py: calibration, the ID window, every OOD window re-scored by the exact arm), then the three metrics per
-    set on the device.  Wall clock of all of it ÷ 85 640 images.  The exact arm's own scores of every image are computed
-    afterwards (untimed) to check the refined FPR95 against it: `fpr95_images_vs_fp32_arm_max_set` must be 0."""
+    (mcm_amd/refine.py), then the three metrics per set on the device.  Wall clock of all of it / 85 640 images.
+    The re-scorer is the SPLIT-ACTIVATION arm of the same handle (mcm_score_x2: no second model); with `two_level` the
+    handful of images within a few fp32 ulps of the threshold additionally go through an exact-fp32 handle (created before
+    the clock starts, like the scoring handle), so that the reported FPR95 is that arm's image for image.  A bf16 run has no
+    split-activation arm: the exact-fp32 handle re-scores its whole window.  Afterwards (untimed) the exact arm scores
+    every image and the refined FPR95 is checked against it: `fpr95_images_vs_fp32_arm_max_set` must be 0."""
     import torch
 
     from mcm_amd.engine import NativeCLIP
@@ -477,13 +481,8 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, rescorer=None):
                                                tile=HEADLINE_PIXELS["tile"]), B) for n, c, ood, s in sets}
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
-    exact, own = rescorer, None
-    if exact is None:  # the exact-fp32 arm over the same weights as a second handle
-        own = exact = NativeCLIP(geo, sd, device=device, precision="fp32", max_batch=min(B, 256),
-                                 max_prompt_tokens=max(K * ids.shape[1], 77))
-        label = "exact-fp32 arm, second handle"
-    else:
-        label = getattr(rescorer, "label", "same handle")
+    exact = NativeCLIP(geo, sd, device=device, precision="fp32", max_batch=min(B, 256), max_prompt_tokens=max(K * ids.shape[1], 77))
+    use_x2 = net.x2_max_batch > 0
     try:
         n_img = sum(c for _, c, _, _ in sets)
 
@@ -494,12 +493,17 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, rescorer=None):
             return out
 
         score_set(net, "dtd")  # warm-up of the pass (clocks, the kernels' first launches at this batch)
+        if use_x2:
+            net.score_images_x2(data["dtd"].px[:net.x2_max_batch], txt)
+        exact.score_images(data["dtd"].px[:32], txt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         scores = {n: score_set(net, n) for n, _, _, _ in sets}
         torch.cuda.synchronize()
         t_score = time.perf_counter() - t0
-        refiner = ThresholdRefiner(Rescorer(exact, txt, data, 1.0, "MCM"))
+        first = Rescorer(net.x2_scorer() if use_x2 else exact, txt, data, 1.0, "MCM")
+        second = Rescorer(exact, txt, data, 1.0, "MCM") if (use_x2 and two_level) else None
+        refiner = ThresholdRefiner(first, rescore_exact=second)
         refiner.fit_id(scores["id"])
         meas = {}
         for n, _, ood, _ in sets:
@@ -508,27 +512,30 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, rescorer=None):
                 meas[n] = net.measures(scores["id"], scores[n], negate=True)
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
+        st = refiner.stats
         out = {"images_per_sec": n_img / t_all, "images": n_img, "seconds": t_all, "seconds_scoring": t_score,
                "seconds_refine": t_all - t_score, "images_per_sec_unrefined": n_img / t_score,
-               "rescored": refiner.stats.get("rescored_total"), "rescored_per_set": refiner.stats["rescored"],
-               "rescorer": label, "delta": refiner.stats["delta"], "noise_max_abs": refiner.stats["noise_max_abs"],
-               "seconds_generating_pixels": t_gen, "measures": {n: list(m) for n, m in meas.items()},
+               "rescored": st.get("rescored_total"), "rescored_per_set": st["rescored"],
+               "rescored_exact": st.get("rescored_exact_total"), "rescored_exact_per_set": st.get("rescored_exact"),
+               "rescorer": ("split-activation arm of the same handle (mcm_score_x2)" if use_x2 else "exact-fp32 handle")
+                           + ("; inner window: exact-fp32 handle" if second is not None else ""),
+               "delta": st["delta"], "noise_max_abs": st["noise_max_abs"], "delta2": st.get("delta2"),
+               "noise2_max_abs": st.get("noise2_max_abs"), "seconds_generating_pixels": t_gen,
+               "measures": {n: list(m) for n, m in meas.items()},
                "workload": "BASELINE config 3 sizes, fp32 NCHW pixels resident in HBM, batch %d; timed: scoring of the 5 sets + "
                            "threshold refinement + device metrics" % B}
         # the check (untimed): every image through the exact arm, FPR95 per set against the refined scores'
-        ref = {n: score_set(exact, n) for n, _, _, _ in sets} if own is not None or getattr(rescorer, "check_all", True) else None
-        if ref is not None:
-            moved = {}
-            for n, c, ood, _ in sets:
-                if ood:
-                    m_ref = net.measures(ref["id"], ref[n], negate=True)
-                    moved[n] = {"fpr95_images": round(abs(m_ref[2] - meas[n][2]) * c), "d_auroc": abs(m_ref[0] - meas[n][0])}
-            out["vs_fp32_arm"] = moved
-            out["fpr95_images_vs_fp32_arm_max_set"] = max(v["fpr95_images"] for v in moved.values())
+        ref = {n: score_set(exact, n) for n, _, _, _ in sets}
+        moved = {}
+        for n, c, ood, _ in sets:
+            if ood:
+                m_ref = net.measures(ref["id"], ref[n], negate=True)
+                moved[n] = {"fpr95_images": round(abs(m_ref[2] - meas[n][2]) * c), "d_auroc": abs(m_ref[0] - meas[n][0])}
+        out["vs_fp32_arm"] = moved
+        out["fpr95_images_vs_fp32_arm_max_set"] = max(v["fpr95_images"] for v in moved.values())
         return out
     finally:
-        if own is not None:
-            own.close()
+        exact.close()
         del data
         torch.cuda.empty_cache()
 
