@@ -31,15 +31,22 @@ from __future__ import annotations
 from typing import Callable, Dict, Optional, Tuple
 
 
-def _kth_threshold(id_scores, recall: float):
-    """Provisional threshold in score space.  Scores are negated confidences (lower = more ID): recall r of the ID set lies
-    at or below the r-quantile.  The exact operating point (closest recall, tie rules) is `mcm_measures`' business; the
-    window only has to contain it, and neighbouring order statistics are orders of magnitude closer than delta."""
+def _threshold_interval(id_scores, recall: float):
+    """The score interval the FPR@recall count depends on.  Scores are negated confidences (lower = more ID).  The reference
+    (utils/detection_util.py:66-105) walks the thresholds in confidence order and takes the one whose recall is CLOSEST to
+    `recall`; between two consecutive ID scores the recall does not change, and its argmin over the reversed arrays picks the
+    far end of that run: with k = round(recall n) the count is #{OOD score < s_(k+1)}, s_(j) the j-th lowest ID score — not
+    s_(k).  Which neighbour it is also depends on how recall n rounds, so the interval returned is [s_(k-1), s_(k+1)]: every
+    image whose side of ANY of the three could change is inside the windows built around it (the exact operating point,
+    closest recall and tie rules, is `mcm_measures`' business).  Round 4 centred the window on s_(k) alone, which was only
+    right because its width (2.5 x the fp16 noise) dwarfed the spacing of neighbouring order statistics; the inner window
+    of the two-level form (a few fp32 ulps) does not."""
     import torch
 
     n = id_scores.numel()
     k = min(n, max(1, int(round(recall * n))))
-    return float(torch.kthvalue(id_scores.double(), k).values)
+    srt = torch.sort(id_scores.double()).values
+    return float(srt[max(0, k - 2)]), float(srt[min(n - 1, k)])   # 0-based: s_(k-1) = srt[k-2], s_(k+1) = srt[k]
 
 
 class ThresholdRefiner:
@@ -54,22 +61,27 @@ class ThresholdRefiner:
         self.stats = {"recall": recall, "margin": margin, "rescored": {}, "rounds": 0}
         if rescore_exact is not None:
             self.stats["rescored_exact"] = {}
-        self.delta, self.delta2, self.threshold = None, None, None
+        self.delta, self.delta2, self.threshold, self.interval = None, None, None, None
 
-    def _window_rounds(self, scores, done, fn, delta, t):
-        """Re-score the not-yet-done images within `delta` of t with `fn`, recompute t, repeat while t moves."""
+    @staticmethod
+    def _near(scores, iv, delta):
+        return (scores >= iv[0] - delta) & (scores <= iv[1] + delta)
+
+    def _window_rounds(self, scores, done, fn, delta, iv):
+        """Re-score the not-yet-done images within `delta` of the threshold interval with `fn`, recompute the interval, repeat
+        while it moves."""
         rounds = 0
         for r in range(self.max_rounds):
             rounds = r + 1
-            idx = (((scores - t).abs() <= delta) & ~done).nonzero().reshape(-1)
+            idx = (self._near(scores, iv, delta) & ~done).nonzero().reshape(-1)
             if idx.numel():
                 scores[idx] = fn("id", idx).to(device=scores.device, dtype=scores.dtype)
                 done[idx] = True
-            t_new = _kth_threshold(scores, self.recall)
-            moved, t = abs(t_new - t), t_new
+            new = _threshold_interval(scores, self.recall)
+            moved, iv = max(abs(new[0] - iv[0]), abs(new[1] - iv[1])), new
             if moved <= 0.5 * delta:
                 break
-        return t, rounds
+        return iv, rounds
 
     def fit_id(self, id_scores):
         """Patches `id_scores` in place; afterwards `threshold` / `delta` (/ `delta2`) are set."""
@@ -85,25 +97,29 @@ class ThresholdRefiner:
         done[idx] = True
         self.delta = self.margin * noise
         st.update(noise_max_abs=noise, delta=self.delta, calibration_images=n_cal)
-        t = _kth_threshold(id_scores, self.recall)
+        iv = _threshold_interval(id_scores, self.recall)
         if self.delta > 0.0:  # (0: the arm IS the better arm)
-            t, st["rounds"] = self._window_rounds(id_scores, done, self.rescore, self.delta, t)
+            iv, st["rounds"] = self._window_rounds(id_scores, done, self.rescore, self.delta, iv)
         st["rescored"]["id"] = int(done.sum())
         if self.rescore_exact is not None:
             n2 = min(int(self.calib_exact), n_cal)
             idx = torch.arange(n2, device=dev)
             exact = self.rescore_exact("id", idx).to(device=dev, dtype=torch.float32)
-            # two exact-grade arms differ by a few fp32 ulps of the score; never less than one ulp at the threshold
-            ulp = float(torch.nextafter(torch.tensor(abs(t), dtype=torch.float32), torch.tensor(float("inf"))) - abs(t))
-            noise2 = max(float((exact - id_scores[idx]).abs().max()), ulp)
+            # two exact-grade arms differ by a few fp32 ulps of the score; never taken below two ulps at the threshold
+            a = max(abs(iv[0]), abs(iv[1]))
+            ulp = float(torch.nextafter(torch.tensor(a, dtype=torch.float32), torch.tensor(float("inf"))) - a)
+            noise2 = max(float((exact - id_scores[idx]).abs().max()), 2.0 * ulp)
             id_scores[idx] = exact
             done2 = torch.zeros(id_scores.numel(), dtype=torch.bool, device=dev)
             done2[idx] = True
             self.delta2 = self.margin * noise2
             st.update(noise2_max_abs=noise2, delta2=self.delta2, calibration_images_exact=n2)
-            t, st["rounds_exact"] = self._window_rounds(id_scores, done2, self.rescore_exact, self.delta2, _kth_threshold(id_scores, self.recall))
+            iv, st["rounds_exact"] = self._window_rounds(id_scores, done2, self.rescore_exact, self.delta2,
+                                                         _threshold_interval(id_scores, self.recall))
             st["rescored_exact"]["id"] = int(done2.sum())
-        self.threshold = st["threshold"] = t
+        self.interval = iv
+        self.threshold = st["threshold"] = iv[1]   # (s_(k+1): the operating threshold when recall n is an integer)
+        st["threshold_interval"] = list(iv)
         return id_scores
 
     def apply(self, name: str, scores):
@@ -111,14 +127,14 @@ class ThresholdRefiner:
         assert self.threshold is not None, "fit_id first"
         n = 0
         if self.delta > 0.0:
-            idx = ((scores - self.threshold).abs() <= self.delta).nonzero().reshape(-1)
+            idx = self._near(scores, self.interval, self.delta).nonzero().reshape(-1)
             n = int(idx.numel())
             if n:
                 scores[idx] = self.rescore(name, idx).to(device=scores.device, dtype=scores.dtype)
         self.stats["rescored"][name] = n
         self.stats["rescored_total"] = sum(self.stats["rescored"].values())
         if self.rescore_exact is not None:
-            idx = ((scores - self.threshold).abs() <= self.delta2).nonzero().reshape(-1)
+            idx = self._near(scores, self.interval, self.delta2).nonzero().reshape(-1)
             if idx.numel():
                 scores[idx] = self.rescore_exact(name, idx).to(device=scores.device, dtype=scores.dtype)
             self.stats["rescored_exact"][name] = int(idx.numel())

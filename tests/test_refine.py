@@ -118,3 +118,29 @@ def test_rescorer_shards_the_window_by_the_loaders_index_ranges(monkeypatch):
         assert all((lo <= int(i) < hi) == (float(v) != 0.0) for i, v in zip(idx, parts[-1]))
     assert torch.equal(sum(parts), truth[idx])
     assert sum(counts) == idx.numel() and max(counts) <= 3   # nobody scores the whole window
+
+
+def test_window_covers_the_order_statistic_the_reference_metric_actually_uses():
+    """With few ID images the neighbouring ID order statistics lie many noise widths apart, and the reference's FPR@recall
+    (utils/detection_util.py:66-105: argmin |recall - 0.95| over the reversed threshold arrays) counts the OOD scores below
+    s_(k+1), not s_(k) (k = round(0.95 n)).  A window centred on s_(k) alone misses the OOD images whose noise carries them
+    across s_(k+1): dense OOD scores, sparse ID scores, both levels."""
+    from mcm_amd.metrics import get_measures
+    from mcm_amd.refine import refine_threshold_scores
+
+    bad_before = 0
+    for seed in range(30):
+        g = torch.Generator().manual_seed(1000 + seed)
+        n_id, n_ood = 400, 40000
+        exact = {"id": torch.randn(n_id, generator=g).float(), "o": (torch.randn(n_ood, generator=g) + 1.0).float()}
+        mid = {k: (v + torch.randn(v.shape, generator=g) * 2e-6).float() for k, v in exact.items()}
+        noisy = {k: (v + torch.randn(v.shape, generator=g) * 1e-4).float() for k, v in exact.items()}
+        want = get_measures(-exact["id"].numpy(), -exact["o"].numpy())[2]
+        bad_before += get_measures(-noisy["id"].numpy(), -noisy["o"].numpy())[2] != want
+        for two in (False, True):
+            sid, sood, st = refine_threshold_scores(noisy["id"].clone(), {"o": noisy["o"].clone()},
+                                                    (lambda name, idx: mid[name][idx]) if two else (lambda name, idx: exact[name][idx]),
+                                                    rescore_exact=(lambda name, idx: exact[name][idx]) if two else None, calib=64)
+            assert get_measures(-sid.numpy(), -sood["o"].numpy())[2] == want, (seed, two, st)
+            assert st["threshold_interval"][0] < st["threshold_interval"][1]
+    assert bad_before >= 5   # the noisy arm really is off on a good share of these draws

@@ -505,16 +505,23 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, two_level=True):
         second = Rescorer(exact, txt, data, 1.0, "MCM") if (use_x2 and two_level) else None
         refiner = ThresholdRefiner(first, rescore_exact=second)
         refiner.fit_id(scores["id"])
-        meas = {}
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0 - t_score
+        meas, t_meas = {}, 0.0
         for n, _, ood, _ in sets:
             if ood:
                 refiner.apply(n, scores[n])
+                torch.cuda.synchronize()
+                tm = time.perf_counter()
                 meas[n] = net.measures(scores["id"], scores[n], negate=True)
+                t_meas += time.perf_counter() - tm
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
         st = refiner.stats
         out = {"images_per_sec": n_img / t_all, "images": n_img, "seconds": t_all, "seconds_scoring": t_score,
                "seconds_refine": t_all - t_score, "images_per_sec_unrefined": n_img / t_score,
+               "seconds_refine_parts": {"id_calibration_and_window": t_fit, "device_metrics_4_sets": t_meas,
+                                        "ood_windows": t_all - t_score - t_fit - t_meas},
                "rescored": st.get("rescored_total"), "rescored_per_set": st["rescored"],
                "rescored_exact": st.get("rescored_exact_total"), "rescored_exact_per_set": st.get("rescored_exact"),
                "rescorer": ("split-activation arm of the same handle (mcm_score_x2)" if use_x2 else "exact-fp32 handle")
