@@ -91,8 +91,12 @@ def short_line(d):
     rf = d.get("refined")
     if rf:
         line["value_refined"] = _r(rf.get("images_per_sec"), 7)
-        line["refined"] = {k: _r(rf.get(k)) for k in ("images", "rescored", "rescored_exact", "seconds", "seconds_refine",
-                                                       "rescorer", "fpr95_images_vs_fp32_arm_max_set", "error") if k in rf}
+        line["refined"] = {k: _r(rf.get(k)) for k in ("images", "rescored", "seconds", "seconds_refine", "rescorer",
+                                                       "fpr95_images_vs_fp32_arm_max_set", "error") if k in rf}
+        if rf.get("exact"):  # --refine-threshold exact: the inner window also through an exact-fp32 handle
+            ex = rf["exact"]
+            line["refined"]["exact"] = {"img_s": _r(ex.get("images_per_sec")), "rescored_exact": ex.get("rescored_exact"),
+                                        "fpr95_images_vs_fp32_arm_max_set": ex.get("fpr95_images_vs_fp32_arm_max_set")}
     ro = d.get("roofline")
     if ro:
         line["roofline"] = {k: _r(ro.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",

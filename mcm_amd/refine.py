@@ -55,7 +55,7 @@ class ThresholdRefiner:
     set `name` ("id" for the ID set); rescore_exact: the optional second level (module docstring)."""
 
     def __init__(self, rescore: Callable, *, rescore_exact: Optional[Callable] = None, recall: float = 0.95, margin: float = 2.5,
-                 calib: int = 512, calib_exact: int = 64, max_rounds: int = 4):
+                 calib: int = 512, calib_exact: int = 16, max_rounds: int = 4):
         self.rescore, self.rescore_exact = rescore, rescore_exact
         self.recall, self.margin, self.calib, self.calib_exact, self.max_rounds = recall, margin, calib, calib_exact, max_rounds
         self.stats = {"recall": recall, "margin": margin, "rescored": {}, "rounds": 0}

@@ -41,8 +41,9 @@ def full_record():
         "collective": "nccl (RCCL) all_gather_into_tensor of the score shards (device tensors, no host bounce), inside the timed region",
         "gflop_per_image": 35.13, "weights": {"regime": "fp16-exact"},
         "refined": {"images_per_sec": 25123.123456, "images": 85640, "seconds": 3.4087654321, "seconds_scoring": 3.26,
-                    "seconds_refine": 0.14876543, "rescored": 879, "rescored_exact": 23,
-                    "rescorer": "split-activation fp16 arm of the same handle, exact-fp32 arm for the inner window",
+                    "seconds_refine": 0.14876543, "rescored": 879,
+                    "exact": {"images_per_sec": 24612.3456, "rescored_exact": 23, "fpr95_images_vs_fp32_arm_max_set": 0, "vs_fp32_arm": {}},
+                    "rescorer": "split-activation arm of the same handle (mcm_score_x2)",
                     "fpr95_images_vs_fp32_arm_max_set": 0, "vs_fp32_arm": {n: {"fpr95_images": 0} for n in "abcd"}},
         "ingest": {"host_u8": dict(leg, source="x" * 300), "host_raw": dict(leg, source="x" * 300),
                    "host_jpeg": {"error": "RuntimeError: " + "y" * 380}},
