@@ -14,7 +14,8 @@
 //   O^T = V^T·P^T; V stays row-major in LDS and the V^T fragments come from the gfx950
 //                 transpose read (ds_read_b64_tr_b16); the softmax denominator is one more
 //                 MFMA per key step (all-ones A operand).
-// fp32 path (parity arm and the text tower): plain fp32 VALU kernel, exact expf.
+// fp32 path: the vision tower of the parity arm on fp32 MFMAs (attn_f32_mfma_kernel, round 5), the causal text tower on the plain
+//   fp32 VALU kernel; both with exact expf.
 // The round-1 kernel (attn_bf16_kernel: V transposed while staged through registers) exists in the
 // harness build only (-DMCM_HARNESS), as the A/B arm of tests/test_gpu_kernels.py.
 // Measurements: DESIGN.md section 4.2.
@@ -620,6 +621,129 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
+// ---- fp32 parity arm on the matrix pipe (round 5) ---------------------------------------------------------------------
+// The bidirectional (vision-tower) form of the fp32 attention on v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
+// accumulation — the arithmetic of the VALU kernel above (q.k summed in another order; softmax with the same expf; tests hold
+// both to the oracle at 1e-4 / 1e-5), 14 x its speed: the VALU kernel was 75 of the exact-fp32 arm's 207 ms per 512 images.
+//   S^T = K Q^T:  A = K tile (lane (fr, g): key fr, dims 16 g + j over the 16 MFMAs j of a tile), B = Q^T (query fr, the same
+//                 dims) — the matrix pipe's four k-slots carry dims {j, 16 + j, 32 + j, 48 + j}, so a lane's 16 operand values
+//                 are 16 CONSECUTIVE floats of its row (four ds_read_b128 / four global 16-byte loads);
+//                 result: lane (fr, g) holds keys 4 g + r (r = 0..3) of the tile for query fr — the softmax row in registers.
+//   O^T = V^T P^T: MFMA r of a tile takes keys {4 g + r}: B = the lane's own P value r, A = V[key 4 g + r][dim block + fr].
+// K and V of the head sit in LDS as fp32 rows of 68 floats (272 B: the 16 rows of a b128 fragment read fall on distinct bank
+// groups).  One workgroup per (sequence, head), 8 waves, q-blocks dealt round-robin; the CLS-only last layer asks for qrows = 1.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                   int L, int heads, int qrows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LP = NT * 16, RS = 68;
+  float* Ks = (float*)smem;        // [LP][68]
+  float* Vs = Ks + LP * RS;        // [LP][68]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+  const int D = heads * 64;
+  const size_t rs = (size_t)3 * D;
+  const float* base = qkv + (size_t)seq * L * rs + h * 64;
+  const int fr = lane & 15, g = lane >> 4;
+  for (int i = threadIdx.x; i < LP * 16; i += NW * 64) {   // 16 float4 per row
+    const int row = i >> 4, c = (i & 15) * 4;
+    f32x4_t kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (row < L) {
+      kv = *(const f32x4_t*)(base + (size_t)row * rs + D + c);
+      vv = *(const f32x4_t*)(base + (size_t)row * rs + 2 * D + c);
+    }
+    *(f32x4_t*)(Ks + row * RS + c) = kv;
+    *(f32x4_t*)(Vs + row * RS + c) = vv;
+  }
+  __syncthreads();
+  const int nqb = (qrows + 15) / 16;
+  for (int qb = wave; qb < nqb; qb += NW) {
+    const int q = qb * 16 + fr;
+    float qv[16];
+    {
+      const float* qp = base + (size_t)min(q, L - 1) * rs + 16 * g;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4_t t = *(const f32x4_t*)(qp + 4 * j4);
+        qv[4 * j4] = t[0]; qv[4 * j4 + 1] = t[1]; qv[4 * j4 + 2] = t[2]; qv[4 * j4 + 3] = t[3];
+      }
+    }
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float* kp = Ks + (t * 16 + fr) * RS + 16 * g;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4_t kk = *(const f32x4_t*)(kp + 4 * j4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[e], qv[4 * j4 + e], acc, 0, 0, 0);
+      }
+      s[t] = acc;
+      __builtin_amdgcn_sched_barrier(0);  // (without it hipcc hoists every tile's fragment reads: 256 VGPRs + scratch)
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = t * 16 + g * 4 + r < L;
+        s[t][r] = ok ? s[t][r] * 0.125f : -INFINITY;
+        m = fmaxf(m, s[t][r]);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float z = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(s[t][r] - m);   // (-inf - m: 0)
+        s[t][r] = e;
+        z += e;
+      }
+    }
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vp = Vs + (t * 16 + 4 * g + r) * RS + fr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[dt * 16], s[t][r], o[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < L && q < qrows) {
+      const float rz = 1.0f / z;
+      float* orow = out + ((size_t)seq * L + q) * D + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(orow + dt * 16) = o[dt] * rz;
+    }
+  }
+}
+
+template <int NT, int NW>
+hipError_t launch_f32_mfma(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s) {
+  constexpr int lds = NT * 16 * 68 * 2 * (int)sizeof(float);
+  static_assert(lds <= 160 * 1024, "K and V of one head must fit the LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_f32_mfma_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_f32_mfma_kernel<NT, NW>), dim3(nseq * heads), dim3(NW * 64), lds, s, (const float*)qkv, (float*)out, L,
+                     heads, qrows);
+  return hipGetLastError();
+}
+
 #ifdef MCM_HARNESS
 template <int PREC, int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
@@ -772,6 +896,13 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
     return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
   if (prec == MCM_PREC_BF16)
     return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
+  if (!causal) {  // the vision tower's form: fp32 MFMAs (attn_f32_mfma_kernel); the causal text tower keeps the VALU kernel
+    const int nt = (L + 15) / 16;
+#define MCM_F32A(N, W) \
+  if (nt <= N) return launch_f32_mfma<N, W>(qkv, out, nseq, L, heads, qrows, s)
+    MCM_F32A(2, 4); MCM_F32A(4, 4); MCM_F32A(8, 4); MCM_F32A(13, 8); MCM_F32A(18, 8);
+#undef MCM_F32A
+  }
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
