@@ -224,12 +224,21 @@ def main(argv=None):
         # like the reference (:77-78) the statistics are always read back from the files get_mean_prec wrote —
         # or that an earlier run wrote, which is what `--generate ""` (argparse's only falsy bool) is for
         stats = {"classwise_mean": torch.empty((args.n_cls, args.feat_dim)), "precision": torch.empty((args.feat_dim, args.feat_dim))}
+        missing = None
         if rank == 0:
             for what in ("classwise_mean", "precision"):
                 f = os.path.join(args.template_dir, maha_file_name(args, what))
                 if not os.path.exists(f):
-                    raise SystemExit(f"--generate is off and {f} does not exist: run once with --generate True")
+                    missing = f
+                    break
                 stats[what] = torch.load(f, map_location="cpu").float().contiguous()
+        if ws > 1:  # every rank learns whether rank 0 found the files BEFORE anybody waits in the broadcast
+            ok = torch.tensor([0.0 if missing else 1.0])
+            mdist.broadcast_tensors([ok], src=0)
+            if float(ok[0]) == 0.0 and missing is None:
+                missing = "the statistics files (see rank 0's message)"
+        if missing:
+            raise SystemExit(f"--generate is off and {missing} does not exist: run once with --generate True")
         if ws > 1:
             mdist.broadcast_tensors([stats["classwise_mean"], stats["precision"]], src=0)
         classwise_mean, precision = stats["classwise_mean"], stats["precision"]

@@ -175,9 +175,12 @@ __global__ __launch_bounds__(256) void cvt_weight_split_kernel(const float* __re
       ((uint16_t*)dst)[o] = hi;
       ((uint16_t*)dst)[o + 64] = f2bf(v - bf2f(hi));
     } else {
-      const _Float16 hi = (_Float16)v;
+      // a weight beyond the fp16 range (|w| > 65504; count_inexact reports it) would round to inf and leave lo = -inf, a NaN
+      // in every product: both halves saturate instead (hi = +-65504, lo = what is left, saturated the same way)
+      const float vc = fminf(fmaxf(v, -65504.0f), 65504.0f);
+      const _Float16 hi = (_Float16)vc;
       ((_Float16*)dst)[o] = hi;
-      ((_Float16*)dst)[o + 64] = (_Float16)(v - (float)hi);
+      ((_Float16*)dst)[o + 64] = (_Float16)fminf(fmaxf(v - (float)hi, -65504.0f), 65504.0f);
     }
   }
 }

@@ -57,7 +57,8 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                   tile: float = 0.0, weights: str = "fp32", seed: int = 1,
                   external: Optional[Dict[str, Callable]] = None,
                   ood_sets: Optional[Sequence] = None, tile_ood: Optional[float] = None,
-                  state_dict: Optional[Dict] = None, operating_point: Optional[float] = None) -> Dict:
+                  state_dict: Optional[Dict] = None, operating_point: Optional[float] = None,
+                  feature_cache: Optional[Dict] = None) -> Dict:
     """weights="fp16-exact": every parameter of the seeded state dict is rounded to the nearest fp16 value
     first (for ALL arms, the fp32 reference included) — the situation of the reference's checkpoints, whose
     Linear / conv / projection weights were trained and released in fp16, so an fp16 operand copy of them is
@@ -69,7 +70,10 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
     tile_ood: texture strength of the OOD sets when it differs from the ID set's `tile`.
     state_dict: score with these parameters instead of the seeded ones (`weights` then only labels the result).
     operating_point: also report every arm on an ID / OOD split of ALL scored images that gives the reference arm this
-    AUROC (`out["operating_point"]`; see REALISTIC_PIXELS)."""
+    AUROC (`out["operating_point"]`; see REALISTIC_PIXELS).
+    feature_cache: a dict the caller keeps between calls that differ ONLY in `score` / `T`: the unit-norm image features of
+    every arm and set are computed by the first call and re-used by the others (mcm_score IS mcm_encode_image followed by
+    mcm_score_features on the same buffer: same bits), so five score kinds cost one pass through the towers."""
     import torch
 
     from .config import geometry
@@ -131,11 +135,24 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
             loader = DevicePatternLoader(n, geo.image_size, K, batch, dev, ood=ood, seed=sd_, amp=amp,
                                          tile=t_ood if ood else tile)
             parts = {p: [] for p in names + list(ext)}
-            for px, _ in loader:
+            if feature_cache is not None and not ext:
+                if tag not in feature_cache:
+                    feats = {p: [] for p in names}
+                    for px, _ in loader:
+                        for p in names:
+                            b = p[:-2] if p.endswith("x2") else p
+                            fn = nets[b].get_image_features_x2 if p.endswith("x2") else nets[b].get_image_features
+                            feats[p].append(fn(px, normalize=True))
+                    feature_cache[tag] = {p: torch.cat(v) for p, v in feats.items()}
                 for p in names:
-                    parts[p].append(scorers[p](px, banks[p], T, score))
-                for e, fn in ext.items():
-                    parts[e].append(fn(px).to(device=dev, dtype=torch.float32).reshape(-1))
+                    b = p[:-2] if p.endswith("x2") else p
+                    parts[p].append(nets[b].score_features(feature_cache[tag][p], banks[p], T, score))
+            else:
+                for px, _ in loader:
+                    for p in names:
+                        parts[p].append(scorers[p](px, banks[p], T, score))
+                    for e, fn in ext.items():
+                        parts[e].append(fn(px).to(device=dev, dtype=torch.float32).reshape(-1))
             for p in parts:
                 scores[p][tag] = torch.cat(parts[p])
         # derived arms: the base arm's scores with the images near the FPR95 threshold re-scored by the exact arm (here the

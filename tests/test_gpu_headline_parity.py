@@ -55,7 +55,7 @@ def test_headline_parity_vs_hf_reference(weights):
     # suite compares against the exact-fp32 arm only — that arm equals HF to 4e-7 there too, measured by every default
     # bench.py run (parity.fp32_valued_weights.vs_hf) — to keep `pytest -m gpu` within a few minutes
     with_hf = weights == "fp16-exact"
-    arms = ("fp16", "bf16", "fp16x2", "fp16+refine", "fp16+refine2") if with_hf else ("fp16", "fp16:single", "bf16", "fp16x2", "fp16+refine", "fp16+refine2")
+    arms = ("fp16", "bf16", "fp16x2", "fp16+refine", "fp16+refine2") if with_hf else ("fp16", "fp16:single", "fp16x2", "fp16+refine", "fp16+refine2")
     d = measure_drift("ViT-B/16", K=1000, n_id=50000, batch=512, arms=arms, ood_sets=CONFIG3_OOD_SETS,
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights,
                       external=_external() if with_hf else None)
@@ -99,12 +99,13 @@ def test_headline_parity_vs_hf_reference(weights):
         assert not d["weight_operands"]["fp16:single"]["split"]
         assert arm["rms_dscore"] < 0.85 * single["rms_dscore"], (arm["rms_dscore"], single["rms_dscore"])
         assert arm["d_auroc"] < 0.5 * single["d_auroc"], (arm["d_auroc"], single["d_auroc"])
-    # bf16 (the dtype BASELINE configs 2/3/5 name) does NOT meet 1e-4 in either regime — 8 significand bits in every
-    # activation; measured 1.2e-4 ... 3.7e-4 in AUROC with its weights exact (split); bounded here so a
-    # regression is visible, reported by bench.py and said by the CLI
-    b = d["arms"]["bf16"]["vs_external"]["hf"] if with_hf else d["arms"]["bf16"]
-    assert b["d_auroc"] <= 1e-3 and b["d_fpr95"] <= 1.5e-3, b
-    assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
+    # bf16 (the dtype BASELINE configs 2/3/5 name) does NOT meet 1e-4 — 8 significand bits in every activation; measured
+    # 1.2e-4 ... 4.9e-4 in AUROC with its weights exact (split); bounded here (fp16-exact regime; the
+    # fp32-valued regime's bf16 numbers are bench.py's --parity-regimes fp32) so a regression is visible, said by the CLI
+    if with_hf:
+        b = d["arms"]["bf16"]["vs_external"]["hf"]
+        assert b["d_auroc"] <= 1e-3 and b["d_fpr95"] <= 1.5e-3, b
+        assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
     assert all(v == 0 for v in d["fp16_saturation_events"].values()), d["fp16_saturation_events"]  # nothing left the fp16 range
 
 
@@ -140,7 +141,7 @@ def test_l14_parity_vs_hf_reference():
     4 000 + 10 000 (50 s)."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-L/14", K=1000, n_id=4000, n_ood=10000, batch=256, arms=("fp16",),
+    d = measure_drift("ViT-L/14", K=1000, n_id=3000, n_ood=10000, batch=256, arms=("fp16",),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp16-exact",
                       external=_external())
     print("L/14 parity (fp16-exact weights):", json.dumps(d))
@@ -229,6 +230,9 @@ def test_outlier_channel_stress_checkpoint():
         net.close()
 
 
+_SCORE_KIND_FEATURES = {}   # the towers' features of the 12 000 images, computed by the first score kind and shared (feature_cache)
+
+
 @pytest.mark.parametrize("score,T", [("max-logit", 1.0), ("energy", 1.0), ("entropy", 1.0), ("var", 1.0), ("MCM", 0.01)])
 def test_every_score_kind_holds_the_bar(score, T):
     """The reference's other `--score` reductions (utils/detection_util.py:233-248) and a sharp temperature: the fp16 arm's
@@ -238,7 +242,7 @@ def test_every_score_kind_holds_the_bar(score, T):
     from mcm_amd.parity import measure_drift
 
     d = measure_drift("ViT-B/16", K=1000, n_id=6000, n_ood=6000, batch=500, arms=("fp16", "fp16+refine2"),
-                      weights="fp16-exact", score=score, T=T)
+                      weights="fp16-exact", score=score, T=T, feature_cache=_SCORE_KIND_FEATURES)
     a, r = d["arms"]["fp16"], d["arms"]["fp16+refine2"]
     print(f"score {score} T {T}:", json.dumps({"reference": d["reference"], "fp16": a, "refined": r, "refine": d["refine"]}))
     assert 0.02 < d["reference"]["auroc"] < 0.98
