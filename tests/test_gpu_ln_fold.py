@@ -76,7 +76,9 @@ def test_folded_tower_vs_unfolded_and_fp32(prec, affine):
     assert float((1 - c_on).max()) < bound
     # the fold must not be a worse approximation of the fp32 tower than the LayerNorm launches are (25 % slack: both
     # are sums of the same kind of rounding noise)
-    assert float((1 - c_on).mean()) < 1.25 * float((1 - c_off).mean()) + 1e-9
+    # (fp16: both means are 2 - 4e-8, the round-off of a float32 cosine itself — half an ulp of 1.0 is 3e-8 — so the slack has
+    # an absolute part of that size; bf16: 1e-5, where the relative part is the test)
+    assert float((1 - c_on).mean()) < 1.25 * float((1 - c_off).mean()) + 3e-8
 
 
 def test_fold_batch_invariance_through_the_score_call():

@@ -36,6 +36,7 @@ PASSES = [
     ["TCC_HIT", "TCC_MISS", "TCC_REQ", "TCC_TAG_STALL"],
 ]
 SIMDS = 1024  # 256 CUs x 4
+XCDS = 8      # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (checked: QKV's mfma_util = 0.58, the known 55 - 60 %)
 
 
 def family(name):
@@ -101,6 +102,8 @@ def main():
         d = dict(c)
         gui = c.get("GRBM_GUI_ACTIVE")
         if gui:
+            gui = gui / XCDS
+            d["gpu_cycles"] = gui
             if "SQ_ACTIVE_INST_VALU" in c:
                 d["valu_util"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (gui * SIMDS)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in c:

@@ -11,7 +11,7 @@ tag=$1; shift
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out $root/profiles
-bench="python $root/bench.py --steps 6 --warmup 2 --no-drift --cpu-seconds 0 --sustain-seconds 0 --no-profile --ingest none --no-arms $*"
+bench="python $root/bench.py --quick --steps 6 --warmup 2 --no-profile $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- $bench > $out/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $out/sq -o s -- $bench > $out/sq.log 2>&1
