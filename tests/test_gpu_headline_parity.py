@@ -116,12 +116,13 @@ def test_realistic_operating_point(weights):
     to 2.5e-4 (module docstring: the threshold sits where the OOD scores are dense)."""
     from mcm_amd.parity import REALISTIC_PIXELS, measure_drift
 
-    d = measure_drift("ViT-B/16", K=1000, n_id=16000, n_ood=16000, batch=500, arms=("fp16", "bf16", "fp16+refine", "fp16+refine2"),
+    n = 16000 if weights == "fp16-exact" else 10000   # (the second regime on a smaller pool: the suite's time budget)
+    d = measure_drift("ViT-B/16", K=1000, n_id=n, n_ood=n, batch=500, arms=("fp16", "bf16", "fp16+refine", "fp16+refine2"),
                       amp=REALISTIC_PIXELS["amp"], tile=REALISTIC_PIXELS["tile"], tile_ood=REALISTIC_PIXELS["tile_ood"],
                       weights=weights, operating_point=0.9)
     op = d["operating_point"]
     print(f"realistic operating point ({weights} weights):", json.dumps(op))
-    assert abs(op["reference"]["auroc"] - 0.9) <= 2e-3 and min(op["n_id"], op["n_ood"]) >= 8000, op
+    assert abs(op["reference"]["auroc"] - 0.9) <= 2e-3 and min(op["n_id"], op["n_ood"]) >= 0.45 * n, op
     assert op["reference"]["score_std"] > 4e-6                     # 0.4 % of |score| (stress set: 0.13 %)
     a = op["arms"]["fp16"]
     assert a["d_auroc"] <= BAR and a["d_aupr"] <= BAR and a["d_fpr95"] <= FPR_OP, a
@@ -132,21 +133,21 @@ def test_realistic_operating_point(weights):
     r, r2 = op["arms"]["fp16+refine"], op["arms"]["fp16+refine2"]
     assert r["d_fpr95_images"] <= 1 and r["d_auroc"] <= BAR and r["d_aupr"] <= BAR, r
     assert r2["d_fpr95_images"] == 0 and r2["d_auroc"] <= BAR and r2["d_aupr"] <= BAR, r2
-    assert op["refine"]["fp16+refine"]["rescored_total"] <= 0.05 * 32000, op["refine"]
+    assert op["refine"]["fp16+refine"]["rescored_total"] <= 0.05 * 2 * n, op["refine"]
 
 
 def test_l14_parity_vs_hf_reference():
     """BASELINE config 4 (ViT-L/14 fp16, batch 256) with 10 000 OOD images, so that FPR95's quantum is 1e-4.  The full
     50 000 + 10 000 run is profiles/r03_parity_L14_50k_vs_hf.json (fp16 vs HF: dAUROC 1.2e-5, dFPR95 0; 4 minutes); here
-    4 000 + 10 000 (50 s)."""
+    2 000 + 7 000 (35 s; FPR95's quantum 1.4e-4: asserted as a count of images)."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-L/14", K=1000, n_id=3000, n_ood=10000, batch=256, arms=("fp16",),
+    d = measure_drift("ViT-L/14", K=1000, n_id=2000, n_ood=7000, batch=256, arms=("fp16",),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp16-exact",
                       external=_external())
     print("L/14 parity (fp16-exact weights):", json.dumps(d))
     r = d["reference"]["vs_external"]["hf"]
-    assert r["d_auroc"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12, r
+    assert r["d_auroc"] <= 1e-5 and r["max_set"]["d_fpr95_images"] <= 1, r
     for vs in (d["arms"]["fp16"], d["arms"]["fp16"]["vs_external"]["hf"]):
         assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
 
