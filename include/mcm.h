@@ -189,8 +189,9 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
  * Scores agree with the exact-fp32 arm (MCM_PREC_F32) to fp32 round-off at about half the fp16 arm's throughput, where
  * the fp32 arm runs at a tenth of it: what mcm_amd/refine.py re-scores the images near the FPR95 threshold with
  * (reference utils/detection_util.py:66-106: FPR95 is a count at one threshold).  No second handle, no extra weights:
- * the activation buffers hold rows of twice the width, so B <= mcm_x2_max_batch(h) (about cfg.max_batch / 2; 0 = this
- * handle is not fp16).  pixel_format: MCM_PIXELS_*.  Asynchronous on `stream`, no allocation, like mcm_score. */
+ * an fp16 handle's activation buffers are allocated at twice the bytes so that the split rows (twice the width) fit at
+ * the full batch: B <= mcm_x2_max_batch(h) = cfg.max_batch (0 = this handle is not fp16).  pixel_format: MCM_PIXELS_*.
+ * Asynchronous on `stream`, no allocation, like mcm_score. */
 int mcm_x2_max_batch(const mcm_handle* h);
 int mcm_encode_image_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, int32_t normalize,
                         float* out_dev, void* stream);

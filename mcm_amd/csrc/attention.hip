@@ -266,7 +266,11 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
 // their lo half into fp16's subnormals; the scale cancels in O / rowsum).  ~22 significand bits on both operands of both
 // GEMMs, the same softmax arithmetic as the 16-bit kernel.  K and V hi AND lo stay in LDS (4 images, 104 KiB at 197 tokens):
 // one workgroup per CU — the arm re-scores a few hundred images per data set.
-template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0, bool X2 = false>
+// NFULL (round 5): the number of leading key tiles the launcher GUARANTEES to hold valid keys only (bidirectional form: every
+// tile but the last when the sequence needs exactly NT tiles).  The key-validity mask of those tiles folds away at compile time —
+// with a run-time L hipcc predicates it instead of branching, 3 VALU instructions per score (v_cmp, v_cndmask, an index v_or) on a
+// kernel whose compute phase is bound by VALU issue: 158 of the 565 issue slots of a 16-query block at B/16.  Same bits.
+template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0, bool X2 = false, int NFULL = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
                                                                          uint16_t* __restrict__ out, int L,
                                                                          int heads, int qrows, int rev, int hm) {
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     constexpr int NS = (NT + 1) / 2;
     // mask of key tile t for this lane's query (only tiles that can hold an invalid key are touched)
     auto mask_tile = [&](f32x4_t& st, int t) {
+      if (!CAUSAL && t < NFULL) return;   // (t is a constant after unrolling)
       const bool full = (t * 16 + 15 < L) && (!CAUSAL || t * 16 + 15 <= qb * 16);
       if (!full) {
 #pragma unroll
@@ -774,13 +779,13 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
 int g_attn_variant = 1;  // 1 = attn_tr_kernel (shipped), 0 = attn_bf16_kernel (round 1), 2/3/4 = s_setprio A/B arms
 #endif
 
-template <int PREC, int NT, int NW, int OCC, int PRIO = 0, bool X2 = false>
+template <int PREC, int NT, int NW, int OCC, int PRIO = 0, bool X2 = false, int NFULL = 0>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                      hipStream_t s, int rev, int hm) {
   constexpr int lds = NT * 16 * 128 * (X2 ? 4 : 2);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, X2>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, X2, NFULL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (!X2) {
       if (e == hipSuccess)
@@ -792,7 +797,7 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
   }
   if constexpr (X2) {  // (the vision tower only: no causal form)
     if (causal) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, true>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, true, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
     return hipGetLastError();
   } else {
@@ -800,7 +805,7 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
     hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   else
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, false, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   return hipGetLastError();
   }
@@ -812,6 +817,7 @@ hipError_t launch_tr_x2(const void* qkv, void* out, int nseq, int L, int heads, 
   const int nt = (L + 15) / 16;
 #define MCM_TRX(N, W) \
   if (nt <= N) return launch_tr<MCM_PREC_F16, N, W, 1, 0, true>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0)
+  if (nt == 13) return launch_tr<MCM_PREC_F16, 13, 8, 1, 0, true, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0);
   MCM_TRX(2, 4); MCM_TRX(4, 4); MCM_TRX(8, 4); MCM_TRX(13, 8); MCM_TRX(17, 8); MCM_TRX(18, 8);
 #undef MCM_TRX
   return hipErrorInvalidValue;
@@ -845,6 +851,11 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
   if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
 #endif
+  // the three checkpoint geometries need exactly 4 / 13 / 17 key tiles (50 / 197 / 257 tokens): every tile but the last is full
+#define MCM_TR_EXACT(N, W, O) \
+  if (nt == N && !causal) return launch_tr<PREC, N, W, O, 0, false, N - 1>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm)
+  MCM_TR_EXACT(4, 4, 3); MCM_TR_EXACT(13, 8, 3); MCM_TR_EXACT(17, 8, 3);
+#undef MCM_TR_EXACT
 #define MCM_TR(N, W, O) \
   if (nt <= N) return launch_tr<PREC, N, W, O>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm)
   MCM_TR(1, 4, 3); MCM_TR(2, 4, 3); MCM_TR(3, 4, 3); MCM_TR(4, 4, 3); MCM_TR(5, 4, 3); MCM_TR(6, 4, 3);

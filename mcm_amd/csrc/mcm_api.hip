@@ -83,8 +83,7 @@ struct mcm_handle {
   hipEvent_t prep_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
   unsigned prep_next = 0;
   int64_t max_rows = 0;
-  int row_scale = 1;   // 2 while a split-activation call runs: its rows are twice as wide, so half as many fit (padded_rows)
-  int x2_batch = 0;    // largest batch of the split-activation arm on this workspace (0: not an fp16 handle)
+  int x2_batch = 0;    // largest batch of the split-activation arm (= max_batch on fp16 handles, whose activation buffers are sized for it; 0: not fp16)
   size_t hbuf_bytes = 0;
   std::vector<void*> owned;       // every hipMalloc'd pointer
   // profiling
@@ -246,7 +245,7 @@ hipError_t gemm(mcm_handle* h, hipStream_t s, int prec, int epi, const GemmArgs&
   const bool from_row0 = a.x == h->ln || a.x == h->att || a.x == h->hbuf;  // not a chunk that starts mid-buffer
   if (epi != EPI_PATCH && from_row0 && a.M % 256 != 0 && a.N % 256 == 0 && a.ldx == a.K && a.ldo == a.N) {
     const int64_t mp = ((int64_t)a.M + 255) / 256 * 256;
-    if (mp <= h->max_rows / h->row_scale) a.M = (int)mp;
+    if (mp <= h->max_rows) a.M = (int)mp;
   }
   if (a.ksplit) a.K *= 2;  // the callers describe the logical problem; the split image has 2 K columns per row
   if (a.xsplit) a.ldx *= 2;           // ... and so have the rows of a split X
@@ -304,7 +303,7 @@ constexpr int g_ln_fold = 0;
 // rows of a dense activation GEMM as gemm() runs it (whole 256-row tiles when the workspace has them)
 int64_t padded_rows(const mcm_handle* h, int M) {
   const int64_t mp = ((int64_t)M + 255) / 256 * 256;
-  return mp <= h->max_rows / h->row_scale ? mp : M;
+  return mp <= h->max_rows ? mp : M;
 }
 hipError_t fold_stats(mcm_handle* h, hipStream_t s, int Mp, int D) {
   Scope sc(h, s, MCM_KC_LAYERNORM, 4.0 * Mp * (D / 64));
@@ -609,8 +608,11 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   const int64_t mv = ((int64_t)c.max_batch * h->ntok + 255) / 256 * 256, mt = ((int64_t)c.max_prompt_tokens + 255) / 256 * 256;
   h->max_rows = mv > mt ? mv : mt;
   // shared by both towers: vision rows in the operand dtype of cfg.precision, text rows in fp32
+  // fp16 handles: the split-activation arm (mcm_score_x2) carries every such row as hi + lo — twice the width — and runs at the
+  // same batch as the fp16 arm, so these buffers are allocated at twice the bytes (B/16, batch 512: +1.5 GB of the part's 288)
+  const int esw = es * (c.precision == MCM_PREC_F16 ? 2 : 1);
   auto both = [&](int64_t vcols, int64_t tcols) {
-    const size_t a = (size_t)mv * vcols * es, b = (size_t)mt * tcols * sizeof(float);
+    const size_t a = (size_t)mv * vcols * esw, b = (size_t)mt * tcols * sizeof(float);
     return a > b ? a : b;
   };
   const int64_t dmax = c.v_width > c.t_width ? c.v_width : c.t_width;
@@ -620,12 +622,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->ln, lnb);
   if (!rc) rc = dev_alloc(h, &h->qkv, qkvb);
   if (!rc) rc = dev_alloc(h, &h->att, attb);
-  // split-activation arm (fp16 handles): the same buffers hold rows of twice the width, so half the rows — and half the
-  // patch matrix
-  if (c.precision == MCM_PREC_F16) {
-    const int64_t by_rows = (mv / 2 / 256 * 256) / h->ntok;
-    h->x2_batch = (int)(by_rows < c.max_batch / 2 ? by_rows : c.max_batch / 2);
-  }
+  if (c.precision == MCM_PREC_F16) h->x2_batch = c.max_batch;
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
   // zeroed once (a ragged vision batch zeroes its pad rows again: encode_image_impl, "Pad rows")
@@ -633,7 +630,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
               hipMemset(h->qkv, 0, qkvb) != hipSuccess || hipMemset(h->att, 0, attb) != hipSuccess ||
               hipMemset(h->hbuf, 0, h->hbuf_bytes) != hipSuccess))
     rc = fail(h, MCM_EHIP, "hipMemset of the activation workspace");
-  if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * es);
+  if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * esw);
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
   if (!rc) rc = dev_alloc(h, (void**)&h->rowidx_dev, (size_t)mt * sizeof(int32_t));
@@ -805,25 +802,19 @@ namespace {
 const float kClipMean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
 const float kClipStd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
-struct RowScale {  // the activation rows of a split-activation call are twice as wide (padded_rows, gemm)
-  mcm_handle* h;
-  RowScale(mcm_handle* h_, int k) : h(h_) { h->row_scale = k; }
-  ~RowScale() { h->row_scale = 1; }
-};
-
 // x2: the split-activation arm (include/mcm.h mcm_score_x2) — same weights, same workspace, B <= h->x2_batch
 int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B, float* out_dev,
                       void* stream, bool normalize = true, bool x2 = false) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
-  if (x2 && h->x2_batch <= 0) return fail(h, MCM_EINVAL, "the split-activation arm needs an fp16 handle (max_batch >= 2)");
+  if (x2 && h->x2_batch <= 0) return fail(h, MCM_EINVAL, "the split-activation arm needs an fp16 handle");
   if (B <= 0 || B > (x2 ? h->x2_batch : h->cfg.max_batch))
     return fail(h, MCM_ERANGE, x2 ? "batch exceeds mcm_x2_max_batch" : "batch exceeds cfg.max_batch");
   hipStream_t s = (hipStream_t)stream;
   const mcm_config& c = h->cfg;
   const int D = c.v_width;
-  RowScale scale(h, x2 ? 2 : 1);
+
   // fp32 NCHW pixels: the patch GEMM gathers its A operand from the image itself (gemm_p256_kernel, GemmArgs::px) when the
   // geometry allows (B/16, B/32 at batches the persistent kernel takes); otherwise — uint8 ingest, L/14's padded K, small
   // batches — patchify writes the patch matrix first

@@ -365,7 +365,7 @@ class NativeCLIP:
 
         nb = self.x2_max_batch
         if nb <= 0:
-            raise RuntimeError("the split-activation arm needs an fp16 handle with max_batch >= 2")
+            raise RuntimeError("the split-activation arm needs an fp16 handle")
         px = self._pixels(pixel_values)
         fmt = 1 if px.dtype == torch.uint8 else 0  # MCM_PIXELS_U8_NHWC / MCM_PIXELS_F32_NCHW
         t = self._bank(text_features)
@@ -383,7 +383,7 @@ class NativeCLIP:
 
         nb = self.x2_max_batch
         if nb <= 0:
-            raise RuntimeError("the split-activation arm needs an fp16 handle with max_batch >= 2")
+            raise RuntimeError("the split-activation arm needs an fp16 handle")
         px = self._pixels(pixel_values)
         fmt = 1 if px.dtype == torch.uint8 else 0
         out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
