@@ -59,8 +59,10 @@ def process_args(argv=None):
     p.add_argument("--max_count", default=250, type=int)
     # additive
     p.add_argument("--weights", default=None, help="CLIP checkpoint (.safetensors / state_dict); default: seeded synthetic")
-    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
-                   help="MFMA operand format of the vision tower (fp16 holds AUROC/FPR95 to the fp32 arm at 1e-4; the text tower is always fp32)")
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp16x2", "fp32"],
+                   help="MFMA operand format of the vision tower (fp16 holds AUROC / AUPR to the fp32 arm at 1e-4 and, with threshold "
+                        "refinement, FPR95 too; fp16x2 = every activation as a hi + lo fp16 pair: every score within one fp32 ulp of "
+                        "the fp32 arm's at half the fp16 arm's speed, 3.7 x the fp32 arm's; the text tower is always fp32)")
     p.add_argument("--synthetic-weights", default="fp16-exact", choices=["fp16-exact", "fp32"],
                    help="without --weights: seeded parameters rounded to fp16 values, as the reference's checkpoints are "
                         "(default), or as drawn (fp32-valued: the 16-bit arms then run the split-weight GEMMs)")
@@ -248,7 +250,8 @@ def main(argv=None):
         _note_pillow_files(net, sources, "id", log)
     net.warn_if_saturated(f"the ID set {args.in_dataset}")
     refiner, net32 = None, None
-    refinable = args.score != "maha" and args.dtype != "fp32"  # (with --host-metrics the scores are host arrays: refined in place too)
+    refinable = args.score != "maha" and args.dtype in ("fp16", "bf16")  # (fp16x2 / fp32 runs ARE exact-grade arms; with
+                                                                       # --host-metrics the scores are host arrays: refined in place too)
     if args.refine_threshold != "off" and refinable:
         from mcm_amd.detection import prompt_bank
         from mcm_amd.refine import Rescorer, ThresholdRefiner

@@ -175,8 +175,11 @@ class NativeCLIP:
             raise RuntimeError("NativeCLIP needs a HIP device (no CPU fallback)")
         self.geo = geometry(geo) if isinstance(geo, str) else geo
         self.device = torch.device("cuda", device)
+        # "fp16x2": an fp16 handle whose `score_images` / `get_image_features` run the split-activation arm (mcm_score_x2) —
+        # every score at fp32-grade accuracy (within one fp32 ulp of the fp32 arm) at about half the fp16 arm's throughput
+        self.x2_default = precision == "fp16x2"
         self.precision = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp16": PREC_F16,
-                          "f16": PREC_F16}[precision]
+                          "f16": PREC_F16, "fp16x2": PREC_F16}[precision]
         self.max_batch = int(max_batch)
         # True: seeded stand-in parameters (the hash tokenizer stand-in is then acceptable); False: a real
         # checkpoint (it is refused); None: the caller did not say (mcm_amd.detection falls back to args.weights)
@@ -254,6 +257,8 @@ class NativeCLIP:
         `normalize=True` fuses the reference's `/= norm` (:226) into the pooling kernel."""
         import torch
 
+        if self.x2_default:
+            return self.get_image_features_x2(pixel_values, normalize=normalize)
         px = self._pixels(pixel_values)
         fmt = 1 if px.dtype == torch.uint8 else 0
         out = torch.empty((px.shape[0], self.geo.proj_dim), device=self.device, dtype=torch.float32)
@@ -340,6 +345,8 @@ class NativeCLIP:
         iteration of the reference loop, utils/detection_util.py:223-248)."""
         import torch
 
+        if self.x2_default:
+            return self.score_images_x2(pixel_values, text_features, T, score, out=out)
         px = self._pixels(pixel_values)
         fn = self._lib.mcm_score_u8 if px.dtype == torch.uint8 else self._lib.mcm_score
         t = self._bank(text_features)
