@@ -179,16 +179,16 @@ def _auroc_case(name, K, n, precisions, fp16_exact_weights=False):
 @pytest.mark.parametrize("fp16_exact", [True, False], ids=["fp16-exact-weights", "fp32-valued-weights"])
 def test_auroc_parity_vs_oracle_large_sample(fp16_exact):
     """North-star bar |ΔAUROC|, |ΔAUPR|, |ΔFPR95| ≤ 1e-4 vs the fp32 ORACLE (CPU), on a sample large enough that
-    1e-4 is above the metric quantum of every metric (tiny geometry, 2 x 12 000 images: FPR95 moves in steps
-    of 8.3e-5).  Both weight regimes are asserted:
+    1e-4 is above the metric quantum of every metric (tiny geometry, 2 x 20 000 images: FPR95 moves in steps
+    of 5e-5).  Both weight regimes are asserted:
       * fp16-exact — seeded weights rounded to fp16 for the oracle and every arm alike, the case of the reference's
         checkpoints (released in fp16): fp32 mode and fp16 mode (the benchmarked dtype) are held to the bar;
       * fp32-valued seeded weights — the fp16 arm additionally rounds its operand copies of the weights: AUROC and
         AUPR are held to the bar, FPR95 to the MEASURED bound of 3e-4 (round 2 measured 2e-4 = 4 of 20 000
         samples on this geometry; it does not meet 1e-4 here and the test says so instead of hiding the regime).
     bf16 is the documented coarser arm and is bounded so a regression shows."""
-    rep = _auroc_case("tiny", K=20, n=12000, precisions=("fp32", "fp16", "bf16"), fp16_exact_weights=fp16_exact)
-    print("tiny n=12000, fp16-exact weights =", fp16_exact, ":", rep)
+    rep = _auroc_case("tiny", K=20, n=20000, precisions=("fp32", "fp16", "bf16"), fp16_exact_weights=fp16_exact)
+    print("tiny n=20000, fp16-exact weights =", fp16_exact, ":", rep)
     assert 0.05 < rep["fp32"]["oracle"][0] < 0.95  # non-degenerate AUROC
     assert rep["fp32"]["d_auroc_aupr_fpr"].max() <= 1e-4, rep
     d16 = rep["fp16"]["d_auroc_aupr_fpr"]
