@@ -126,6 +126,11 @@ bool parse_dht(Parsed& p, const uint8_t* s, int sl) {
     for (int l = 1; l <= 16; ++l) cnt += (h.bits[l] = s[o + l]);
     if (cnt > 256 || o + 17 + cnt > sl) return false;
     memcpy(h.vals, s + o + 17, (size_t)cnt);
+    // libjpeg's jpeg_make_d_derived_tbl refuses a DC table with a symbol above 15 (JERR_BAD_HUFF_TABLE): such a file goes to
+    // the Pillow fallback, which raises what the reference's loader raises (it used to be scored silently)
+    if (!tc)
+      for (int i = 0; i < cnt; ++i)
+        if (h.vals[i] > 15) return false;
     if (!h.build()) return false;
     if (tc) h.build_fast_ac();
     h.set = true;

@@ -167,3 +167,33 @@ def test_damaged_files_never_crash_the_entropy_decoder(tmp_path):
     # damaged blocks: libjpeg-turbo's SIMD code works in 16 bits there, the restatement exactly — rare, and not a file any
     # two libjpeg builds agree on either)
     assert agree > 10 and differ <= 3, (agree, differ)
+
+
+def test_dc_huffman_symbol_above_15_goes_to_the_fallback(tmp_path):
+    """libjpeg (jpeg_make_d_derived_tbl) refuses a DC Huffman table with a symbol above 15 and Pillow raises
+    'broken data stream'; the native entropy decoder used to take such a file when the bad symbol was never decoded.  It is
+    now handed to the fallback (status 2), which raises what the reference's loader raises."""
+    p = str(tmp_path / "ok.jpg")
+    Image.fromarray(_photo(64, 80, 5)).save(p, quality=85)
+    data = bytearray(open(p, "rb").read())
+    i = 2
+    patched = False
+    while i + 4 <= len(data) and data[i] == 0xFF:
+        mk, ln = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if mk == 0xC4:  # DHT: walk its tables, overwrite the LAST symbol of the first DC table
+            o = i + 4
+            end = i + 2 + ln
+            while o < end:
+                tc, cnt = data[o] >> 4, sum(data[o + 1:o + 17])
+                if tc == 0 and not patched:
+                    data[o + 17 + cnt - 1] = 0x1F
+                    patched = True
+                o += 17 + cnt
+        if mk == 0xDA:
+            break
+        i += 2 + ln
+    assert patched
+    bad = str(tmp_path / "bad_dc.jpg")
+    open(bad, "wb").write(bytes(data))
+    meta, _, _ = entropy_decode([p, bad])
+    assert meta[0].status == 0 and meta[1].status == 2
