@@ -76,6 +76,7 @@ struct mcm_handle {
   // call), and the sample-plane workspace (grown on demand; one per handle: the kernels of consecutive calls are stream-ordered)
   char* jpg_pin = nullptr;
   char* jpg_dev = nullptr;
+  bool jpg_ready = false;
   hipEvent_t jpg_ev[PREP_RING] = {nullptr, nullptr, nullptr, nullptr};
   unsigned jpg_next = 0;
   uint8_t* jpg_planes = nullptr;
@@ -1011,12 +1012,18 @@ int mcm_jpeg_reconstruct(mcm_handle* h, const void* coef_dev, const mcm_jpeg_ima
   const size_t qoff = ((size_t)h->cfg.max_batch * sizeof(JpegImageDev) + 15) / 16 * 16;
   const size_t slot_bytes = (qoff + (size_t)h->cfg.max_batch * 3 * 64 * sizeof(uint16_t) + 255) / 256 * 256;
   if ((uintptr_t)coef_dev & 15) return fail(h, MCM_EINVAL, "coef_dev must be 16-byte aligned");
-  if (!h->jpg_pin) {  // first call on this handle
-    if (hipHostMalloc((void**)&h->jpg_pin, mcm_handle::PREP_RING * slot_bytes) != hipSuccess) return fail(h, MCM_ENOMEM, "hipHostMalloc jpeg");
-    rc = dev_alloc(h, (void**)&h->jpg_dev, mcm_handle::PREP_RING * slot_bytes);
-    if (rc) return rc;
+  if (!h->jpg_ready) {  // first call on this handle; `jpg_ready` only once EVERY piece exists (a failed half is retried)
+    if (!h->jpg_pin && hipHostMalloc((void**)&h->jpg_pin, mcm_handle::PREP_RING * slot_bytes) != hipSuccess) {
+      h->jpg_pin = nullptr;
+      return fail(h, MCM_ENOMEM, "hipHostMalloc jpeg");
+    }
+    if (!h->jpg_dev && (rc = dev_alloc(h, (void**)&h->jpg_dev, mcm_handle::PREP_RING * slot_bytes))) return rc;
     for (int k = 0; k < mcm_handle::PREP_RING; ++k)
-      if (hipEventCreateWithFlags(&h->jpg_ev[k], hipEventDisableTiming) != hipSuccess) return fail(h, MCM_EHIP, "hipEventCreate jpeg");
+      if (!h->jpg_ev[k] && hipEventCreateWithFlags(&h->jpg_ev[k], hipEventDisableTiming) != hipSuccess) {
+        h->jpg_ev[k] = nullptr;
+        return fail(h, MCM_EHIP, "hipEventCreate jpeg");
+      }
+    h->jpg_ready = true;
   }
   const unsigned slot = h->jpg_next++ % mcm_handle::PREP_RING;
   char* pin = h->jpg_pin + slot * slot_bytes;
