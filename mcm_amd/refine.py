@@ -10,7 +10,7 @@ same side of the threshold in both arms as long as its own noise is below `delta
 
     delta = margin x (largest |better arm - 16-bit| score difference over a calibration sample of the ID set)
 
-  1. calibration: the first `calib` ID images are re-scored -> noise estimate, delta;
+  1. calibration: `calib` ID images (runs of 64 spread evenly over the set) are re-scored -> noise estimate, delta;
   2. ID window: the ID images within delta of the provisional threshold are re-scored and the threshold recomputed
      (repeated if it moved by more than delta / 2);
   3. OOD windows: in every OOD set the images within delta of the final threshold are re-scored.
@@ -47,6 +47,22 @@ def _threshold_interval(id_scores, recall: float):
     k = min(n, max(1, int(round(recall * n))))
     srt = torch.sort(id_scores.double()).values
     return float(srt[max(0, k - 2)]), float(srt[min(n - 1, k)])   # 0-based: s_(k-1) = srt[k-2], s_(k+1) = srt[k]
+
+
+def _calibration_indices(n: int, n_cal: int, device):
+    """`n_cal` calibration images as runs of 64 consecutive indices spread evenly over the set: under `world_size > 1` the
+    contiguous index shards then each hold about n_cal / W of them (the first n_cal images would all sit in rank 0's shard —
+    the one stage of the refinement whose cost did not divide by W), and a loader that generates or decodes in blocks
+    (`DevicePatternLoader.gather`: aligned 64-image blocks) still touches n_cal / 64 blocks only."""
+    import torch
+
+    if n_cal >= n:
+        return torch.arange(n, device=device)
+    run = 64
+    nb = -(-n_cal // run)
+    starts = [(k * (n // nb)) // run * run for k in range(nb)]
+    idx = torch.cat([torch.arange(s, min(s + run, n)) for s in starts])[:n_cal]
+    return idx.to(device)
 
 
 class ThresholdRefiner:
@@ -89,7 +105,7 @@ class ThresholdRefiner:
 
         dev, st = id_scores.device, self.stats
         n_cal = min(int(self.calib), id_scores.numel())
-        idx = torch.arange(n_cal, device=dev)
+        idx = _calibration_indices(id_scores.numel(), n_cal, dev)
         better = self.rescore("id", idx).to(device=dev, dtype=torch.float32)
         noise = float((better - id_scores[idx]).abs().max())
         id_scores[idx] = better
@@ -103,7 +119,7 @@ class ThresholdRefiner:
         st["rescored"]["id"] = int(done.sum())
         if self.rescore_exact is not None:
             n2 = min(int(self.calib_exact), n_cal)
-            idx = torch.arange(n2, device=dev)
+            idx = idx[:: max(1, n_cal // n2)][:n2]   # a spread subset of the (already split-arm-scored) calibration images
             exact = self.rescore_exact("id", idx).to(device=dev, dtype=torch.float32)
             # two exact-grade arms differ by a few fp32 ulps of the score; never taken below two ulps at the threshold
             a = max(abs(iv[0]), abs(iv[1]))
