@@ -133,3 +133,13 @@ def test_harness_switches_are_one_option_and_quick_turns_every_leg_off():
     d = bench.parse_args([])
     assert d.gpus == 1 and d.steps == 20 and d.batch == 512 and d.prompts == 1000 and d.ckpt == "ViT-B/16" and d.precision == "fp16"
     assert "host-jpeg" not in d.ingest and d.parity_regimes == "fp16-exact"
+
+
+def test_an_oversized_record_loses_sections_not_the_measurement():
+    rec = full_record()
+    rec["arms"] = {f"arm_with_a_long_name_{i:03d}": dict(images_per_sec=1.0, frac=0.1) for i in range(120)}   # a leg gone wild
+    out = bench.fit_line(bench.short_line(rec))
+    assert len(out) <= bench.LINE_LIMIT
+    back = json.loads(out)
+    assert back["value"] > 0 and back["roofline"]["frac"] > 0 and back["cpu_baseline"]["value"] > 0
+    assert "arms" in back["dropped_for_length"] and "arms" not in back
