@@ -270,3 +270,23 @@ def test_split_arm_is_refused_by_handles_that_cannot_run_it():
                                   torch.zeros((4, geo.proj_dim), device="cuda"))
         finally:
             n.close()
+
+
+def test_split_arm_edge_batches():
+    """A one-image handle (197 rows padded into one 256-row tile), an empty batch, a one-prompt bank, and more images than
+    max_batch (chunked) — each equal to what the fp32 arm gives, to fp32 round-off."""
+    geo, n16, n32, bank = _towers("B16-2L", "fp16-exact", 1)
+    try:
+        assert n16.x2_max_batch == 1
+        g = torch.Generator(device="cuda").manual_seed(9)
+        px = torch.randn((3, 3, geo.image_size, geo.image_size), device="cuda", generator=g)
+        want = n32.score_images(px, bank).double()
+        got = n16.score_images_x2(px, bank).double()                     # three chunks of one image
+        assert float((got - want).abs().max()) <= 2e-9
+        assert n16.score_images_x2(px[:0], bank).shape == (0,)
+        one = bank[:1].contiguous()                                      # K = 1: the softmax over one prompt is 1 -> score -1
+        s1 = n16.score_images_x2(px, one)
+        assert torch.equal(s1, torch.full_like(s1, -1.0))
+    finally:
+        n16.close()
+        n32.close()
