@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16x2": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 DEFAULT_PRECISION = "fp16"  # the 16-bit mode that holds AUROC/FPR95 to the fp32 arm
 LINE_LIMIT = 4096           # bytes of the printed line (a 33.6 KB line left the driver with parsed = null)
@@ -184,7 +184,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
     ap.add_argument("--prompts", type=int, default=1000, help="K: size of the concept bank")
     ap.add_argument("--ckpt", default="ViT-B/16")
-    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["bf16", "fp16", "fp16x2", "fp32"],
+                    help="fp16x2: the whole step through the split-activation arm (hi + lo fp16 operands; FLOP counted on the LOGICAL problem)")
     ap.add_argument("--weights-regime", default="fp16-exact", choices=["fp16-exact", "fp32"],
                     help="seeded weights rounded to fp16 values (the reference's checkpoints were trained and released in "
                          "fp16: one fp16 operand per weight is lossless) or as drawn (fp32-valued: the 16-bit arms then run "
@@ -248,7 +249,7 @@ def hbm_kernels(prof, n_prof, geo, B, precision):
     ALGORITHMIC bytes of one step ÷ HIP-event time of that family in one step.  out-proj is the one GEMM shape that is
     HBM-bound (N = K = width: its fp32 read-modify-write of the residual outweighs its FLOP at the machine balance): X in,
     W in, residual read + written in fp32."""
-    M, D, L, es = B * geo.v_tokens, geo.v_width, geo.v_layers, 2 if precision != "fp32" else 4
+    M, D, L, es = B * geo.v_tokens, geo.v_width, geo.v_layers, 2 if precision in ("fp16", "bf16") else 4   # (fp16x2: hi + lo = 4 bytes)
     ln_bytes = ((2 * (L - 1) + 1) * M * D * (4 + es)      # layer_norm1/2 of the full layers + the last layer_norm1
                 + B * D * (4 + es)                          # the last layer's layer_norm2: CLS rows only
                 + M * D * 4)                                # the fused pre_layrnorm pass also rewrites x in fp32
@@ -495,7 +496,7 @@ def main():
             leg_done("cpu_baseline")
     px0 = bufs[0]
     del bufs, scores
-    if side and not args.no_refined and args.precision != "fp32":
+    if side and not args.no_refined and args.precision in ("fp16", "bf16"):   # (fp32 / fp16x2 runs ARE exact-grade arms)
         # throughput AT PARITY: config 3's sizes scored by this arm and threshold-refined, wall clock, same handle
         try:
             line["refined"] = bl.refined_leg(net, geo, sd, txt, ids, mask, B, K, local)
@@ -546,7 +547,7 @@ def main():
         line["configs"] = bl.config_legs(local)
         leg_done("configs")
     if rank == 0:
-        if side and not args.no_drift and args.precision != "fp32":
+        if side and not args.no_drift and args.precision in ("fp16", "bf16"):
             try:
                 line["parity"] = bl.parity_leg(args, K, B, local)
             except Exception as e:
