@@ -46,7 +46,7 @@ class HFReference:
         self.device = torch.device(device)
         self.model = CLIPModel(cfg).eval()
         missing, unexpected = self.model.load_state_dict(
-            {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in state_dict.items()},
+            {k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in state_dict.items()},   # (a copy: the seeded arrays are read-only)
             strict=False)
         bad = [m for m in missing if not m.endswith("position_ids") and m != "logit_scale"]  # unused by MCM
         if bad or unexpected:
