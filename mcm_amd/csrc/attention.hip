@@ -21,6 +21,18 @@
 // Measurements: DESIGN.md section 4.2.
 #include "common.hpp"
 
+// -DMCM_ATTN_TRACE (tools/attn_trace.hip only): cycle stamps of a workgroup's phases, one record per (workgroup, wave)
+#ifdef MCM_ATTN_TRACE
+__device__ unsigned long long* g_attn_trace = nullptr;   // [workgroups][8 waves][8 stamps]
+#define ATTN_STAMP(k)                                                                                                   \
+  do {                                                                                                                  \
+    if (g_attn_trace && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8)                                              \
+      g_attn_trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();             \
+  } while (0)
+#else
+#define ATTN_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ int ktile_off(int r, int c) {  // same image as the GEMM tile
@@ -311,23 +323,32 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   const uint16_t* base = X2 ? qkv + (size_t)seq * L * rs + h * 128
                             : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
+  ATTN_STAMP(0);   // workgroup running
+#ifdef MCM_ATTN_TRACE
+  if (g_attn_trace && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {  // where it runs: (XCC id << 32) | HW_ID
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_attn_trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 7] = ((unsigned long long)(xcc & 0xfu) << 32) | hw;
+  }
+#endif
 
   // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
   const int nqb = (qrows + 15) / 16;
-  uint4 qf[MAXQB][2];
-  uint4 ql[X2 ? MAXQB : 1][2];  // X2: the lo halves (64 elements further on in the row)
-#pragma unroll
-  for (int i = 0; i < MAXQB; ++i) {
+  // Q of the wave's FIRST q-block is requested here, with K and V; Q of a further block is requested as soon as the previous
+  // block's Q K^T is done (it lands under that block's softmax and P V): the Q fragments of one block are live at a time, which
+  // is what lets the B/16 instantiation fit 80 registers — three workgroups per CU instead of two (EXPERIMENTS.md R5.8)
+  uint4 qcur[2], qlcur[X2 ? 2 : 1];
+  auto load_q = [&](int i) {
     const int qr = min((wq + NW * i) * 16 + fr, L - 1);
+    const bool have = wq + NW * i < nqb;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      qf[i][kk] = (wq + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8)
-                                       : make_uint4(0, 0, 0, 0);
-      if constexpr (X2)
-        ql[i][kk] = (wq + NW * i < nqb) ? *(const uint4*)(base + (size_t)qr * rs + 64 + (kk * 4 + g) * 8)
-                                         : make_uint4(0, 0, 0, 0);
+      qcur[kk] = have ? *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
+      if constexpr (X2) qlcur[kk] = have ? *(const uint4*)(base + (size_t)qr * rs + 64 + (kk * 4 + g) * 8) : make_uint4(0, 0, 0, 0);
     }
-  }
+  };
+  load_q(0);
   for (int blk = wave; blk < LP / 8; blk += NW) {  // 1-KiB pieces: 8 key rows each
 #pragma unroll
     for (int part = 0; part < (X2 ? 2 : 1); ++part) {  // hi image, (X2) lo image
@@ -346,8 +367,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
       }
     }
   }
+  ATTN_STAMP(1);   // every load issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(2);   // this wave's loads landed
   __syncthreads();
+  ATTN_STAMP(3);   // everybody's loads landed
 
   int koff[2];
 #pragma unroll
@@ -371,7 +395,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     const int qb = wq + NW * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
-    const uint4 q0 = qf[i][0], q1 = qf[i][1];
+    const uint4 q0 = qcur[0], q1 = qcur[1];
+    uint4 ql0 = make_uint4(0, 0, 0, 0), ql1 = ql0;
+    if constexpr (X2) { ql0 = qlcur[0]; ql1 = qlcur[1]; }
     const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     f32x4_t lacc = zero;
     f32x4_t o[4] = {zero, zero, zero, zero};
@@ -455,8 +481,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         const uint4 kl0 = *(const uint4*)(Ks + LO + t * 2048 + koff[0]), kl1 = *(const uint4*)(Ks + LO + t * 2048 + koff[1]);
         s[t] = mfma_keep<PREC>(kl0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
         s[t] = mfma_keep<PREC>(kl1, q1, s[t]);
-        s[t] = mfma_keep<PREC>(k0, ql[i][0], s[t]);
-        s[t] = mfma_keep<PREC>(k1, ql[i][1], s[t]);
+        s[t] = mfma_keep<PREC>(k0, ql0, s[t]);
+        s[t] = mfma_keep<PREC>(k1, ql1, s[t]);
         s[t] = mfma_keep<PREC>(k0, q0, s[t]);
         s[t] = mfma_keep<PREC>(k1, q1, s[t]);
       } else {
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     }
     if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (i + 1 < MAXQB) load_q(i + 1);   // the next block's Q: under this block's softmax and P V
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -571,7 +598,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         if constexpr (X2) *(uint4*)(orow + 64 + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = widel[pr];
       }
     }
+    ATTN_STAMP(4 + i);   // q-block i of this wave done (stores issued)
   }
+  ATTN_STAMP(6);   // wave done
 }
 
 // ---- fp32 parity arm -------------------------------------------------------------------
