@@ -405,10 +405,18 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
  * 9 = the flagged ping-pong text with every flag off (honours mcm_debug_gemm_group_n) — 6 ... 9: whole tiles, others run as 5.
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
-/* 16-bit attention kernel: 1 (shipped) = the transpose-read kernel, 0 = the round-1 kernel, 2 ... 9 = priority / wave-count /
- * two-pass arms of the shipped kernel at the B/16 shape, 10 = XCD-aware deal of the (sequence, head) workgroups,
- * 11 = the q-blocks dealt to the waves rotated per workgroup (SIMD balance; bit-identical, no gain). */
+/* 16-bit attention kernel: 1 = the shipped policy (the transpose-read kernel; its persistent form at the B/16 shape from 16 jobs
+ * per CU on), 0 = the round-1 kernel, 2 ... 9 = priority / wave-count / two-pass arms of the 8-wave kernel at the B/16 shape,
+ * 10 = XCD-aware deal of the (sequence, head) workgroups, 11 = the q-blocks dealt to the waves rotated per workgroup (SIMD
+ * balance; bit-identical, no gain); round 5 (B/16 shape): 12 - 14 = 6 / 7 / 5 waves per workgroup, 15 - 17 = phase probes of
+ * the 8-wave kernel (WRONG results by design: times only), 18 - 35 = the persistent form at every size (21 = the shipped
+ * parameters: 4 loader waves, window 4; others: loader count / window / K-V units / probes, attention.hip), 36 = the 8-wave kernel
+ * at every size. */
 int mcm_debug_attention_variant(int32_t variant);
+/* mcm_op_attention with the two launch parameters only the model sets: query rows (0 = all; the CLS-only last layer passes 1)
+ * and the walk direction (reverse != 0: jobs in descending order). */
+int mcm_debug_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,
+                           int32_t heads, int32_t causal, int32_t qrows, int32_t reverse, void* stream);
 /* A/B and ablation bits of the GEMM kernels (gemm.hip, GemmArgs::dbg; 0 = shipped behaviour). */
 int mcm_debug_gemm_dbg(int32_t bits);
 /* A/B: run the QKV projection + attention of every layer per chunk of the batch (n chunks; 1 = shipped). */

@@ -270,7 +270,9 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
 }
 
 // PRIO (harness A/B only; 0 = shipped): 1 = s_setprio 1 around the softmax VALU block, 2 = around the MFMA blocks,
-// 3 = static priority 1 for the upper half of the waves
+// 3 = static priority 1 for the upper half of the waves; 5 / 6 / 7 = the phase probes of EXPERIMENTS.md R5.9 (WRONG results by
+// design): 5 = every workgroup reads sequence 0 (reads hit the L2: compute + stores), 6 = no arithmetic (loads, barrier,
+// stores of zeros: the memory phases alone), 7 = sequence-0 reads and no stores (the compute phase alone)
 // X2 (fp16; the split-activation arm): qkv and out are SPLIT images — [rows][6 D] in, [rows][2 D] out,
 // per 64 columns (= one head of q, k or v) hi[64] then lo[64] — and every product runs as three fp16 MFMAs on the hi / lo
 // pairs: S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi, O = V_lo P_hi + V_hi P_lo + V_hi P_hi (the lo x lo terms are below fp32
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   // and V are three runs of L x 128 consecutive bytes.  rs: row stride, KO / VO: from a q row to the k / v row (elements)
   const size_t rs = X2 ? (size_t)6 * D : MCM_HM(hm) ? (size_t)64 : (size_t)3 * D;
   const size_t KO = X2 ? (size_t)2 * D : MCM_HM(hm) ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
-  const uint16_t* base = X2 ? qkv + (size_t)seq * L * rs + h * 128
-                            : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
+  const int lseq = (PRIO == 5 || PRIO == 7) ? 0 : seq;   // (probe arms: L2-resident reads)
+  const uint16_t* base = X2 ? qkv + (size_t)lseq * L * rs + h * 128
+                            : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)lseq * L) * 64 : qkv + (size_t)lseq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
   ATTN_STAMP(0);   // workgroup running
 #ifdef MCM_ATTN_TRACE
@@ -395,6 +398,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     const int qb = wq + NW * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
+    if constexpr (PRIO == 6) {  // (probe arm: the memory phases alone)
+      if (q < L) {
+        uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) *(uint4*)(orow + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = make_uint4(0, 0, 0, 0);
+      }
+      continue;
+    }
     const uint4 q0 = qcur[0], q1 = qcur[1];
     uint4 ql0 = make_uint4(0, 0, 0, 0), ql1 = ql0;
     if constexpr (X2) { ql0 = qlcur[0]; ql1 = qlcur[1]; }
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         widel[pr] = make_uint4(l0[0], l1[0], l0[1], l1[1]);
       }
     }
-    if (q < L) {
+    if (q < L && (PRIO != 7 || hm == 12345)) {   // (probe arm 7: never true at run time, the arithmetic stays)
       uint16_t* orow = X2 ? out + ((size_t)seq * L + q) * 2 * D + h * 128 : out + ((size_t)seq * L + q) * D + h * 64;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {  // even g: block 2pr, dims g*4 .. g*4+7; odd g: block 2pr+1, dims (g-1)*4 ..
@@ -601,6 +612,260 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     ATTN_STAMP(4 + i);   // q-block i of this wave done (stores issued)
   }
   ATTN_STAMP(6);   // wave done
+}
+
+// ---- persistent, specialised form of the 16-bit kernel (round 5, EXPERIMENTS.md R5.9) -------------------------------------
+// The phase probes say: the memory phases of attn_tr_kernel alone take 88 us per launch (7 TB/s), its arithmetic alone 94 us, and
+// the kernel 145 us (standalone, B/16 batch 512) — two 8-wave workgroups per CU, each loading THEN computing, overlap only by
+// chance.  Here the two run side by side by construction: ONE 16-wave workgroup per CU that lives for the whole launch,
+//   * NLD loader waves (the last ones): nothing but LDS-DMA of the K and V images of job n + 2 (a job = one (sequence, head)) into
+//     a ring of three 52-KiB buffers, `ready[loader]` = number of jobs whose pieces have landed (s_waitcnt vmcnt + one LDS store);
+//   * 16 - NLD compute waves: 16-query blocks handed out by an LDS counter in job order (so a SIMD that carries a loader wave
+//     simply takes fewer blocks), each waits for `ready > job`, runs the q-block of attn_tr_kernel unchanged (same arithmetic in the
+//     same order: bit-identical results), and counts itself into `done[buffer]` after its last LDS read — which is what the loaders
+//     wait for before they overwrite a buffer.
+// No workgroup barrier after the first one; no wave waits for a load it issued itself.
+// PROBE (harness): 1 = no loads (arithmetic alone), 2 = no arithmetic, 3 = nobody waits for the loaders.  WIN > 0: a loader wave
+// keeps at most WIN + 1 pieces in flight.  SPLIT: K and V of a job are separate units of the ring — K's slot is free again after the
+// job's last Q K^T (a third into the q-block), V is only waited for before P V: the loaders run further ahead of the arithmetic.
+template <int PREC, int NT, int NFULL, int NLD, int PROBE = 0, int WIN = 0, bool SPLIT = false>
+__global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L,
+                                                        int heads, int qrows, int njobs, int rev) {
+  enter_precision_mode<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LP = NT * 16, BUF = 2 * LP * 128, NCW = 16 - NLD;
+  constexpr int U = SPLIT ? 2 : 1;                            // units (ring entries) per job: K, V — or both as one
+  constexpr int PIECES = 2 * (LP / 8) / U, PPL = PIECES / NLD;   // 1-KiB pieces of a unit, per loader wave
+  static_assert(PIECES % NLD == 0 && PPL < 60, "pieces per loader wave: whole, and within vmcnt's range");
+  constexpr uint32_t ONE2 = PREC == MCM_PREC_F16 ? 0x3c003c00u : 0x3f803f80u;
+  // flags (LDS, after the three buffers): [0..3] units landed per loader wave, [4..6] q-blocks done with K (SPLIT) or with the job,
+  // per buffer, cumulative, [7] next block, [8..10] q-blocks done with V (SPLIT)
+  volatile uint32_t* flags = (volatile uint32_t*)(smem + 3 * BUF);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int D = heads * 64;
+  const size_t rs = (size_t)3 * D;
+  const int nj = (njobs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // jobs blockIdx.x + n gridDim.x, n < nj
+  const int nqb = (qrows + 15) / 16;
+  // rev: the jobs in descending order (the model alternates the walk direction from kernel to kernel, DESIGN.md 4.4d: the rows the
+  // QKV GEMM wrote last are the ones still in the Infinity Cache)
+  auto jobid = [&](int n) { const int j = (int)blockIdx.x + n * (int)gridDim.x; return rev ? njobs - 1 - j : j; };
+  if (threadIdx.x < 12) flags[threadIdx.x] = (threadIdx.x < 4 && ((int)threadIdx.x >= NLD || PROBE == 1)) ? 0x7fffffffu : 0u;
+  __syncthreads();
+
+  if (wave >= NCW) {  // ---------------- loader wave
+    if constexpr (PROBE == 1) return;
+    const int lw = wave - NCW;
+    __builtin_amdgcn_s_setprio(3);
+    for (int m = 0; m < nj * U; ++m) {
+      const int n = m / U, part = m - n * U;
+      const int job = jobid(n);
+      const int seq = job / heads, h = job - seq * heads;
+      const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+      const int b = n % 3;
+      const uint32_t need = (uint32_t)(nqb * (n / 3));   // q-blocks of this slot's earlier jobs
+      const int di = (SPLIT && part) ? 8 + b : 4 + b;
+      if (flags[di] < need) {
+        // the slot is still being read: everything this wave has in flight belongs to units < m — say so before waiting
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flags[lw] = (uint32_t)m;
+        while (flags[di] < need) __builtin_amdgcn_s_sleep(2);
+      }
+      const uint32_t kb = lds_addr(smem + b * BUF), vb = kb + LP * 128;
+#pragma unroll(PPL > 13 ? 2 : PPL)
+      for (int i = 0; i < PPL; ++i) {
+        const int piece = lw * PPL + i;
+        if (SPLIT ? part == 0 : piece < LP / 8) {   // K piece: 8 key rows in the GEMM-style pair / XOR image
+          const int blk = piece;
+          const int p = blk * 4 + (lane >> 4), sl = lane & 15;
+          const int row = min(2 * p + (sl >> 3), L - 1);
+          const int chunk = (sl & 7) ^ (p & 7);
+          glds16(base + (size_t)row * rs + D + chunk * 8, kb + blk * 1024);
+        } else {                // V piece: 8 key rows, 32-B segments XORed with (key >> 1) & 3
+          const int blk = SPLIT ? piece : piece - LP / 8;
+          const int row = blk * 8 + (lane >> 3), pc = lane & 7;
+          const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);
+          glds16(base + (size_t)min(row, L - 1) * rs + 2 * D + lc * 8, vb + blk * 1024);
+        }
+        if constexpr (WIN > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIN) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");   // every piece older than this unit's has landed
+      flags[lw] = (uint32_t)m;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flags[lw] = (uint32_t)(nj * U);
+    return;
+  }
+
+  // ---------------- compute wave
+  const int fr = lane & 15, g = lane >> 4;
+  const int total = nj * nqb;
+  auto fetch = [&]() {  // the next q-block of this workgroup, in job order
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd((uint32_t*)(smem + 3 * BUF) + 7, 1u);
+    return (int)__builtin_amdgcn_readfirstlane(t);
+  };
+  uint4 qcur[2];
+  auto load_q = [&](int T) {
+    const int n = T / nqb, qb = T - n * nqb;
+    const int job = jobid(n);
+    const int seq = job / heads, h = job - seq * heads;
+    const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
+    const int qr = min(qb * 16 + fr, L - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qcur[kk] = *(const uint4*)(base + (size_t)qr * rs + (kk * 4 + g) * 8);
+  };
+  int koff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) koff[kk] = ktile_off(fr, kk * 4 + g);
+  int voff[4];
+  {
+    const int sw = (2 * g + (fr >> 3)) & 3;
+    const int vb = LP * 128 + (4 * g + (fr >> 2)) * 128 + (fr & 3) * 8;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = vb + ((dt ^ sw) << 5);
+  }
+  constexpr float SC = 0.125f * 1.4426950408889634f;
+  int T = fetch();
+  if (T < total) load_q(T);
+  while (T < total) {
+    const int n = T / nqb, qb = T - n * nqb;
+    const int job = jobid(n);
+    const int seq = job / heads, h = job - seq * heads;
+    const int b = n % 3;
+    const int q = qb * 16 + fr;
+    auto wait_unit = [&](int m) {  // unit m has landed (every loader wave says so)
+      for (;;) {
+        if constexpr (PROBE == 3) break;   // (probe: loaders run, nobody waits for them — wrong results, interference alone)
+        const uint32_t r0 = flags[0], r1 = flags[1], r2 = flags[2], r3 = flags[3];
+        if ((int)min(min(r0, r1), min(r2, r3)) > m) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    };
+    wait_unit(n * U);
+    if constexpr (PROBE == 2) {
+      if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + 4 + b, 1u);
+      T = fetch();
+      continue;
+    }
+    const char* Ks = smem + b * BUF;
+    const uint4 q0 = qcur[0], q1 = qcur[1];
+    const f32x4_t zero = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t lacc = zero;
+    f32x4_t o[4] = {zero, zero, zero, zero};
+    constexpr int NS = (NT + 1) / 2;
+    f32x4_t s[NT];
+    uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const uint4 k0 = kn0, k1 = kn1;
+      if (t + 1 < NT) {
+        kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
+        kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
+      }
+      s[t] = mfma_keep<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+      s[t] = mfma_keep<PREC>(k1, q1, s[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (SPLIT) {  // this wave's last read of the job's K has been issued (LDS executes a wave's instructions in order)
+      asm volatile("" ::: "memory");
+      if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + 4 + b, 1u);
+      asm volatile("" ::: "memory");
+    }
+    const int Tn = fetch();          // the next block and its Q: under this block's softmax and P V
+    if (Tn < total) load_q(Tn);
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t >= NFULL && t * 16 + 15 >= L) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = (t * 16 + g * 4 + r < L) ? s[t][r] : -INFINITY;
+      }
+      m = fmaxf(fmaxf(fmaxf(fmaxf(m, s[t][0]), s[t][1]), s[t][2]), s[t][3]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msc = m * SC;
+    uint2 pt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], SC, -msc));
+      pt[t] = make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
+    }
+#define MCM_PSTEP(u)                                                                             \
+  ((2 * (u) + 1 < NT) ? make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
+                                   pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
+                      : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
+    if constexpr (SPLIT) wait_unit(n * U + 1);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const uint4 pu = MCM_PSTEP(u);
+      lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), pu, lacc);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char* vp = Ks + voff[dt];
+        const uint2 lo = tr_read16(vp + (2 * u) * 2048);
+        const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
+        o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pu, o[dt]);
+      }
+    }
+#undef MCM_PSTEP
+    // this wave's last LDS read of the buffer has been issued (LDS executes a wave's instructions in order): count the block
+    asm volatile("" ::: "memory");
+    if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + (SPLIT ? 8 : 4) + b, 1u);
+    asm volatile("" ::: "memory");
+    const float rl = 1.0f / lacc[0];
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      pk[dt][0] = pack2<PREC>(o[dt][0] * rl, o[dt][1] * rl);
+      pk[dt][1] = pack2<PREC>(o[dt][2] * rl, o[dt][3] * rl);
+    }
+    uint4 wide[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+      const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+      wide[pr] = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+    }
+    if (q < L) {
+      uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) *(uint4*)(orow + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = wide[pr];
+    }
+    T = Tn;
+  }
+}
+
+int device_cus() {  // CUs of the current device (one persistent workgroup each)
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+template <int PREC, int NT, int NFULL, int NLD, int PROBE = 0, int WIN = 0, bool SPLIT = false>
+hipError_t launch_ps(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev = 0) {
+  constexpr int lds = 3 * 2 * NT * 16 * 128 + 64;
+  static bool attr_set = false;
+  const int cus = device_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int njobs = nseq * heads;
+  hipLaunchKernelGGL((attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>), dim3(min(cus, njobs)), dim3(1024), lds, s, (const uint16_t*)qkv,
+                     (uint16_t*)out, L, heads, qrows, njobs, rev & 1);
+  return hipGetLastError();
 }
 
 // ---- fp32 parity arm -------------------------------------------------------------------
@@ -879,7 +1144,39 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
   // two-pass form at 80 registers (three workgroups per CU) and at the default budget
   if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
   if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
+  // round 5: 6 / 7 waves per workgroup on the 52-KiB kernel (92 registers: 6 waves x 3 workgroups fit a CU), and the phase probes
+  if (nt == 13 && g_attn_variant == 12 && !causal) return launch_tr<PREC, 13, 6, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 13 && !causal) return launch_tr<PREC, 13, 7, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 14 && !causal) return launch_tr<PREC, 13, 5, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 15 && !causal) return launch_tr<PREC, 13, 8, 3, 5, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 16 && !causal) return launch_tr<PREC, 13, 8, 3, 6, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
+  if (nt == 13 && g_attn_variant == 18 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 0>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 19 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 0>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 20 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 2>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 21 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 4>(qkv, out, nseq, L, heads, qrows, s, rev);
+  if (nt == 13 && g_attn_variant == 22 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 8>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 23 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 4>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 24 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 8>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 25 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 1, 0>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 26 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 2, 0>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 27 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 2, 4>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 28 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 16>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 29 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 1>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 30 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 3, 8>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 31 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 3, 4>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 32 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 8, true>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 33 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 4, true>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 34 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 0, true>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 35 && !causal && !hm) return launch_ps<PREC, 13, 12, 1, 0, 8, true>(qkv, out, nseq, L, heads, qrows, s);
+  if (nt == 13 && g_attn_variant == 17 && !causal) return launch_tr<PREC, 13, 8, 3, 7, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
 #endif
+  // B/16's 13 key tiles, every query row, from 16 jobs per CU on (batch 342 at 12 heads): the persistent form — loader waves and
+  // compute waves side by side (-3.5 ... -5.5 % per launch at batch 512 / 768, break-even at 256, slower below: tools/attn_sweep.py)
+  bool persistent = nt == 13 && !causal && !hm && qrows == L && (int64_t)nseq * heads >= 16 * (int64_t)device_cus();
+#ifdef MCM_HARNESS
+  if (g_attn_variant == 36) persistent = false;   // A/B: the 8-wave kernel at every size
+#endif
+  if (persistent) return launch_ps<PREC, 13, 12, 4, 0, 4>(qkv, out, nseq, L, heads, qrows, s, rev);
   // the three checkpoint geometries need exactly 4 / 13 / 17 key tiles (50 / 197 / 257 tokens): every tile but the last is full
 #define MCM_TR_EXACT(N, W, O) \
   if (nt == N && !causal) return launch_tr<PREC, N, W, O, 0, false, N - 1>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm)

@@ -1313,8 +1313,17 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
 
 #ifdef MCM_HARNESS  // libmcm_hip_harness.so only: process-wide A/B switches for tests and tools
 int mcm_debug_attention_variant(int32_t variant) {
-  if (variant < 0 || variant > 11) return MCM_EINVAL;
+  if (variant < 0 || variant > 40) return MCM_EINVAL;
   attention_set_variant(variant);
+  return MCM_OK;
+}
+
+// mcm_op_attention with the two launch parameters only the model sets: the number of query rows (the CLS-only last layer) and
+// the walk direction
+int mcm_debug_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,
+                           int32_t heads, int32_t causal, int32_t qrows, int32_t reverse, void* stream) {
+  if (!h) return MCM_EINVAL;
+  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, qrows, (hipStream_t)stream, reverse != 0));
   return MCM_OK;
 }
 

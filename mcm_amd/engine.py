@@ -102,6 +102,7 @@ def load_library(harness: bool = False):
         L.mcm_debug_patch_fold.argtypes = [i32]
         L.mcm_debug_resize_fused_only.argtypes = [i32]
         L.mcm_debug_persistent_grid.argtypes = [i32]
+        L.mcm_debug_op_attention.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.mcm_encode_image_u8.argtypes = [vp, vp, i32, vp, vp]
     L.mcm_score_u8.argtypes = [vp, vp, i32, vp, i32, f32, i32, vp, vp]
     L.mcm_reduce_bank.argtypes = [vp, vp, i32, i32, vp, vp]
@@ -153,7 +154,7 @@ HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
                         "mcm_debug_ln_tail", "mcm_debug_ln_tail_timeouts", "mcm_debug_nsplit",
                         "mcm_debug_gemm_group_n", "mcm_debug_patch_fold", "mcm_debug_resize_fused_only",
-                        "mcm_debug_persistent_grid"]
+                        "mcm_debug_persistent_grid", "mcm_debug_op_attention"]
 
 
 def _stream_ptr():

@@ -485,6 +485,46 @@ def test_attention_every_tile_count(tiny_net, harness_net, nseq, L, heads, causa
         harness_net._lib.mcm_debug_attention_variant(1)
 
 
+PS_CASES = [(1, 197, 12, None), (7, 197, 12, None), (43, 197, 12, None), (30, 193, 12, None), (25, 208, 3, None),
+            (9, 200, 16, None), (40, 197, 12, 1), (33, 197, 12, 40), (400, 197, 12, None)]
+
+
+@pytest.mark.parametrize("nseq,L,heads,qrows", PS_CASES)
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_attention_persistent_form_bitwise(harness_net, nseq, L, heads, qrows, prec):
+    """The persistent form of the 13-tile kernel (loader waves + compute waves, one workgroup per CU: DESIGN.md 4.2) forced at
+    every size — fewer jobs than CUs, job counts that are no multiple of the grid, every valid key count of the 13-tile class,
+    reduced query rows (mcm_op_attention_q), both walk directions — against the 8-wave kernel, bit for bit, and against the
+    oracle for the small cases.  (Both kernels run a q-block's arithmetic in the same order.)"""
+    from oracle import oracle as orc
+
+    lib = harness_net._lib
+    D = heads * 64
+    dt = DTYPE[prec]
+    g = torch.Generator(device="cuda").manual_seed(L * 1000 + nseq)
+    qkv = (torch.randn((nseq * L, 3 * D), device="cuda", generator=g) * 1.4).to(dt)
+    outs = {}
+    try:
+        for variant in (36, 21):
+            assert lib.mcm_debug_attention_variant(variant) == 0
+            for rep in range(2):   # both walk directions
+                out = torch.zeros((nseq * L, D), device="cuda", dtype=dt)
+                rc = lib.mcm_debug_op_attention(harness_net._h, PREC[prec], _ptr(qkv), _ptr(out), nseq, L, heads, 0, qrows or 0,
+                                                rep, None)
+                assert rc == 0, lib.mcm_last_error(harness_net._h)
+                torch.cuda.synchronize()
+                outs[(variant, rep)] = out
+        assert torch.equal(outs[(36, 0)], outs[(36, 1)])
+        for rep in range(2):
+            assert torch.equal(outs[(21, rep)].view(torch.int16), outs[(36, 0)].view(torch.int16)), f"walk {rep}"
+    finally:
+        lib.mcm_debug_attention_variant(1)
+    if nseq <= 9 and qrows is None:
+        want = orc.attention(qkv.float().cpu().numpy(), nseq, L, heads, 64, False)
+        tol = 2e-2 if prec == "bf16" else 3e-3
+        np.testing.assert_allclose(outs[(21, 0)].float().cpu().numpy(), want, rtol=tol, atol=tol)
+
+
 def test_attention_full_size_bitwise_repeatable(tiny_net):
     """B/16 batch 512 (6144 workgroups, 3 per CU): three launches bit-identical, and equal to the same
     sequences run as a small launch (a timing-dependent fault shows up as a differing workgroup)."""
