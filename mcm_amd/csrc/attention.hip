@@ -248,7 +248,7 @@ __device__ __forceinline__ uint2 tr_read16(const char* p) {  // ds_read_b64_tr_b
   return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)p));
 }
 
-// Two things learned on the device while bringing this kernel up (tools/attn_debug.py):
+// Two things learned on the device while bringing this kernel up (round 2):
 //  * every value that feeds an MFMA must come from an instruction hipcc can see.  The bf16 pack used to
 //    be an inline-asm v_cvt_pk_bf16_f32; hipcc pads no wait states between an asm statement's VALU write
 //    and an MFMA reading it as an operand (guide §5.7 item 2), and here the packed probabilities go
