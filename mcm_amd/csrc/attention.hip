@@ -854,13 +854,13 @@ int device_cus() {  // CUs of the current device (one persistent workgroup each)
 template <int PREC, int NT, int NFULL, int NLD, int PROBE = 0, int WIN = 0, bool SPLIT = false>
 hipError_t launch_ps(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev = 0) {
   constexpr int lds = 3 * 2 * NT * 16 * 128 + 64;
-  static bool attr_set = false;
+  static PerDeviceFlag attr_set;
   const int cus = device_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
-  if (!attr_set) {
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   const int njobs = nseq * heads;
   hipLaunchKernelGGL((attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>), dim3(min(cus, njobs)), dim3(1024), lds, s, (const uint16_t*)qkv,
@@ -1032,11 +1032,11 @@ template <int NT, int NW>
 hipError_t launch_f32_mfma(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s) {
   constexpr int lds = NT * 16 * 68 * 2 * (int)sizeof(float);
   static_assert(lds <= 160 * 1024, "K and V of one head must fit the LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_f32_mfma_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((attn_f32_mfma_kernel<NT, NW>), dim3(nseq * heads), dim3(NW * 64), lds, s, (const float*)qkv, (float*)out, L,
                      heads, qrows);
@@ -1048,15 +1048,15 @@ template <int PREC, int LP>
 hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, bool causal,
                        int qrows, hipStream_t s, int rev) {
   constexpr int lds = LP * 128 + 64 * vt_stride(LP);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<PREC, LP, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)attn_bf16_kernel<PREC, LP, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   if (causal)
     hipLaunchKernelGGL((attn_bf16_kernel<PREC, LP, true>), dim3(nseq * heads), dim3(256), lds, s,
@@ -1077,8 +1077,8 @@ template <int PREC, int NT, int NW, int OCC, int PRIO = 0, bool X2 = false, int 
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                      hipStream_t s, int rev, int hm) {
   constexpr int lds = NT * 16 * 128 * (X2 ? 4 : 2);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, X2, NFULL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (!X2) {
@@ -1087,7 +1087,7 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   if constexpr (X2) {  // (the vision tower only: no causal form)
     if (causal) return hipErrorInvalidValue;
@@ -1242,15 +1242,15 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   }
   const int lds = (L * 65 + L * 64 + 4 * 64 + 4 * L) * (int)sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)attn_f32_kernel<true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   if (causal)
     hipLaunchKernelGGL(attn_f32_kernel<true>, dim3(nseq * heads), dim3(256), lds, s,

@@ -6,6 +6,15 @@
 
 #include "../../include/mcm.h"
 
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: a launcher's "already raised the dynamic-LDS limit"
+// flag is kept per device, so that a process holding handles on two devices sets it on both.
+struct PerDeviceFlag {
+  bool done[64] = {};
+  static int dev() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1; }
+  bool get() const { const int d = dev(); return d >= 0 && done[d]; }
+  void set() { const int d = dev(); if (d >= 0) done[d] = true; }
+};
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

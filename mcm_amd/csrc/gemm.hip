@@ -1288,12 +1288,12 @@ int persistent_grid() {
 
 template <int PREC, int EPI>
 hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, tile::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   const int nbn = (a.N + tile::BN - 1) / tile::BN, nbm = (a.M + tile::BM - 1) / tile::BM;
   hipLaunchKernelGGL((gemm_tile_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
@@ -1302,12 +1302,12 @@ hipError_t launch_tile(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 hipError_t launch_tile64(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tile64_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, tile64::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   const int nbn = (a.N + tile64::BN - 1) / tile64::BN, nbm = (a.M + tile64::BM - 1) / tile64::BM;
   hipLaunchKernelGGL((gemm_tile64_kernel<PREC, EPI>), dim3(nbn * nbm), dim3(256), tile64::LDS_BYTES, s, a);
@@ -1316,12 +1316,12 @@ hipError_t launch_tile64(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI, bool CS, bool PXF = false>
 hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_p256_kernel<PREC, EPI, CS, PXF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_p256_kernel<PREC, EPI, CS, PXF>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
@@ -1329,12 +1329,12 @@ hipError_t launch_p256(const GemmArgs& a, hipStream_t s) {
 
 template <int PREC, int EPI>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_pp_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();

@@ -1522,12 +1522,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
 // ---- launchers of the arms ----------------------------------------------------------------------------------------
 template <int PREC, int EPI>
 hipError_t launch_tile_fold(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_tile_kernel<PREC, EPI, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, tile::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   const int nbn = (a.N + tile::BN - 1) / tile::BN, nbm = (a.M + tile::BM - 1) / tile::BM;
   hipLaunchKernelGGL((arms::gemm_tile_kernel<PREC, EPI, true>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
@@ -1535,36 +1535,36 @@ hipError_t launch_tile_fold(const GemmArgs& a, hipStream_t s) {
 }
 template <int PREC, int EPI, bool CS>
 hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<PREC, EPI, CS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, persist::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 template <int PREC, int EPI>
 hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_pp32_kernel<PREC, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_pp32_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();

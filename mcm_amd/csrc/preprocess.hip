@@ -325,12 +325,12 @@ hipError_t launch_resize_crop(const PrepImage* meta_dev, int32_t* coef_dev, int 
   const int lds_fused = (S * KMAX + ROWS * KMAX) * 4 + (2 * S + 2 * ROWS) * 4;
   const int lds_form = (S * FT + ROWS * FT) * 4 + (S + 2 * ROWS) * 4 + 16 + LDS_FORM_BYTES + 64;
   const int lds = lds_fused > lds_form ? lds_fused : lds_form;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)resize_crop_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   const bool lds_ok = coef_dev && !fused_only && (S & 3) == 0;

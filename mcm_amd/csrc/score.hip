@@ -203,12 +203,12 @@ hipError_t launch_score(const float* img, int B, const float* text, int K, int P
     return hipErrorInvalidValue;
   const int lds = (P + K) * (int)sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute((const void*)score_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL(score_kernel, dim3(B), dim3(NWV * 64), lds, s, img, text, K, P, T, kind, scores);
   return hipGetLastError();
