@@ -96,6 +96,35 @@ class ClipGeometry:
         d, ff, L = self.t_width, self.t_mlp, self.t_layers
         return float(L * (8 * d * d + 4 * d * ff))
 
+    # ---- batch sizes and the persistent GEMM grid (EXPERIMENTS.md R5.11)
+    def gemm_tile_rounds(self, batch: int, cus: int = 256) -> dict:
+        """Tile rounds of the persistent 256x256 GEMM kernels at `batch` images: for each full-layer shape
+        {qkv, outproj, fc1, fc2} the rounds the launch takes (the fullest XCD decides: M tiles are striped over the 8 XCDs,
+        an XCD's cus / 8 workgroups walk its tiles) and the fraction of its tile slots that hold a tile."""
+        mt = -(-batch * self.v_tokens // 256)
+        per_xcd = cus // 8
+        out = {}
+        for name, n in (("qkv", 3 * self.v_width), ("outproj", self.v_width), ("fc1", self.v_mlp), ("fc2", self.v_width)):
+            nbn = -(-n // 256)
+            rounds = max(-(-((mt - x + 7) // 8) * nbn // per_xcd) for x in range(8))
+            out[name] = {"rounds": rounds, "fill": mt * nbn / (rounds * cus)}
+        return out
+
+    def full_round_batches(self, lo: int = 1, hi: int = 2048, cus: int = 256) -> list:
+        """Batch sizes in [lo, hi] at which EVERY vision GEMM fills its last tile round (the largest batch of each such
+        M-tile count): per-image throughput peaks there — measured on one MI355X, ViT-B/16 batch 665 / 1330 against 512:
+        +2.7 % / +4.1 %; ViT-L/14 255 against 256: +4.4 %; ViT-B/32 1310 against 512: +20 % (profiles/r05_m_*).  Scores do
+        not depend on the batch they were computed in (bit-identical kernels), so this is a free choice of the caller."""
+        out = []
+        mt = 8
+        while mt * 256 // self.v_tokens <= hi:
+            b = mt * 256 // self.v_tokens  # the largest batch whose token rows fit mt M tiles
+            if b >= lo and all(abs(v["fill"] - 1.0) < 1e-9 for v in self.gemm_tile_rounds(b, cus).values()):
+                if -(-b * self.v_tokens // 256) == mt:
+                    out.append(b)
+            mt += 8
+        return out
+
     def to_c(self, *, device: int = 0, precision: int = PREC_BF16, max_batch: int = 512,
              max_prompt_tokens: int = 1024 * 77, weight_operands: int = 0) -> CConfig:
         d = asdict(self)

@@ -203,3 +203,21 @@ def test_native_image_packing_equals_a_python_copy():
         assert np.array_equal(dst, want), threads
     assert L.mcm_pack_u8(srcs, sizes, offsets, n, dst.ctypes.data_as(vp), o - 64, 4) == -7     # MCM_ERANGE: last image does not fit
     assert L.mcm_pack_u8(srcs, sizes, offsets, 0, dst.ctypes.data_as(vp), dst.size, 4) == 0
+
+
+def test_full_round_batches():
+    """ClipGeometry.full_round_batches / gemm_tile_rounds (EXPERIMENTS.md R5.11): the batches at which every vision GEMM
+    fills its last round of the persistent 256-workgroup grid; batch 512 of the headline config does not."""
+    from mcm_amd.config import geometry
+
+    b16, l14, b32 = geometry("ViT-B/16"), geometry("ViT-L/14"), geometry("ViT-B/32")
+    assert b16.full_round_batches(1, 1400) == [332, 665, 998, 1330]
+    assert l14.full_round_batches(200, 520) == [255, 318, 382, 446, 510]
+    assert b32.full_round_batches(1, 2048) == [1310]
+    r = b16.gemm_tile_rounds(512)
+    assert {k: v["rounds"] for k, v in r.items()} == {"qkv": 15, "outproj": 5, "fc1": 19, "fc2": 5}
+    assert abs(r["outproj"]["fill"] - 394 * 3 / (5 * 256)) < 1e-12
+    assert all(v["fill"] == 1.0 for v in b16.gemm_tile_rounds(665).values())
+    assert l14.gemm_tile_rounds(256)["outproj"]["rounds"] == 5 and l14.gemm_tile_rounds(255)["outproj"]["rounds"] == 4
+    for b in b16.full_round_batches(1, 1400):  # the largest batch of its M-tile count
+        assert -(-(b + 1) * 197 // 256) == -(-b * 197 // 256) + 1

@@ -66,7 +66,8 @@ def full_record():
                                    "value_hoisted: bank encoded once) after a warm-up (bank + 8 images) of 7.1 s; same seeded weights",
                          "parity_max_abs_dscore_vs_native": 2.4330802261829376e-08, "parity_images": 64},
         "arms": {n: dict(leg) for n in ("fp32", "bf16_single_operand", "bf16_split", "fp16_split_weights", "fp16x2_split_activations")},
-        "configs": {n: dict(leg) for n in ("c4_L14_fp16_b256", "c2_B16_K100_bf16", "c2_B16_K100_fp16")},
+        "configs": {n: dict(leg) for n in ("c4_L14_fp16_b256", "c2_B16_K100_bf16", "c2_B16_K100_fp16",
+                                                "c4_L14_fp16_b255", "c3_B16_fp16_b665")},
         "parity": {"config": "c" * 250, "bar": "b" * 180, "vs": "HF CLIPModel fp32 on this device",
                    "fp16_exact_weights": regime, "fp32_valued_weights": regime,
                    "meets_1e-4": {w: {a: False for a in arms} for w in ("fp16_exact_weights", "fp32_valued_weights")},

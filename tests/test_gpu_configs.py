@@ -31,6 +31,21 @@ def _np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
+def test_cli_full_round_batch_same_scores(tmp_path, monkeypatch):
+    """`--full-round-batch` (512 -> 665 at ViT-B/16: every GEMM fills its tile rounds, EXPERIMENTS.md R5.11) changes the batch
+    the images are scored in and nothing else: the same float32 scores, bit for bit."""
+    import eval_ood_detection as cli
+
+    monkeypatch.chdir(tmp_path)
+    common = ["--in_dataset", "ImageNet10", "--CLIP_ckpt", "ViT-B/16", "--synthetic", "--synthetic-n", "700",
+              "--refine-threshold", "off"]
+    a = cli.main(common + ["-b", "512", "--name", "b512"])
+    b = cli.main(common + ["-b", "512", "--full-round-batch", "--name", "b665"])
+    assert (a["batch_size"], b["batch_size"]) == (512, 665)
+    np.testing.assert_array_equal(_np(a["in_score"]), _np(b["in_score"]))
+    np.testing.assert_array_equal(_np(a["out_scores"]["ImageNet20"]), _np(b["out_scores"]["ImageNet20"]))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16", "fp16x2"])
 def test_config1_imagenet10_vs_imagenet20_b16_batch64(tmp_path, monkeypatch, dtype):
     import pandas as pd

@@ -569,7 +569,8 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, two_level=True):
 
 def config_legs(device, steps=3):
     """BASELINE configs 4 and 2 on this device, 3 timed steps each after one warm-up step (like `arms`): ViT-L/14 fp16 batch 256
-    K = 1000 (config 4's per-GPU work) and ViT-B/16 K = 100 batch 512 in bf16 (the dtype config 2 names) and fp16."""
+    K = 1000 (config 4's per-GPU work) and ViT-B/16 K = 100 batch 512 in bf16 (the dtype config 2 names) and fp16; plus
+    configs 4 and 3 at the nearest full-round batch (255, 665)."""
     import torch
 
     from mcm_amd.config import geometry
@@ -579,7 +580,11 @@ def config_legs(device, steps=3):
     out = {}
     for name, ckpt, prec, B, K in (("c4_L14_fp16_b256", "ViT-L/14", "fp16", 256, 1000),
                                    ("c2_B16_K100_bf16", "ViT-B/16", "bf16", 512, 100),
-                                   ("c2_B16_K100_fp16", "ViT-B/16", "fp16", 512, 100)):
+                                   ("c2_B16_K100_fp16", "ViT-B/16", "fp16", 512, 100),
+                                   # the same work at a batch whose GEMMs fill every tile round (ClipGeometry.full_round_batches,
+                                   # EXPERIMENTS.md R5.11): what a caller free to choose its batch gets per image
+                                   ("c4_L14_fp16_b255", "ViT-L/14", "fp16", 255, 1000),
+                                   ("c3_B16_fp16_b665", "ViT-B/16", "fp16", 665, 1000)):
         try:
             geo = geometry(ckpt)
             sd = synth_state_dict(geo, 0, "fp16-exact")
