@@ -54,9 +54,9 @@ def test_headline_parity_vs_hf_reference(weights):
     from mcm_amd.parity import CONFIG3_OOD_SETS, HEADLINE_PIXELS, measure_drift
 
     assert DEFAULT_PRECISION == "fp16"
-    # HF itself scores the 85 640 images in the fp16-exact regime (50 s of the test); in the fp32-valued regime the
-    # suite compares against the exact-fp32 arm only — that arm equals HF to 4e-7 there too, measured by every default
-    # bench.py run (parity.fp32_valued_weights.vs_hf) — to keep `pytest -m gpu` within a few minutes
+    # HF itself scores the 85 640 images in the fp16-exact regime (50 s of the test); in the fp32-valued regime this test
+    # compares against the exact-fp32 arm only — that arm equals HF there too: test_fp32_valued_regime_fp32_arm_equals_hf
+    # (20 000 images) and bench.py --parity-regimes fp16-exact,fp32 (all 85 640: 4e-7) — to keep `pytest -m gpu` within minutes
     with_hf = weights == "fp16-exact"
     arms = ("fp16", "bf16", "fp16x2", "fp16+refine", "fp16+refine2") if with_hf else ("fp16", "fp16:single", "fp16x2", "fp16+refine", "fp16+refine2")
     d = measure_drift("ViT-B/16", K=1000, n_id=50000, batch=512, arms=arms, ood_sets=CONFIG3_OOD_SETS,
@@ -110,6 +110,23 @@ def test_headline_parity_vs_hf_reference(weights):
         assert b["d_auroc"] <= 1e-3 and b["d_fpr95"] <= 1.5e-3, b
         assert arm["rms_dscore"] < d["arms"]["bf16"]["rms_dscore"]
     assert all(v == 0 for v in d["fp16_saturation_events"].values()), d["fp16_saturation_events"]  # nothing left the fp16 range
+
+
+def test_fp32_valued_regime_fp32_arm_equals_hf():
+    """The fp32-valued weight regime against HF itself (the headline test above compares that regime with
+    the exact-fp32 arm only): the arm every other arm of that regime is measured against IS the HF computation there too —
+    headline pixels and bank, 10 000 ID + 10 000 OOD images (HF scores them in 12 s)."""
+    from mcm_amd.parity import CONFIG3_OOD_SETS, HEADLINE_PIXELS, measure_drift
+
+    d = measure_drift("ViT-B/16", K=1000, n_id=10000, batch=512, arms=("fp16",), ood_sets=CONFIG3_OOD_SETS[:1],
+                      amp=HEADLINE_PIXELS["amp"], tile=HEADLINE_PIXELS["tile"], weights="fp32", external=_external())
+    print("fp32-valued regime vs HF:", json.dumps(d))
+    assert d["weight_operands"]["fp16"]["split"]
+    r = d["reference"]["vs_external"]["hf"]
+    assert r["d_auroc"] <= 1e-5 and r["d_aupr"] <= 1e-5 and r["rms_dscore"] <= 1e-9, r
+    assert r["max_set"]["d_fpr95_images"] <= 1, r
+    vs = d["arms"]["fp16"]["vs_external"]["hf"]     # and the benchmarked dtype (split weights here) against HF directly
+    assert vs["max_set"]["d_auroc"] <= BAR and vs["max_set"]["d_aupr"] <= BAR, vs
 
 
 @pytest.mark.parametrize("weights", ["fp16-exact", "fp32"])
