@@ -5,8 +5,13 @@ below which 95 % of the ID set lies.  A 16-bit arm's score noise (rms 5.6e-9 for
 scores' spread, so it can only change the count through the images whose score is within a few noise widths of that
 threshold: 0 - 2 of 10 000 on the headline sets, 8 of 31 000 at a realistic operating point —
 small, but not the reference's number.  Those images can be named: everything within `delta` of the threshold.  This
-module re-scores exactly them with a better arm and patches their scores in place; every other image is provably on the
-same side of the threshold in both arms as long as its own noise is below `delta`.
+module re-scores exactly them with a better arm and patches their scores in place; every other image is on the same side
+of the threshold in both arms AS LONG AS its own noise is below `delta` — which is an assumption about the 85 000 images
+that were not calibrated, not a proof: `delta` is `margin` x the largest difference seen on `calib` images, a tail-probability
+argument.  What holds it up is measured, not derived: tests/test_gpu_headline_parity.py asserts, over every image of BASELINE
+config 3, max |split-activation arm - 16-bit arm| <= delta (the calibration bound held everywhere).  And the repair is
+specific to FPR at THIS recall level: a score outside the window keeps its 16-bit noise, so another consumer of the
+per-sample scores (another recall level, a downstream threshold) gets the raw arm there.
 
     delta = margin x (largest |better arm - 16-bit| score difference over a calibration sample of the ID set)
 
@@ -59,10 +64,11 @@ def _calibration_indices(n: int, n_cal: int, device):
     if n_cal >= n:
         return torch.arange(n, device=device)
     run = 64
-    nb = -(-n_cal // run)
-    starts = [(k * (n // nb)) // run * run for k in range(nb)]
-    idx = torch.cat([torch.arange(s, min(s + run, n)) for s in starts])[:n_cal]
-    return idx.to(device)
+    blocks = -(-n // run)                       # aligned 64-image blocks of the set (the last one may be short)
+    nb = min(blocks, -(-n_cal // run))
+    picked = [(k * blocks) // nb for k in range(nb)]   # nb DISTINCT blocks, evenly spread (blocks >= nb): no image twice
+    idx = torch.cat([torch.arange(b * run, min((b + 1) * run, n)) for b in picked])[:n_cal]
+    return idx.to(device)   # (idx.numel() can fall short of n_cal by the short last block: callers report idx.numel())
 
 
 class ThresholdRefiner:
@@ -107,6 +113,7 @@ class ThresholdRefiner:
         n_cal = min(int(self.calib), id_scores.numel())
         idx = _calibration_indices(id_scores.numel(), n_cal, dev)
         better = self.rescore("id", idx).to(device=dev, dtype=torch.float32)
+        n_cal = int(idx.numel())
         noise = float((better - id_scores[idx]).abs().max())
         id_scores[idx] = better
         done = torch.zeros(id_scores.numel(), dtype=torch.bool, device=dev)
@@ -118,7 +125,7 @@ class ThresholdRefiner:
             iv, st["rounds"] = self._window_rounds(id_scores, done, self.rescore, self.delta, iv)
         st["rescored"]["id"] = int(done.sum())
         if self.rescore_exact is not None:
-            n2 = min(int(self.calib_exact), n_cal)
+            n2 = max(1, min(int(self.calib_exact), n_cal))
             idx = idx[:: max(1, n_cal // n2)][:n2]   # a spread subset of the (already split-arm-scored) calibration images
             exact = self.rescore_exact("id", idx).to(device=dev, dtype=torch.float32)
             # two exact-grade arms differ by a few fp32 ulps of the score; never taken below two ulps at the threshold
