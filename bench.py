@@ -88,9 +88,23 @@ def short_line(d):
     for k in ("harness", "note"):
         if d.get(k):
             line[k] = str(d[k])[:160]
+    if d.get("kernel_faults"):
+        line["kernel_faults"] = d["kernel_faults"]
+    if d.get("per_rank"):   # N > 1: one compact record per rank — own images/s in the timed region, own sustained clock and power
+        line["per_rank"] = [{"img_s": _r(r.get("img_s")), "sclk_mhz": _r(r.get("sclk_mhz"), 4), "power_w": _r(r.get("power_w"), 4),
+                             "ag_ms": _r(r.get("ms_allgather"), 3)} for r in d["per_rank"]]
+        line["allgather_ms"] = [_r(d.get("allgather_ms_min"), 3), _r(d.get("allgather_ms"), 3)]   # [min, max] over ranks
+    # throughput AT PARITY and the exact-grade split-activation arm, each with its own end-to-end fraction of the dense MFMA peak
+    # (images/s x nominal GFLOP per image / peak: SURVEY section 8d's definition) — always-kept keys
+    gpi, peak = d.get("gflop_per_image"), MFMA_PEAK_TFLOPS.get(d.get("dtype"), 2500.0)
+    x2 = _get(d, "arms", "fp16x2_split_activations", "images_per_sec")
+    if x2 and gpi:
+        line["value_fp16x2"], line["frac_fp16x2"] = _r(x2, 7), _r(x2 * gpi / 1e3 / MFMA_PEAK_TFLOPS["fp16x2"], 3)
     rf = d.get("refined")
     if rf:
         line["value_refined"] = _r(rf.get("images_per_sec"), 7)
+        if rf.get("images_per_sec") and gpi:
+            line["frac_refined"] = _r(rf["images_per_sec"] * gpi / 1e3 / peak, 3)
         line["refined"] = {k: _r(rf.get(k)) for k in ("images", "rescored", "seconds", "seconds_refine", "rescorer",
                                                        "fpr95_images_vs_fp32_arm_max_set", "error") if k in rf}
         if rf.get("exact"):  # --refine-threshold exact: the inner window also through an exact-fp32 handle
@@ -150,7 +164,7 @@ def fit_line(short):
     """The line as text, never above LINE_LIMIT: should a leg ever produce more than the worst case the CPU test builds, whole
     optional sections are dropped (least important first; the detail file has them) rather than losing the run's measurement."""
     short = dict(short)
-    for k in (None, "kernel_ms_per_step", "ingest", "configs", "sustained", "arms", "roofline_hbm", "parity", "refined", "collective"):
+    for k in (None, "kernel_ms_per_step", "ingest", "configs", "sustained", "arms", "roofline_hbm", "parity", "refined", "collective", "per_rank"):
         if k is not None:
             if k not in short:
                 continue
@@ -160,7 +174,8 @@ def fit_line(short):
         if len(out) <= LINE_LIMIT:
             return out
     return json.dumps({k: short.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                                 "scaling", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "detail")},
+                                                 "scaling", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "value_refined",
+                                                 "frac_refined", "value_fp16x2", "frac_fp16x2", "detail")},
                       separators=(",", ":"))[:LINE_LIMIT]
 
 
@@ -365,9 +380,14 @@ def main():
         if args.idle_ms >= 0:  # measurement hook: an idle device between steps (kernel times come from the HIP events)
             torch.cuda.synchronize()
             time.sleep(args.idle_ms * 1e-3)
+    t_own = t_ag = None
     if coll:  # the path's only exchange: per-dataset all-gather of the score shards
+        torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0          # this rank's own steps (no collective yet)
         full = mdist.all_gather_scores(scores.reshape(-1), ws * args.steps * B)
         assert full.numel() == ws * args.steps * B
+        torch.cuda.synchronize()
+        t_ag = time.perf_counter() - t0 - t_own   # the all-gather as THIS rank saw it: its own cost + waiting for the slowest rank
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -390,21 +410,34 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:  # every rank runs it (the chip-level power state is what is being measured)
         n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
-        sampler = bl.SmiSampler() if rank == 0 else None
-        if sampler:
-            sampler.start()
+        # EVERY rank samples ITS OWN GPU (sysfs / rocm-smi -d): on a chassis where eight 1.35-kW parts share a power budget a
+        # sub-linear curve must be attributable to clocks from the line alone
+        sampler = bl.SmiSampler(period=0.5 if ws == 1 else 1.0, device=local)
+        sampler.start()
         barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(n_sus):
             step(i, scores[i % args.steps])
         torch.cuda.synchronize()
+        dts_own = time.perf_counter() - t1
         barrier()
         dts = time.perf_counter() - t1
         sustained = {"steps": n_sus, "seconds": dts, "images_per_sec": ws * n_sus * B / dts}
-        if sampler:
-            sustained.update(sampler.stop())
+        mine = sampler.stop()
+        sustained.update(mine)
+        sustained["own_images_per_sec"] = n_sus * B / dts_own
         leg_done("sustained")
+
+    per_rank = None
+    if coll:  # one record per rank, gathered outside the timed region: what each GPU did on its own, at what clock and power
+        rec = {"rank": rank, "device": local, "img_s": args.steps * B / t_own, "ms_own_steps": 1e3 * t_own, "ms_allgather": 1e3 * t_ag,
+               "kernel_faults": net.kernel_faults}
+        if sustained:
+            rec.update(sustained_img_s=sustained.get("own_images_per_sec"), sclk_mhz=sustained.get("sclk_mhz_mean"),
+                       power_w=sustained.get("power_w_mean"), smi=sustained.get("source"))
+        per_rank = [None] * ws
+        torch.distributed.all_gather_object(per_rank, rec)
 
     ingest = None
     if side and args.ingest != "none":
@@ -446,6 +479,11 @@ def main():
                                   "check, not a scaling number" % (ws, ndev)) if shared else \
                 "%s all_gather_into_tensor of the score shards (device tensors, no host bounce), inside the timed region" % \
                 ("nccl (RCCL)" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend())
+        line["kernel_faults"] = net.kernel_faults   # bounded waits of the persistent kernels that ran out (0 in a correct run)
+        if per_rank:
+            line["per_rank"] = per_rank
+            line["allgather_ms"] = max(r["ms_allgather"] for r in per_rank)   # incl. waiting for the slowest rank
+            line["allgather_ms_min"] = min(r["ms_allgather"] for r in per_rank)  # ~ the collective's own cost (the slowest rank waits for nobody)
         if ingest:
             line["ingest"] = ingest
         if sustained:

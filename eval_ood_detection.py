@@ -93,16 +93,11 @@ def process_args(argv=None):
                         "decoding on host threads, the rest of libjpeg's work + Resize + CenterCrop on the GPU, Pillow for files that "
                         "are not Huffman YCbCr / grayscale JPEGs); same pixels either way")
     p.add_argument("--full-round-batch", action="store_true",
-                   help="raise --batch-size to the next batch at which every vision GEMM fills its last tile round of the "
-                        "persistent grid (ViT-B/16: 512 -> 665, +2.7 %% images/sec; ViT-L/14: 256 -> 318; mcm_amd.config."
-                        "ClipGeometry.full_round_batches).  Scores do not depend on the batch they were computed in")
+                   help="raise --batch-size to the next batch (within 4 x) at which every vision GEMM fills its last tile round of "
+                        "the persistent grid on this device (mcm_amd.config.ClipGeometry.full_round_batches; ViT-B/16 on 256 CUs: "
+                        "512 -> 665; ViT-L/14: 256 -> 318, +4 %% images/sec; the chosen batch, or that there is none, is logged).  "
+                        "Scores do not depend on the batch they were computed in")
     args = p.parse_args(argv)
-    if args.full_round_batch:
-        from mcm_amd.config import geometry
-
-        better = geometry(args.CLIP_ckpt).full_round_batches(args.batch_size, 4 * args.batch_size)
-        if better:
-            args.batch_size = better[0]
     if args.decoder:
         os.environ["MCM_GPU_JPEG"] = "1" if args.decoder == "device" else "0"
     if args.templates:
@@ -200,9 +195,26 @@ def main(argv=None):
     log = setup_log(args)
     dev = (local % ndev) if ws > 1 else args.gpu
     torch.cuda.set_device(dev)
+    if args.full_round_batch:   # (resolved here, not in process_args: the tile rounds depend on THIS device's CU count)
+        from mcm_amd.config import geometry
+
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count // 8 * 8   # the persistent GEMMs' grid
+        better = geometry(args.CLIP_ckpt).full_round_batches(args.batch_size, 4 * args.batch_size, cus=cus) if cus >= 8 else []
+        if better:
+            log.debug(f"--full-round-batch: batch {args.batch_size} -> {better[0]} (every vision GEMM of {args.CLIP_ckpt} fills its last "
+                      f"tile round on {cus} CUs; the activation workspace grows with it)")
+            args.batch_size = better[0]
+        else:
+            log.debug(f"--full-round-batch: no batch in [{args.batch_size}, {4 * args.batch_size}] fills every GEMM's last tile round "
+                      f"for {args.CLIP_ckpt} on {cus} CUs; keeping batch {args.batch_size}")
+    # the split-activation workspace of an fp16 handle (include/mcm.h mcm_config.x2_max_batch): the whole run goes
+    # through that arm with --dtype fp16x2 (full batch: twice the activation bytes); threshold refinement re-scores a few hundred
+    # images, for which half the batch costs nothing extra; otherwise the workspace is not allocated at all
+    will_refine = args.refine_threshold != "off" and args.score != "maha"
+    x2_batch = 0 if args.dtype == "fp16x2" else (max(1, args.batch_size // 2) if (args.dtype == "fp16" and will_refine) else -1)
     net = build_model(args.CLIP_ckpt, weights=args.weights, device=dev, precision=args.dtype,
                       max_batch=args.batch_size, synthetic_regime=args.synthetic_weights,
-                      weight_operands=args.weight_operands)
+                      weight_operands=args.weight_operands, x2_max_batch=x2_batch)
     net.eval()
     if args.dtype != "fp32":
         log.debug(f"vision GEMM weights: {net.weights_inexact} element(s) are not {args.dtype} numbers -> "

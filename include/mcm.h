@@ -29,11 +29,13 @@
 extern "C" {
 #endif
 
-#define MCM_ABI_VERSION 3 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
+#define MCM_ABI_VERSION 4 /* 2: mcm_set_weight takes the host element type; mcm_config.weight_operands; split-weight
                           * arm and mcm_weights_operand_exact; mcm_op_linear_ex / mcm_op_split_weight; the round-2
                           * mcm_debug_* exports live in libmcm_hip_harness.so only
                           * 3: MCM_KC_COUNT 7 -> 11 (per-shape GEMM classes: mcm_profile_read's arrays grew); the
-                          * split-activation arm (mcm_score_x2 ...) and the MCM_LINEAR_SPLIT_X / _OUT flags */
+                          * split-activation arm (mcm_score_x2 ...) and the MCM_LINEAR_SPLIT_X / _OUT flags
+                          * 4: mcm_config.x2_max_batch (the split-activation workspace is sized by the caller);
+                          * mcm_kernel_faults + the sticky fault word (every wait of a persistent kernel is bounded) */
 
 /* error codes */
 #define MCM_OK 0
@@ -105,6 +107,10 @@ typedef struct mcm_config {
   int32_t max_batch;        /* images per mcm_encode_image / mcm_score call           */
   int32_t max_prompt_tokens;/* K*S per mcm_encode_text call                           */
   int32_t weight_operands;  /* MCM_WEIGHTS_*; ignored in MCM_PREC_F32                 */
+  int32_t x2_max_batch;     /* MCM_PREC_F16 handles: images per mcm_score_x2 / mcm_encode_image_x2 call.  0 = max_batch (the
+                             * activation buffers at twice the bytes: +1.5 GB at ViT-B/16 batch 512), n > 0 = at most n (the
+                             * buffers hold max(max_batch rows, 2 x the rows of n images): nothing extra for n <= max_batch / 2),
+                             * < 0 = no split-activation workspace (those calls return MCM_EINVAL)  */
 } mcm_config;
 
 int mcm_abi_version(void);
@@ -189,8 +195,8 @@ int mcm_score_u8(mcm_handle* h, const uint8_t* pixels_dev, int32_t B, const floa
  * Scores agree with the exact-fp32 arm (MCM_PREC_F32) to fp32 round-off at about half the fp16 arm's throughput, where
  * the fp32 arm runs at a tenth of it: what mcm_amd/refine.py re-scores the images near the FPR95 threshold with
  * (reference utils/detection_util.py:66-106: FPR95 is a count at one threshold).  No second handle, no extra weights:
- * an fp16 handle's activation buffers are allocated at twice the bytes so that the split rows (twice the width) fit at
- * the full batch: B <= mcm_x2_max_batch(h) = cfg.max_batch (0 = this handle is not fp16).  pixel_format: MCM_PIXELS_*.
+ * the split rows (twice the width) live in the same activation buffers, which mcm_create sizes for cfg.x2_max_batch images
+ * of them: B <= mcm_x2_max_batch(h) (0 = this handle is not fp16, or was created without the workspace).  pixel_format: MCM_PIXELS_*.
  * Asynchronous on `stream`, no allocation, like mcm_score. */
 int mcm_x2_max_batch(const mcm_handle* h);
 int mcm_encode_image_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, int32_t normalize,
@@ -394,6 +400,14 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
 int mcm_saturation_check(mcm_handle* h, int32_t on);
 int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, void* stream);
 
+/* Kernel faults (ABI 4).  The persistent attention kernel (one workgroup per CU: loader waves and compute waves that wait for each
+ * other through LDS counters) bounds every wait: a wave that has polled 2^22 times (three orders of magnitude above the kernel's
+ * whole run time) stops its workgroup and stores 1 to a sticky per-handle word in host-mapped memory, so that a protocol slip ends
+ * the launch with wrong rows instead of holding the GPU until a watchdog fires.  From then on every compute call on the handle
+ * returns MCM_EHIP (mcm_last_error says why): the handle must be destroyed.  mcm_kernel_faults reads the word without
+ * synchronising (non-zero = faulted; for a definitive answer synchronise the stream first); 0 in every correct run. */
+int mcm_kernel_faults(const mcm_handle* h);
+
 #ifdef MCM_HARNESS
 /* libmcm_hip_harness.so only (built with -DMCM_HARNESS next to the shipped library; loaded by the A/B tests
  * and tools, never by the product path).  Process-wide switches.
@@ -406,13 +420,16 @@ int mcm_saturation_count(mcm_handle* h, int32_t reset, uint64_t* count_host, voi
  * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
 /* 16-bit attention kernel: 1 = the shipped policy (the transpose-read kernel; its persistent form at the B/16 shape from 16 jobs
- * per CU on), 0 = the round-1 kernel, 2 ... 9 = priority / wave-count / two-pass arms of the 8-wave kernel at the B/16 shape,
- * 10 = XCD-aware deal of the (sequence, head) workgroups, 11 = the q-blocks dealt to the waves rotated per workgroup (SIMD
- * balance; bit-identical, no gain); round 5 (B/16 shape): 12 - 14 = 6 / 7 / 5 waves per workgroup, 15 - 17 = phase probes of
- * the 8-wave kernel (WRONG results by design: times only), 18 - 35 = the persistent form at every size (21 = the shipped
- * parameters: 4 loader waves, window 4; others: loader count / window / K-V units / probes, attention.hip), 36 = the 8-wave kernel
- * at every size. */
+ * per CU on), 0 = the round-1 kernel, 10 = XCD-aware deal of the (sequence, head) workgroups, 11 = the q-blocks dealt to the waves
+ * rotated per workgroup (SIMD balance; bit-identical, no gain), 21 = the persistent form at every size and query count of the
+ * 13-tile shape, 36 = the 8-wave kernel at every size.  Anything else: MCM_EINVAL (the arms 2 - 9, 12 - 20, 22 - 35 of rounds
+ * 2 - 5 were removed in round 6: EXPERIMENTS.md "Removed arms"). */
 int mcm_debug_attention_variant(int32_t variant);
+/* Polls a wait of the persistent attention kernel may take before it gives up (the shipped library always passes 2^22);
+ * 0 = every wait that has to wait gives up at once.  mcm_debug_clear_faults resets the handle's sticky fault word.  Both exist
+ * for the test of the fault path only. */
+int mcm_debug_attn_spin_budget(int64_t polls);
+int mcm_debug_clear_faults(mcm_handle* h);
 /* mcm_op_attention with the two launch parameters only the model sets: query rows (0 = all; the CLS-only last layer passes 1)
  * and the walk direction (reverse != 0: jobs in descending order). */
 int mcm_debug_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,

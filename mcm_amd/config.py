@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass, asdict, replace
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2
@@ -53,6 +53,7 @@ class CConfig(ctypes.Structure):
         ("max_batch", ctypes.c_int32),
         ("max_prompt_tokens", ctypes.c_int32),
         ("weight_operands", ctypes.c_int32),
+        ("x2_max_batch", ctypes.c_int32),
     ]
 
 
@@ -126,12 +127,12 @@ class ClipGeometry:
         return out
 
     def to_c(self, *, device: int = 0, precision: int = PREC_BF16, max_batch: int = 512,
-             max_prompt_tokens: int = 1024 * 77, weight_operands: int = 0) -> CConfig:
+             max_prompt_tokens: int = 1024 * 77, weight_operands: int = 0, x2_max_batch: int = 0) -> CConfig:
         d = asdict(self)
         d.pop("name")
         return CConfig(abi_version=ABI_VERSION, device=device, precision=precision,
                        max_batch=max_batch, max_prompt_tokens=max_prompt_tokens,
-                       weight_operands=weight_operands, **d)
+                       weight_operands=weight_operands, x2_max_batch=x2_max_batch, **d)
 
     def hf_configs(self):
         """HF `CLIPConfig` of the same geometry (golden-fixture generation and the

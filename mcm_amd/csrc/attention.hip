@@ -269,10 +269,8 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
   return d;
 }
 
-// PRIO (harness A/B only; 0 = shipped): 1 = s_setprio 1 around the softmax VALU block, 2 = around the MFMA blocks,
-// 3 = static priority 1 for the upper half of the waves; 5 / 6 / 7 = the phase probes of EXPERIMENTS.md R5.9 (WRONG results by
-// design): 5 = every workgroup reads sequence 0 (reads hit the L2: compute + stores), 6 = no arithmetic (loads, barrier,
-// stores of zeros: the memory phases alone), 7 = sequence-0 reads and no stores (the compute phase alone)
+// (The s_setprio arms, the two-pass 80-register form and the phase probes of rounds 2 - 5 were measured and removed in round 6:
+// EXPERIMENTS.md "Removed arms", git history before round 6.)
 // X2 (fp16; the split-activation arm): qkv and out are SPLIT images — [rows][6 D] in, [rows][2 D] out,
 // per 64 columns (= one head of q, k or v) hi[64] then lo[64] — and every product runs as three fp16 MFMAs on the hi / lo
 // pairs: S = K_lo Q_hi + K_hi Q_lo + K_hi Q_hi, O = V_lo P_hi + V_hi P_lo + V_hi P_hi (the lo x lo terms are below fp32
@@ -284,11 +282,11 @@ __device__ __forceinline__ f32x4_t mfma_keep(uint4 a, uint4 b, f32x4_t c) {
 // tile but the last when the sequence needs exactly NT tiles).  The key-validity mask of those tiles folds away at compile time —
 // with a run-time L hipcc predicates it instead of branching, 3 VALU instructions per score (v_cmp, v_cndmask, an index v_or) on a
 // kernel whose compute phase is bound by VALU issue: 158 of the 565 issue slots of a 16-query block at B/16.  Same bits.
-template <int PREC, int NT, bool CAUSAL, int NW, int OCC, int PRIO = 0, bool X2 = false, int NFULL = 0>
+template <int PREC, int NT, bool CAUSAL, int NW, int OCC, bool X2 = false, int NFULL = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* __restrict__ qkv,
                                                                          uint16_t* __restrict__ out, int L,
                                                                          int heads, int qrows, int rev, int hm) {
-  static_assert(!X2 || (PREC == MCM_PREC_F16 && PRIO == 0), "split activations: fp16, the shipped one-pass form");
+  static_assert(!X2 || PREC == MCM_PREC_F16, "split activations: fp16");
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP = NT * 16;           // padded keys
@@ -322,9 +320,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   // and V are three runs of L x 128 consecutive bytes.  rs: row stride, KO / VO: from a q row to the k / v row (elements)
   const size_t rs = X2 ? (size_t)6 * D : MCM_HM(hm) ? (size_t)64 : (size_t)3 * D;
   const size_t KO = X2 ? (size_t)2 * D : MCM_HM(hm) ? (size_t)heads * hm * 64 : (size_t)D, VO = 2 * KO;
-  const int lseq = (PRIO == 5 || PRIO == 7) ? 0 : seq;   // (probe arms: L2-resident reads)
-  const uint16_t* base = X2 ? qkv + (size_t)lseq * L * rs + h * 128
-                            : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)lseq * L) * 64 : qkv + (size_t)lseq * L * rs + h * 64;
+  const uint16_t* base = X2 ? qkv + (size_t)seq * L * rs + h * 128
+                            : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
   ATTN_STAMP(0);   // workgroup running
 #ifdef MCM_ATTN_TRACE
@@ -389,23 +386,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     for (int dt = 0; dt < 4; ++dt) vlane[dt] = vb + ((dt ^ sw) << 5);
   }
   constexpr float SC = 0.125f * 1.4426950408889634f;  // scale * log2(e)
-  if constexpr (PRIO == 3) {
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-  }
 
 #pragma unroll
   for (int i = 0; i < MAXQB; ++i) {
     const int qb = wq + NW * i;
     if (qb >= nqb) break;
     const int q = qb * 16 + fr;
-    if constexpr (PRIO == 6) {  // (probe arm: the memory phases alone)
-      if (q < L) {
-        uint16_t* orow = out + ((size_t)seq * L + q) * D + h * 64;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) *(uint4*)(orow + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = make_uint4(0, 0, 0, 0);
-      }
-      continue;
-    }
     const uint4 q0 = qcur[0], q1 = qcur[1];
     uint4 ql0 = make_uint4(0, 0, 0, 0), ql1 = ql0;
     if constexpr (X2) { ql0 = qlcur[0]; ql1 = qlcur[1]; }
@@ -426,61 +412,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         }
       }
     };
-    if constexpr (PRIO == 4) {
-      // TWO-PASS form (harness A/B): pass 1 computes S = K Q^T only for the row max and throws it away; pass 2
-      // recomputes it key step by key step, exponentiates and feeds P straight into the row-sum and P V MFMAs.  The
-      // 13-tile score array (52 registers) never exists, so the kernel fits 80 registers and three 8-wave workgroups
-      // share a CU (one of them always loading); the exponentials of step u+1 overlap the MFMAs of step u.  Same
-      // arithmetic in the same order as the one-pass form: bit-identical results; 26 more MFMAs and K-fragment reads
-      // per q-block on pipes that are 24 % busy.
-      float m = -INFINITY;
-      {
-        uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const uint4 k0 = kn0, k1 = kn1;
-          if (t + 1 < NT) {
-            kn0 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[0]);
-            kn1 = *(const uint4*)(Ks + (t + 1) * 2048 + koff[1]);
-          }
-          f32x4_t st = mfma_keep<PREC>(k0, q0, zero);
-          st = mfma_keep<PREC>(k1, q1, st);
-          mask_tile(st, t);
-          m = fmaxf(fmaxf(fmaxf(fmaxf(m, st[0]), st[1]), st[2]), st[3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      const float msc = m * SC;
-      auto ptile = [&](int t) {  // P of key tile t in MFMA operand order
-        f32x4_t st = mfma_keep<PREC>(*(const uint4*)(Ks + t * 2048 + koff[0]), q0, zero);
-        st = mfma_keep<PREC>(*(const uint4*)(Ks + t * 2048 + koff[1]), q1, st);
-        mask_tile(st, t);
-        float e[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(st[r], SC, -msc));
-        return make_uint2(pack2<PREC>(e[0], e[1]), pack2<PREC>(e[2], e[3]));
-      };
-#pragma unroll
-      for (int u = 0; u < NS; ++u) {
-        const uint2 p0 = ptile(2 * u);
-        const uint2 p1 = (2 * u + 1 < NT) ? ptile((2 * u + 1 < NT) ? 2 * u + 1 : 0) : make_uint2(0u, 0u);
-        const uint4 pu = make_uint4(p0.x, p0.y, p1.x, p1.y);
-        lacc = mfma_keep<PREC>(make_uint4(ONE2, ONE2, ONE2, ONE2), pu, lacc);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const char* vp = vlane[dt];
-          const uint2 lo = tr_read16(vp + (2 * u) * 2048);
-          const uint2 hi = (2 * u + 1 < NT) ? tr_read16(vp + (2 * u + 1) * 2048) : make_uint2(0u, 0u);
-          o[dt] = mfma_keep<PREC>(make_uint4(lo.x, lo.y, hi.x, hi.y), pu, o[dt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
     f32x4_t s[NT];
     uint4 kn0 = *(const uint4*)(Ks + koff[0]), kn1 = *(const uint4*)(Ks + koff[1]);
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const uint4 k0 = kn0, k1 = kn1;
@@ -502,8 +435,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if (i + 1 < MAXQB) load_q(i + 1);   // the next block's Q: under this block's softmax and P V
     float m = -INFINITY;
 #pragma unroll
@@ -535,8 +466,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   ((2 * (u) + 1 < NT) ? make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
                                    pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
                       : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
-    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
     // O^T = V^T · P^T for the four 16-dim blocks and the row sum (all-ones A operand), key step by key step: five
     // independent accumulator chains in flight, so no MFMA waits for the one just issued (dim-block-outer order
     // made each of the 7 steps of a chain wait out the previous step's latency)
@@ -569,8 +498,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
     }
 #undef MCM_PLSTEP
 #undef MCM_PSTEP
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    }
     const float rl = 1.0f / lacc[0];
     // A lane holds 4 dims (8 B) of each of the four 16-dim blocks.  Lanes g and g^1 (16 lanes apart) trade one
     // block of each pair by v_permlane16_swap, after which a lane owns 8 consecutive dims (16 B) of ONE block:
@@ -601,7 +528,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         widel[pr] = make_uint4(l0[0], l1[0], l0[1], l1[1]);
       }
     }
-    if (q < L && (PRIO != 7 || hm == 12345)) {   // (probe arm 7: never true at run time, the arithmetic stays)
+    if (q < L) {
       uint16_t* orow = X2 ? out + ((size_t)seq * L + q) * 2 * D + h * 128 : out + ((size_t)seq * L + q) * D + h * 64;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {  // even g: block 2pr, dims g*4 .. g*4+7; odd g: block 2pr+1, dims (g-1)*4 ..
@@ -620,26 +547,33 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
 // chance.  Here the two run side by side by construction: ONE 16-wave workgroup per CU that lives for the whole launch,
 //   * NLD loader waves (the last ones): nothing but LDS-DMA of the K and V images of job n + 2 (a job = one (sequence, head)) into
 //     a ring of three 52-KiB buffers, `ready[loader]` = number of jobs whose pieces have landed (s_waitcnt vmcnt + one LDS store);
+//     a loader wave keeps at most WIN + 1 pieces in flight;
 //   * 16 - NLD compute waves: 16-query blocks handed out by an LDS counter in job order (so a SIMD that carries a loader wave
 //     simply takes fewer blocks), each waits for `ready > job`, runs the q-block of attn_tr_kernel unchanged (same arithmetic in the
 //     same order: bit-identical results), and counts itself into `done[buffer]` after its last LDS read — which is what the loaders
 //     wait for before they overwrite a buffer.
 // No workgroup barrier after the first one; no wave waits for a load it issued itself.
-// PROBE (harness): 1 = no loads (arithmetic alone), 2 = no arithmetic, 3 = nobody waits for the loaders.  WIN > 0: a loader wave
-// keeps at most WIN + 1 pieces in flight.  SPLIT: K and V of a job are separate units of the ring — K's slot is free again after the
-// job's last Q K^T (a third into the q-block), V is only waited for before P V: the loaders run further ahead of the arithmetic.
-template <int PREC, int NT, int NFULL, int NLD, int PROBE = 0, int WIN = 0, bool SPLIT = false>
+// EVERY WAIT IS BOUNDED (round 6): a wave that has polled `spin_budget` times without its condition coming true — a protocol slip,
+// a lost wave — raises the workgroup's abort word, stores 1 to the handle's fault word (host-mapped: the next API call on the
+// handle returns MCM_EHIP, mcm_kernel_faults reads it) and returns; every other wave of the workgroup sees the abort word in its
+// own polls and returns too.  The workgroup's output rows are then garbage, but the launch ENDS (the budget, 2^22 polls of >= 64
+// cycles, is three orders of magnitude above the kernel's whole run time) instead of holding the GPU until a watchdog fires.
+// (Measured and removed in round 6 — EXPERIMENTS.md "Removed arms": 1 / 2 loader waves, windows 0 / 1 / 2 / 8 / 16, K and V as
+// separate ring entries, the no-load / no-arithmetic / nobody-waits probes.)
+constexpr int PS_WIN = 4;                      // a loader wave keeps at most PS_WIN + 1 pieces in flight
+constexpr unsigned int PS_SPIN_BUDGET = 1u << 22;
+template <int PREC, int NT, int NFULL, int NLD>
 __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L,
-                                                        int heads, int qrows, int njobs, int rev) {
+                                                        int heads, int qrows, int njobs, int rev, unsigned int spin_budget,
+                                                        unsigned int* __restrict__ fault) {
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LP = NT * 16, BUF = 2 * LP * 128, NCW = 16 - NLD;
-  constexpr int U = SPLIT ? 2 : 1;                            // units (ring entries) per job: K, V — or both as one
-  constexpr int PIECES = 2 * (LP / 8) / U, PPL = PIECES / NLD;   // 1-KiB pieces of a unit, per loader wave
+  constexpr int PIECES = 2 * (LP / 8), PPL = PIECES / NLD;   // 1-KiB pieces of a job's K + V images, per loader wave
   static_assert(PIECES % NLD == 0 && PPL < 60, "pieces per loader wave: whole, and within vmcnt's range");
   constexpr uint32_t ONE2 = PREC == MCM_PREC_F16 ? 0x3c003c00u : 0x3f803f80u;
-  // flags (LDS, after the three buffers): [0..3] units landed per loader wave, [4..6] q-blocks done with K (SPLIT) or with the job,
-  // per buffer, cumulative, [7] next block, [8..10] q-blocks done with V (SPLIT)
+  // flags (LDS, after the three buffers): [0..3] jobs landed per loader wave, [4..6] q-blocks done with the job, per buffer,
+  // cumulative, [7] next block, [11] abort (a wait ran out of its budget somewhere in this workgroup)
   volatile uint32_t* flags = (volatile uint32_t*)(smem + 3 * BUF);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -650,50 +584,56 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
   // rev: the jobs in descending order (the model alternates the walk direction from kernel to kernel, DESIGN.md 4.4d: the rows the
   // QKV GEMM wrote last are the ones still in the Infinity Cache)
   auto jobid = [&](int n) { const int j = (int)blockIdx.x + n * (int)gridDim.x; return rev ? njobs - 1 - j : j; };
-  if (threadIdx.x < 12) flags[threadIdx.x] = (threadIdx.x < 4 && ((int)threadIdx.x >= NLD || PROBE == 1)) ? 0x7fffffffu : 0u;
+  if (threadIdx.x < 12) flags[threadIdx.x] = (threadIdx.x < 4 && (int)threadIdx.x >= NLD) ? 0x7fffffffu : 0u;
   __syncthreads();
+  auto give_up = [&]() {   // this wave's wait ran out: stop the workgroup, tell the host
+    flags[11] = 1u;
+    if (lane == 0 && fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
 
   if (wave >= NCW) {  // ---------------- loader wave
-    if constexpr (PROBE == 1) return;
     const int lw = wave - NCW;
     __builtin_amdgcn_s_setprio(3);
-    for (int m = 0; m < nj * U; ++m) {
-      const int n = m / U, part = m - n * U;
+    for (int n = 0; n < nj; ++n) {
       const int job = jobid(n);
       const int seq = job / heads, h = job - seq * heads;
       const uint16_t* base = qkv + (size_t)seq * L * rs + h * 64;
       const int b = n % 3;
       const uint32_t need = (uint32_t)(nqb * (n / 3));   // q-blocks of this slot's earlier jobs
-      const int di = (SPLIT && part) ? 8 + b : 4 + b;
-      if (flags[di] < need) {
-        // the slot is still being read: everything this wave has in flight belongs to units < m — say so before waiting
+      if (flags[4 + b] < need) {
+        // the slot is still being read: everything this wave has in flight belongs to jobs < n — say so before waiting
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        flags[lw] = (uint32_t)m;
-        while (flags[di] < need) __builtin_amdgcn_s_sleep(2);
+        flags[lw] = (uint32_t)n;
+        unsigned int polls = 0;
+        while (flags[4 + b] < need) {
+          if (flags[11] != 0u) return;
+          if (++polls > spin_budget) { give_up(); return; }
+          __builtin_amdgcn_s_sleep(2);
+        }
       }
       const uint32_t kb = lds_addr(smem + b * BUF), vb = kb + LP * 128;
 #pragma unroll(PPL > 13 ? 2 : PPL)
       for (int i = 0; i < PPL; ++i) {
         const int piece = lw * PPL + i;
-        if (SPLIT ? part == 0 : piece < LP / 8) {   // K piece: 8 key rows in the GEMM-style pair / XOR image
+        if (piece < LP / 8) {   // K piece: 8 key rows in the GEMM-style pair / XOR image
           const int blk = piece;
           const int p = blk * 4 + (lane >> 4), sl = lane & 15;
           const int row = min(2 * p + (sl >> 3), L - 1);
           const int chunk = (sl & 7) ^ (p & 7);
           glds16(base + (size_t)row * rs + D + chunk * 8, kb + blk * 1024);
         } else {                // V piece: 8 key rows, 32-B segments XORed with (key >> 1) & 3
-          const int blk = SPLIT ? piece : piece - LP / 8;
+          const int blk = piece - LP / 8;
           const int row = blk * 8 + (lane >> 3), pc = lane & 7;
           const int lc = ((((pc >> 1) ^ (row >> 1)) & 3) << 1) | (pc & 1);
           glds16(base + (size_t)min(row, L - 1) * rs + 2 * D + lc * 8, vb + blk * 1024);
         }
-        if constexpr (WIN > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WIN) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PS_WIN) : "memory");
       }
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");   // every piece older than this unit's has landed
-      flags[lw] = (uint32_t)m;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPL) : "memory");   // every piece older than this job's has landed
+      flags[lw] = (uint32_t)n;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    flags[lw] = (uint32_t)(nj * U);
+    flags[lw] = (uint32_t)nj;
     return;
   }
 
@@ -734,20 +674,16 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
     const int seq = job / heads, h = job - seq * heads;
     const int b = n % 3;
     const int q = qb * 16 + fr;
-    auto wait_unit = [&](int m) {  // unit m has landed (every loader wave says so)
+    {  // job n has landed (every loader wave says so)
+      unsigned int polls = 0;
       for (;;) {
-        if constexpr (PROBE == 3) break;   // (probe: loaders run, nobody waits for them — wrong results, interference alone)
         const uint32_t r0 = flags[0], r1 = flags[1], r2 = flags[2], r3 = flags[3];
-        if ((int)min(min(r0, r1), min(r2, r3)) > m) break;
+        if ((int)min(min(r0, r1), min(r2, r3)) > n) break;
+        if (flags[11] != 0u) return;
+        if (++polls > spin_budget) { give_up(); return; }
         __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");
-    };
-    wait_unit(n * U);
-    if constexpr (PROBE == 2) {
-      if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + 4 + b, 1u);
-      T = fetch();
-      continue;
     }
     const char* Ks = smem + b * BUF;
     const uint4 q0 = qcur[0], q1 = qcur[1];
@@ -767,11 +703,6 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
       s[t] = mfma_keep<PREC>(k0, q0, (f32x4_t){0.f, 0.f, 0.f, 0.f});
       s[t] = mfma_keep<PREC>(k1, q1, s[t]);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (SPLIT) {  // this wave's last read of the job's K has been issued (LDS executes a wave's instructions in order)
-      asm volatile("" ::: "memory");
-      if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + 4 + b, 1u);
-      asm volatile("" ::: "memory");
     }
     const int Tn = fetch();          // the next block and its Q: under this block's softmax and P V
     if (Tn < total) load_q(Tn);
@@ -799,7 +730,6 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
   ((2 * (u) + 1 < NT) ? make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].x, \
                                    pt[(2 * (u) + 1 < NT) ? 2 * (u) + 1 : 0].y)                  \
                       : make_uint4(pt[2 * (u)].x, pt[2 * (u)].y, 0u, 0u))
-    if constexpr (SPLIT) wait_unit(n * U + 1);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const uint4 pu = MCM_PSTEP(u);
@@ -815,7 +745,7 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
 #undef MCM_PSTEP
     // this wave's last LDS read of the buffer has been issued (LDS executes a wave's instructions in order): count the block
     asm volatile("" ::: "memory");
-    if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + (SPLIT ? 8 : 4) + b, 1u);
+    if (lane == 0) atomicAdd((uint32_t*)(smem + 3 * BUF) + 4 + b, 1u);
     asm volatile("" ::: "memory");
     const float rl = 1.0f / lacc[0];
     uint32_t pk[4][2];
@@ -840,31 +770,29 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const uint16_t* __restric
   }
 }
 
-int device_cus() {  // CUs of the current device (one persistent workgroup each)
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
+#ifdef MCM_HARNESS
+unsigned int g_ps_spin_budget = PS_SPIN_BUDGET;   // mcm_debug_attn_spin_budget: 0 = every wait gives up at once (the fault path's test)
+#endif
 
-template <int PREC, int NT, int NFULL, int NLD, int PROBE = 0, int WIN = 0, bool SPLIT = false>
-hipError_t launch_ps(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev = 0) {
+template <int PREC, int NT, int NFULL, int NLD>
+hipError_t launch_ps(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev, unsigned int* fault) {
   constexpr int lds = 3 * 2 * NT * 16 * 128 + 64;
   static PerDeviceFlag attr_set;
-  const int cus = device_cus();
+  const int cus = device_cu_count();
   if (cus <= 0) return hipErrorInvalidDevice;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_ps_kernel<PREC, NT, NFULL, NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set.set();
   }
   const int njobs = nseq * heads;
-  hipLaunchKernelGGL((attn_ps_kernel<PREC, NT, NFULL, NLD, PROBE, WIN, SPLIT>), dim3(min(cus, njobs)), dim3(1024), lds, s, (const uint16_t*)qkv,
-                     (uint16_t*)out, L, heads, qrows, njobs, rev & 1);
+#ifdef MCM_HARNESS
+  const unsigned int budget = g_ps_spin_budget;
+#else
+  const unsigned int budget = PS_SPIN_BUDGET;
+#endif
+  hipLaunchKernelGGL((attn_ps_kernel<PREC, NT, NFULL, NLD>), dim3(min(cus, njobs)), dim3(1024), lds, s, (const uint16_t*)qkv,
+                     (uint16_t*)out, L, heads, qrows, njobs, rev & 1, budget, fault);
   return hipGetLastError();
 }
 
@@ -1070,20 +998,21 @@ hipError_t launch_bf16(const void* qkv, void* out, int nseq, int L, int heads, b
 #endif
 
 #ifdef MCM_HARNESS
-int g_attn_variant = 1;  // 1 = attn_tr_kernel (shipped), 0 = attn_bf16_kernel (round 1), 2/3/4 = s_setprio A/B arms
+int g_attn_variant = 1;  // 1 = the shipped policy, 0 = attn_bf16_kernel (round 1), 10 / 11 = XCD-aware / rotated deals of
+                         // attn_tr_kernel, 21 = the persistent form at every size, 36 = attn_tr_kernel at every size
 #endif
 
-template <int PREC, int NT, int NW, int OCC, int PRIO = 0, bool X2 = false, int NFULL = 0>
+template <int PREC, int NT, int NW, int OCC, bool X2 = false, int NFULL = 0>
 hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
                      hipStream_t s, int rev, int hm) {
   constexpr int lds = NT * 16 * 128 * (X2 ? 4 : 2);
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, X2, NFULL>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, false, NW, OCC, X2, NFULL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (!X2) {
       if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO, X2>,
+        e = hipFuncSetAttribute((const void*)attn_tr_kernel<PREC, NT, true, NW, OCC, X2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     if (e != hipSuccess) return e;
@@ -1091,15 +1020,15 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
   }
   if constexpr (X2) {  // (the vision tower only: no causal form)
     if (causal) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, true, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, true, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
     return hipGetLastError();
   } else {
   if (causal)
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC, PRIO>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, true, NW, OCC>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   else
-    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, PRIO, false, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
+    hipLaunchKernelGGL((attn_tr_kernel<PREC, NT, false, NW, OCC, false, NFULL>), dim3(nseq * heads), dim3(NW * 64), lds, s,
                        (const uint16_t*)qkv, (uint16_t*)out, L, heads, qrows, rev, hm);
   return hipGetLastError();
   }
@@ -1110,8 +1039,8 @@ hipError_t launch_tr(const void* qkv, void* out, int nseq, int L, int heads, boo
 hipError_t launch_tr_x2(const void* qkv, void* out, int nseq, int L, int heads, int qrows, hipStream_t s, int rev) {
   const int nt = (L + 15) / 16;
 #define MCM_TRX(N, W) \
-  if (nt <= N) return launch_tr<MCM_PREC_F16, N, W, 1, 0, true>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0)
-  if (nt == 13) return launch_tr<MCM_PREC_F16, 13, 8, 1, 0, true, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0);
+  if (nt <= N) return launch_tr<MCM_PREC_F16, N, W, 1, true>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0)
+  if (nt == 13) return launch_tr<MCM_PREC_F16, 13, 8, 1, true, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, 0);
   MCM_TRX(2, 4); MCM_TRX(4, 4); MCM_TRX(8, 4); MCM_TRX(13, 8); MCM_TRX(17, 8); MCM_TRX(18, 8);
 #undef MCM_TRX
   return hipErrorInvalidValue;
@@ -1127,59 +1056,23 @@ hipError_t launch_tr_x2(const void* qkv, void* out, int nseq, int L, int heads, 
 // for every wave count (a q-block's arithmetic does not depend on which wave runs it).
 template <int PREC>
 hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int heads, bool causal, int qrows,
-                              hipStream_t s, int rev, int hm) {
+                              hipStream_t s, int rev, int hm, unsigned int* fault) {
   const int nt = (L + 15) / 16;
 #ifdef MCM_HARNESS
   if (g_attn_variant == 10 && nseq % 8 == 0) rev |= 2;  // XCD-aware deal of the (sequence, head) workgroups
   if (g_attn_variant == 11) rev |= 4;                   // q-blocks dealt to the waves rotated per workgroup (SIMD balance)
 #endif
-#ifdef MCM_HARNESS  // priority A/B arms, B/16 shape only (13 key tiles)
-  if (nt == 13 && g_attn_variant == 2) return launch_tr<PREC, 13, 8, 3, 1>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 3) return launch_tr<PREC, 13, 8, 3, 2>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 4) return launch_tr<PREC, 13, 8, 3, 3>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  // wave-count arms: one q-block per wave (13 waves, 832 threads) at two register budgets, and 10 waves
-  if (nt == 13 && g_attn_variant == 5) return launch_tr<PREC, 13, 13, 7>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 6) return launch_tr<PREC, 13, 13, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 7) return launch_tr<PREC, 13, 10, 5>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  // two-pass form at 80 registers (three workgroups per CU) and at the default budget
-  if (nt == 13 && g_attn_variant == 8) return launch_tr<PREC, 13, 8, 6, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 9) return launch_tr<PREC, 13, 8, 3, 4>(qkv, out, nseq, L, heads, causal, qrows, s, rev, hm);
-  // round 5: 6 / 7 waves per workgroup on the 52-KiB kernel (92 registers: 6 waves x 3 workgroups fit a CU), and the phase probes
-  if (nt == 13 && g_attn_variant == 12 && !causal) return launch_tr<PREC, 13, 6, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 13 && !causal) return launch_tr<PREC, 13, 7, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 14 && !causal) return launch_tr<PREC, 13, 5, 3, 0, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 15 && !causal) return launch_tr<PREC, 13, 8, 3, 5, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 16 && !causal) return launch_tr<PREC, 13, 8, 3, 6, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-  if (nt == 13 && g_attn_variant == 18 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 0>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 19 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 0>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 20 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 2>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 21 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 4>(qkv, out, nseq, L, heads, qrows, s, rev);
-  if (nt == 13 && g_attn_variant == 22 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 8>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 23 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 4>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 24 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 8>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 25 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 1, 0>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 26 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 2, 0>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 27 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 2, 4>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 28 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 16>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 29 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 0, 1>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 30 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 3, 8>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 31 && !causal && !hm) return launch_ps<PREC, 13, 12, 4, 3, 4>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 32 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 8, true>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 33 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 4, true>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 34 && !causal && !hm) return launch_ps<PREC, 13, 12, 2, 0, 0, true>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 35 && !causal && !hm) return launch_ps<PREC, 13, 12, 1, 0, 8, true>(qkv, out, nseq, L, heads, qrows, s);
-  if (nt == 13 && g_attn_variant == 17 && !causal) return launch_tr<PREC, 13, 8, 3, 7, false, 12>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm);
-#endif
   // B/16's 13 key tiles, every query row, from 16 jobs per CU on (batch 342 at 12 heads): the persistent form — loader waves and
   // compute waves side by side (-3.5 ... -5.5 % per launch at batch 512 / 768, break-even at 256, slower below: tools/attn_sweep.py)
-  bool persistent = nt == 13 && !causal && !hm && qrows == L && (int64_t)nseq * heads >= 16 * (int64_t)device_cus();
+  bool persistent = nt == 13 && !causal && !hm && qrows == L && (int64_t)nseq * heads >= 16 * (int64_t)device_cu_count();
 #ifdef MCM_HARNESS
-  if (g_attn_variant == 36) persistent = false;   // A/B: the 8-wave kernel at every size
+  if (g_attn_variant == 36) persistent = false;                      // A/B: the 8-wave kernel at every size
+  if (g_attn_variant == 21) persistent = nt == 13 && !causal && !hm;  // A/B: the persistent form at every size and query count
 #endif
-  if (persistent) return launch_ps<PREC, 13, 12, 4, 0, 4>(qkv, out, nseq, L, heads, qrows, s, rev);
+  if (persistent) return launch_ps<PREC, 13, 12, 4>(qkv, out, nseq, L, heads, qrows, s, rev, fault);
   // the three checkpoint geometries need exactly 4 / 13 / 17 key tiles (50 / 197 / 257 tokens): every tile but the last is full
 #define MCM_TR_EXACT(N, W, O) \
-  if (nt == N && !causal) return launch_tr<PREC, N, W, O, 0, false, N - 1>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm)
+  if (nt == N && !causal) return launch_tr<PREC, N, W, O, false, N - 1>(qkv, out, nseq, L, heads, false, qrows, s, rev, hm)
   MCM_TR_EXACT(4, 4, 3); MCM_TR_EXACT(13, 8, 3); MCM_TR_EXACT(17, 8, 3);
 #undef MCM_TR_EXACT
 #define MCM_TR(N, W, O) \
@@ -1195,10 +1088,11 @@ hipError_t launch_tr_by_tiles(const void* qkv, void* out, int nseq, int L, int h
 
 #ifdef MCM_HARNESS
 void attention_set_variant(int v) { g_attn_variant = v; }
+void attention_set_spin_budget(unsigned int polls) { g_ps_spin_budget = polls; }
 #endif
 
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse, int hm, bool split) {
+                            bool causal, int qrows, hipStream_t s, bool reverse, int hm, bool split, unsigned int* fault) {
   if (nseq <= 0 || L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if (qrows <= 0 || qrows > L) qrows = L;
   if (split) {  // split images in and out (GemmArgs::xsplit): fp16, bidirectional, row-major
@@ -1230,9 +1124,9 @@ hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int 
   }
 #endif
   if (prec == MCM_PREC_F16)
-    return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
+    return launch_tr_by_tiles<MCM_PREC_F16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm, fault);
   if (prec == MCM_PREC_BF16)
-    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm);
+    return launch_tr_by_tiles<MCM_PREC_BF16>(qkv, out, nseq, L, heads, causal, qrows, s, reverse ? 1 : 0, hm, fault);
   if (!causal) {  // the vision tower's form: fp32 MFMAs (attn_f32_mfma_kernel); the causal text tower keeps the VALU kernel
     const int nt = (L + 15) / 16;
 #define MCM_F32A(N, W) \

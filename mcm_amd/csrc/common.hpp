@@ -15,6 +15,20 @@ struct PerDeviceFlag {
   void set() { const int d = dev(); if (d >= 0) done[d] = true; }
 };
 
+// CUs of the CURRENT device, cached per device (a process may hold handles on several devices, and a partitioned or
+// CU-masked lease reports fewer than 256): the grid of every persistent kernel and the size policies that depend on it
+// (a process-wide static used the first device's count everywhere).  0 on error.
+inline int device_cu_count() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev < 64) cus[dev] = n;
+  return n;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -299,7 +313,8 @@ hipError_t launch_fold_stats(const float2* part, int slots, int M, int D, float 
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 8: see gemm.hip
-void attention_set_variant(int v);  // 1 = transpose-read kernel (the shipped one), 0 = round-1 kernel
+void attention_set_variant(int v);  // 1 = the shipped policy, 0 = round-1 kernel, 10 / 11 deals, 21 / 36 persistent / 8-wave form forced
+void attention_set_spin_budget(unsigned int polls);
 #endif
 
 // x_stride / y_stride: row strides in elements (0 = D, contiguous rows)
@@ -320,7 +335,8 @@ hipError_t launch_layernorm_pre(int prec, float* x, const float* g0, const float
 // modes only; `qkv` is then the base of the whole array and the launch covers sequences from row 0)
 // split: qkv [rows][6 D] and out [rows][2 D] are split images (fp16, not causal; attention.hip attn_tr_kernel<X2>)
 hipError_t launch_attention(int prec, const void* qkv, void* out, int nseq, int L, int heads,
-                            bool causal, int qrows, hipStream_t s, bool reverse = false, int hm = 0, bool split = false);
+                            bool causal, int qrows, hipStream_t s, bool reverse = false, int hm = 0, bool split = false,
+                            unsigned int* fault = nullptr);   // fault: the handle's host-mapped kernel-fault word (attn_ps_kernel)
 
 // split: the patch matrix as a split image [B*np, 2 kpad] (fp16; GemmArgs::xsplit)
 hipError_t launch_patchify(int prec, const float* pixels, void* patches, int B, int image,

@@ -1276,14 +1276,7 @@ int persistent_grid() {
 #ifdef MCM_HARNESS
   if (g_grid_override > 0) return g_grid_override;
 #endif
-  static int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      return 0;
-    return cus / 8 * 8;
-  }();
-  return n;
+  return device_cu_count() / 8 * 8;   // (cached per device, common.hpp)
 }
 
 template <int PREC, int EPI>

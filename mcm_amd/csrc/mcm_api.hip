@@ -10,6 +10,7 @@
 // and the reference's own tail utils/detection_util.py:226,231-248.
 // The residual stream is fp32 in HBM; vision GEMM operands are fp16 or bf16 (cfg.precision; exact fp32 in the
 // parity mode), the text tower always runs the exact-fp32 kernels.
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -96,6 +97,10 @@ struct mcm_handle {
   double flops[MCM_KC_COUNT] = {0};
   bool flip = false;  // walk direction of the next kernel (next_dir)
   unsigned int* sat_dev = nullptr;  // sticky fp16 saturation counter (common.hpp sat_report)
+  // sticky kernel-fault word: pinned host memory mapped into the device; a persistent kernel whose wait ran out of its budget
+  // stores 1 there (attention.hip attn_ps_kernel) and every later compute call on the handle returns MCM_EHIP (check_ready)
+  unsigned int* fault_pin = nullptr;
+  unsigned int* fault_dev = nullptr;
   bool sat_on = true;
   float2 *fold_part = nullptr, *fold_rs = nullptr;  // LayerNorm fold: row moments [v_width / 64][rows], (rstd, mean rstd) [rows]
   // LayerNorm in the tail of the residual GEMMs (gemm.hip): per-XCD regions of counters, all zero between launches;
@@ -280,7 +285,7 @@ hipError_t attn(mcm_handle* h, hipStream_t s, int prec, int nseq, int L, int hea
   if (split) return launch_attention(prec, h->qkv, h->att, nseq, L, heads, causal, qrows, s, next_dir(h), 0, true);
   const size_t es = prec_esize(prec), D = (size_t)heads * 64, row0 = (size_t)seq0 * L;
   return launch_attention(prec, (const char*)h->qkv + row0 * 3 * D * es, (char*)h->att + row0 * D * es, nseq, L,
-                          heads, causal, qrows, s, next_dir(h), hm);
+                          heads, causal, qrows, s, next_dir(h), hm, false, h->fault_dev);
 }
 // A/B arm (harness: mcm_debug_qkv_head_major): qkv of the 16-bit towers head-major ([3 heads][rows][64],
 // GemmArgs::hm) between the QKV projection and attention.  Bit-identical; attention 1.63 -> 1.56 ms per step, the QKV
@@ -529,6 +534,9 @@ int build_tower(mcm_handle* h, Tower& t, const std::string& tower, hipStream_t s
 int check_ready(mcm_handle* h) {
   if (!h) return MCM_EINVAL;
   if (!h->finalized) return fail(h, MCM_ENOWEIGHT, "mcm_finalize_weights has not been called");
+  if (h->fault_pin && *(volatile unsigned int*)h->fault_pin)
+    return fail(h, MCM_EHIP, "a persistent kernel of an earlier call gave up a wait that exceeded its poll budget (attn_ps_kernel): "
+                             "that call's results are invalid and the handle is unusable — mcm_kernel_faults");
   return MCM_OK;
 }
 
@@ -611,10 +619,14 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   // shared by both towers: vision rows in the operand dtype of cfg.precision, text rows in fp32
   // fp16 handles: the split-activation arm (mcm_score_x2) carries every such row as hi + lo — twice the width — and runs at the
   // same batch as the fp16 arm, so these buffers are allocated at twice the bytes (B/16, batch 512: +1.5 GB of the part's 288)
-  const int esw = es * (c.precision == MCM_PREC_F16 ? 2 : 1);
+  // cfg.x2_max_batch (ABI 4): 0 = the arm runs at the full batch (the buffers at twice the bytes), n > 0 = at most n images per
+  // x2 call (the buffers hold max(max_batch rows, 2 x the x2 rows)), < 0 = no split workspace at all
+  if (c.precision == MCM_PREC_F16 && c.x2_max_batch >= 0)
+    h->x2_batch = c.x2_max_batch == 0 || c.x2_max_batch > c.max_batch ? c.max_batch : c.x2_max_batch;
+  const int64_t mvx = ((int64_t)h->x2_batch * h->ntok + 255) / 256 * 256;   // token rows of the largest x2 batch (0: none)
   auto both = [&](int64_t vcols, int64_t tcols) {
-    const size_t a = (size_t)mv * vcols * esw, b = (size_t)mt * tcols * sizeof(float);
-    return a > b ? a : b;
+    const size_t a = (size_t)mv * vcols * es, ax = (size_t)mvx * vcols * es * 2, b = (size_t)mt * tcols * sizeof(float);
+    return std::max(std::max(a, ax), b);
   };
   const int64_t dmax = c.v_width > c.t_width ? c.v_width : c.t_width;
   const size_t xb = (size_t)h->max_rows * dmax * sizeof(float), lnb = both(c.v_width, c.t_width),
@@ -623,7 +635,6 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
   if (!rc) rc = dev_alloc(h, &h->ln, lnb);
   if (!rc) rc = dev_alloc(h, &h->qkv, qkvb);
   if (!rc) rc = dev_alloc(h, &h->att, attb);
-  if (c.precision == MCM_PREC_F16) h->x2_batch = c.max_batch;
   h->hbuf_bytes = both(c.v_mlp, c.t_mlp);
   if (!rc) rc = dev_alloc(h, &h->hbuf, h->hbuf_bytes);
   // zeroed once (a ragged vision batch zeroes its pad rows again: encode_image_impl, "Pad rows")
@@ -631,7 +642,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
               hipMemset(h->qkv, 0, qkvb) != hipSuccess || hipMemset(h->att, 0, attb) != hipSuccess ||
               hipMemset(h->hbuf, 0, h->hbuf_bytes) != hipSuccess))
     rc = fail(h, MCM_EHIP, "hipMemset of the activation workspace");
-  if (!rc) rc = dev_alloc(h, &h->patches, (size_t)c.max_batch * h->np * h->kpad * esw);
+  if (!rc) rc = dev_alloc(h, &h->patches, std::max((size_t)c.max_batch * h->np * h->kpad * es, (size_t)h->x2_batch * h->np * h->kpad * es * 2));
   if (!rc) rc = dev_alloc(h, (void**)&h->feat, (size_t)c.max_batch * c.proj_dim * sizeof(float));
   if (!rc) rc = dev_alloc(h, (void**)&h->ids_dev, (size_t)mt * sizeof(int32_t));
   if (!rc) rc = dev_alloc(h, (void**)&h->rowidx_dev, (size_t)mt * sizeof(int32_t));
@@ -658,6 +669,11 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
 #endif
   if (!rc) rc = dev_alloc(h, (void**)&h->sat_dev, 16);
   if (!rc && hipMemset(h->sat_dev, 0, 16) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset saturation counter");
+  if (!rc && hipHostMalloc((void**)&h->fault_pin, 64, hipHostMallocMapped) != hipSuccess) rc = fail(h, MCM_ENOMEM, "hipHostMalloc fault word");
+  if (!rc) {
+    memset(h->fault_pin, 0, 64);
+    if (hipHostGetDevicePointer((void**)&h->fault_dev, h->fault_pin, 0) != hipSuccess) rc = fail(h, MCM_EHIP, "hipHostGetDevicePointer fault word");
+  }
   if (!rc && hipHostMalloc((void**)&h->prep_pin, (size_t)mcm_handle::PREP_RING * c.max_batch * sizeof(PrepImage)) != hipSuccess)
     rc = fail(h, MCM_ENOMEM, "hipHostMalloc prep");
   for (int k = 0; !rc && k < mcm_handle::PREP_RING; ++k)
@@ -678,6 +694,7 @@ void mcm_destroy(mcm_handle* h) {
   if (h->ids_pin) (void)hipHostFree(h->ids_pin);
   if (h->rowidx_pin) (void)hipHostFree(h->rowidx_pin);
   if (h->prep_pin) (void)hipHostFree(h->prep_pin);
+  if (h->fault_pin) (void)hipHostFree(h->fault_pin);
   if (h->jpg_pin) (void)hipHostFree(h->jpg_pin);
   if (h->jpg_planes) (void)hipFree(h->jpg_planes);
   for (auto& e : h->jpg_ev)
@@ -809,7 +826,7 @@ int encode_image_impl(mcm_handle* h, const void* pixels_dev, bool u8, int32_t B,
   int rc = check_ready(h);
   if (rc) return rc;
   if (!pixels_dev || !out_dev) return fail(h, MCM_EINVAL, "null pointer");
-  if (x2 && h->x2_batch <= 0) return fail(h, MCM_EINVAL, "the split-activation arm needs an fp16 handle");
+  if (x2 && h->x2_batch <= 0) return fail(h, MCM_EINVAL, "the split-activation arm needs an fp16 handle created with a split-activation workspace (cfg.x2_max_batch >= 0)");
   if (B <= 0 || B > (x2 ? h->x2_batch : h->cfg.max_batch))
     return fail(h, MCM_ERANGE, x2 ? "batch exceeds mcm_x2_max_batch" : "batch exceeds cfg.max_batch");
   hipStream_t s = (hipStream_t)stream;
@@ -892,6 +909,8 @@ int mcm_encode_image_ex(mcm_handle* h, const void* pixels_dev, int32_t pixel_for
 }
 
 int mcm_x2_max_batch(const mcm_handle* h) { return h ? h->x2_batch : 0; }
+
+int mcm_kernel_faults(const mcm_handle* h) { return h && h->fault_pin ? (int)*(volatile unsigned int*)h->fault_pin : 0; }
 
 int mcm_encode_image_x2(mcm_handle* h, const void* pixels_dev, int32_t pixel_format, int32_t B, int32_t normalize,
                         float* out_dev, void* stream) {
@@ -1307,14 +1326,30 @@ int mcm_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out
                      int32_t seq_len, int32_t heads, int32_t causal, void* stream) {
   if (!h) return MCM_EINVAL;
   HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, 0,
-                              (hipStream_t)stream));
+                              (hipStream_t)stream, false, 0, false, h->fault_dev));
   return MCM_OK;
 }
 
 #ifdef MCM_HARNESS  // libmcm_hip_harness.so only: process-wide A/B switches for tests and tools
 int mcm_debug_attention_variant(int32_t variant) {
-  if (variant < 0 || variant > 40) return MCM_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 21 && variant != 36) return MCM_EINVAL;
   attention_set_variant(variant);
+  return MCM_OK;
+}
+
+// polls a wait of the persistent attention kernel may take before it gives up (attention.hip PS_SPIN_BUDGET = 1 << 22 is what
+// the shipped library always passes); 0 = every wait that has to wait gives up at once: the test of the fault path
+int mcm_debug_attn_spin_budget(int64_t polls) {
+  if (polls < 0 || polls > 0xffffffffLL) return MCM_EINVAL;
+  attention_set_spin_budget((unsigned int)polls);
+  return MCM_OK;
+}
+
+// clears the handle's sticky kernel-fault word (tests of the fault path only: a real fault leaves results invalid)
+int mcm_debug_clear_faults(mcm_handle* h) {
+  if (!h || !h->fault_pin) return MCM_EINVAL;
+  (void)hipDeviceSynchronize();
+  *(volatile unsigned int*)h->fault_pin = 0u;
   return MCM_OK;
 }
 
@@ -1323,7 +1358,8 @@ int mcm_debug_attention_variant(int32_t variant) {
 int mcm_debug_op_attention(mcm_handle* h, int32_t prec, const void* qkv_dev, void* out_dev, int32_t nseq, int32_t seq_len,
                            int32_t heads, int32_t causal, int32_t qrows, int32_t reverse, void* stream) {
   if (!h) return MCM_EINVAL;
-  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, qrows, (hipStream_t)stream, reverse != 0));
+  HIP_TRY(h, launch_attention(prec, qkv_dev, out_dev, nseq, seq_len, heads, causal != 0, qrows, (hipStream_t)stream, reverse != 0, 0, false,
+                              h->fault_dev));
   return MCM_OK;
 }
 

@@ -48,7 +48,15 @@ def init_from_env(backend: str | None = None, force: bool = False) -> Tuple[int,
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            if ws == 1:   # a forced 1-rank group: nobody else has to know the port — take a free one (two such processes on one
+                import socket   # host used to collide on a fixed default)
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            else:         # ws > 1 without a launcher-provided port: every rank must agree, so a fixed default it is
+                os.environ["MASTER_PORT"] = "29511"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

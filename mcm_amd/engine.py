@@ -86,11 +86,15 @@ def load_library(harness: bool = False):
     L.mcm_op_attention_split.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.mcm_x2_max_batch.argtypes = [vp]
     L.mcm_x2_max_batch.restype = i32
+    L.mcm_kernel_faults.argtypes = [vp]
+    L.mcm_kernel_faults.restype = i32
     L.mcm_encode_image_x2.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.mcm_score_x2.argtypes = [vp, vp, i32, i32, vp, i32, f32, i32, vp, vp]
     if harness:
         L.mcm_debug_gemm_variant.argtypes = [i32]
         L.mcm_debug_attention_variant.argtypes = [i32]
+        L.mcm_debug_attn_spin_budget.argtypes = [ctypes.c_int64]
+        L.mcm_debug_clear_faults.argtypes = [vp]
         L.mcm_debug_qkv_chunks.argtypes = [i32]
         L.mcm_debug_ln_fold.argtypes = [i32]
         L.mcm_debug_qkv_head_major.argtypes = [i32]
@@ -149,12 +153,14 @@ EXPORTED_SYMBOLS = [
     "mcm_weights_operand_exact", "mcm_op_linear_ex", "mcm_op_split_weight", "mcm_pack_u8",
     "mcm_jpeg_entropy_decode", "mcm_jpeg_reconstruct",
     "mcm_x2_max_batch", "mcm_encode_image_x2", "mcm_score_x2", "mcm_op_layernorm_split", "mcm_op_attention_split",
+    "mcm_kernel_faults",
 ]
 HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant", "mcm_debug_qkv_chunks",
                         "mcm_debug_gemm_dbg", "mcm_debug_ln_fold", "mcm_debug_qkv_head_major",
                         "mcm_debug_ln_tail", "mcm_debug_ln_tail_timeouts", "mcm_debug_nsplit",
                         "mcm_debug_gemm_group_n", "mcm_debug_patch_fold", "mcm_debug_resize_fused_only",
-                        "mcm_debug_persistent_grid", "mcm_debug_op_attention"]
+                        "mcm_debug_persistent_grid", "mcm_debug_op_attention", "mcm_debug_attn_spin_budget",
+                        "mcm_debug_clear_faults"]
 
 
 def _stream_ptr():
@@ -169,7 +175,7 @@ class NativeCLIP:
     def __init__(self, geo: ClipGeometry | str, state_dict: Dict[str, np.ndarray], *,
                  device: int = 0, precision: str = "fp16", max_batch: int = 512,
                  max_prompt_tokens: int = 1024 * 77, synthetic_weights: Optional[bool] = None,
-                 harness: bool = False, weight_operands: str = "auto"):
+                 harness: bool = False, weight_operands: str = "auto", x2_max_batch: Optional[int] = None):
         import torch
 
         if not torch.cuda.is_available():
@@ -192,7 +198,11 @@ class NativeCLIP:
         # weight IS a number of that dtype (the reference's fp16-trained checkpoints), W_hi + W_lo otherwise
         self._cfg = self.geo.to_c(device=device, precision=self.precision, max_batch=max_batch,
                                   max_prompt_tokens=max_prompt_tokens,
-                                  weight_operands=WEIGHT_OPERANDS[weight_operands])
+                                  weight_operands=WEIGHT_OPERANDS[weight_operands],
+                                  # the split-activation workspace (fp16 handles; include/mcm.h mcm_config.x2_max_batch): None /
+                                  # 0 = the arm runs at the full batch (twice the activation bytes), n = at most n images per
+                                  # x2 call (free up to max_batch / 2), < 0 = none
+                                  x2_max_batch=int(x2_max_batch or 0))
         self._h = ctypes.c_void_p()
         rc = self._lib.mcm_create(ctypes.byref(self._cfg), ctypes.byref(self._h))
         if rc:
@@ -362,8 +372,13 @@ class NativeCLIP:
     # -- split-activation arm: the re-scorer of threshold refinement (include/mcm.h mcm_score_x2) ----------------------
     @property
     def x2_max_batch(self) -> int:
-        """Largest batch of the split-activation arm on this handle's workspace (0: not an fp16 handle)."""
+        """Largest batch of the split-activation arm on this handle's workspace (0: not an fp16 handle, or created without it)."""
         return int(self._lib.mcm_x2_max_batch(self._h))
+
+    @property
+    def kernel_faults(self) -> int:
+        """Non-zero when a persistent kernel gave up a bounded wait (include/mcm.h mcm_kernel_faults): 0 in every correct run."""
+        return int(self._lib.mcm_kernel_faults(self._h))
 
     def score_images_x2(self, pixel_values, text_features, T: float = 1.0, score: str = "MCM", out=None):
         """`score_images` through the split-activation arm: the same weights and workspace, every MFMA operand activation as a

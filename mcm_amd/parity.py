@@ -169,7 +169,10 @@ def measure_drift(ckpt: str = "ViT-B/16", *, K: int = 1000, n_id: int = 50000, n
                                                    lambda name, idx, first=first: scores[first][name][idx],
                                                    rescore_exact=(lambda name, idx: scores[ref][name][idx])
                                                    if (kind == "refine2" and first != ref) else None)
-                refine_stats[a] = dict(st, rescorer=first)
+                # what the refinement's argument assumes of the images it did NOT calibrate on, measured on every image of every
+                # set: the largest |re-scorer - base arm| score difference (mcm_amd/refine.py: delta = margin x the calibration max)
+                noise_all = max(float((scores[first][t] - scores[b][t]).abs().max()) for t in tags)
+                refine_stats[a] = dict(st, rescorer=first, noise_all_max_abs=noise_all, calibration_bound_held=bool(noise_all <= st["delta"]))
             names = names + derived
         out = {"ckpt": ckpt, "K": K, "n_id": n_id, "n_ood": n_ood if not ood_sets else {n: c for n, c, _ in sets},
                "batch": batch, "score": score, "T": T, "reference_arm": ref,

@@ -525,6 +525,45 @@ def test_attention_persistent_form_bitwise(harness_net, nseq, L, heads, qrows, p
         np.testing.assert_allclose(outs[(21, 0)].float().cpu().numpy(), want, rtol=tol, atol=tol)
 
 
+def test_attention_persistent_form_waits_are_bounded(harness_net):
+    """every wait of the persistent attention kernel is bounded.  With the poll budget forced to 0 (harness
+    switch) the compute waves' very first wait for a job gives up: the launch ENDS (no hang), the handle's sticky fault word is
+    set, every later compute call returns MCM_EHIP and says why; with the word cleared and the shipped budget restored the same
+    launch is bit-identical to the 8-wave kernel again and reports no fault."""
+    lib, h = harness_net._lib, harness_net._h
+    nseq, L, heads = 43, 197, 12
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = (torch.randn((nseq * L, 3 * D), device="cuda", generator=g) * 1.4).to(torch.float16)
+
+    def run(variant):
+        assert lib.mcm_debug_attention_variant(variant) == 0
+        out = torch.zeros((nseq * L, D), device="cuda", dtype=torch.float16)
+        rc = lib.mcm_debug_op_attention(h, PREC["fp16"], _ptr(qkv), _ptr(out), nseq, L, heads, 0, 0, 0, None)
+        assert rc == 0, lib.mcm_last_error(h)
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        assert lib.mcm_kernel_faults(h) == 0
+        want = run(36)
+        assert lib.mcm_debug_attn_spin_budget(0) == 0
+        run(21)                                  # returns: the kernel gave up instead of waiting
+        assert lib.mcm_kernel_faults(h) != 0
+        px = torch.zeros((1, 3, harness_net.geo.image_size, harness_net.geo.image_size), device="cuda")
+        with pytest.raises(RuntimeError, match="gave up a wait"):
+            harness_net.get_image_features(pixel_values=px)
+        assert lib.mcm_debug_attn_spin_budget(1 << 22) == 0
+        assert lib.mcm_debug_clear_faults(h) == 0 and lib.mcm_kernel_faults(h) == 0
+        got = run(21)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)) and lib.mcm_kernel_faults(h) == 0
+        harness_net.get_image_features(pixel_values=px)   # the handle works again
+    finally:
+        lib.mcm_debug_attn_spin_budget(1 << 22)
+        lib.mcm_debug_clear_faults(h)
+        lib.mcm_debug_attention_variant(1)
+
+
 def test_attention_full_size_bitwise_repeatable(tiny_net):
     """B/16 batch 512 (6144 workgroups, 3 per CU): three launches bit-identical, and equal to the same
     sequences run as a small launch (a timing-dependent fault shows up as a differing workgroup)."""
@@ -546,6 +585,7 @@ def test_attention_full_size_bitwise_repeatable(tiny_net):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(small, outs[0][100 * L:107 * L])
+    assert tiny_net.kernel_faults == 0   # the persistent form's bounded waits never ran out (include/mcm.h mcm_kernel_faults)
 
 
 @pytest.mark.parametrize("epi", [0, 1])

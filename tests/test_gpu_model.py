@@ -251,6 +251,8 @@ def test_full_size_properties(b16):
     # max-logit is the plain cosine: bounded by 1 and equal to the max of f @ txt.T
     ml = b16.score_features(f, txt, 1.0, "max-logit")
     torch.testing.assert_close(-ml, (f @ txt.T).max(dim=1).values, rtol=1e-5, atol=1e-6)
+    torch.cuda.synchronize()
+    assert b16.kernel_faults == 0   # full-size runs through the persistent attention kernel: no wait ran out of its budget
 
 
 def test_full_size_bf16_vs_oracle_small_sample(b16):

@@ -290,3 +290,37 @@ def test_split_arm_edge_batches():
     finally:
         n16.close()
         n32.close()
+
+
+def test_x2_workspace_is_sized_by_the_caller():
+    """mcm_config.x2_max_batch (ABI 4): 0 = the arm at the full batch, n = at most n images per call (same scores, in
+    chunks), < 0 = no split-activation workspace — those calls are refused, the fp16 arm is untouched."""
+    from mcm_amd.config import geometry
+    from mcm_amd.engine import NativeCLIP
+    from mcm_amd.synth import make_pixels, make_token_ids
+    from mcm_amd.weights import synth_state_dict
+
+    geo = geometry("B16-2L")
+    sd = synth_state_dict(geo, 0, "fp16-exact")
+    ids, _ = make_token_ids(7, seed=2)
+    px = torch.from_numpy(make_pixels(10, geo.image_size, 7, ood=False, seed=3)[0]).cuda()
+    out = {}
+    for name, x2 in (("full", None), ("three", 3), ("none", -1)):
+        n = NativeCLIP(geo, sd, precision="fp16", max_batch=10, max_prompt_tokens=1024, x2_max_batch=x2)
+        try:
+            txt = n.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+            assert n.x2_max_batch == {"full": 10, "three": 3, "none": 0}[name]
+            out[name] = n.score_images(px, txt).clone()
+            if name == "none":
+                with pytest.raises(RuntimeError):
+                    n.score_images_x2(px, txt)
+                rc = n._lib.mcm_score_x2(n._h, px.data_ptr(), 0, 2, txt.data_ptr(), txt.shape[0], 1.0, 0, out[name].data_ptr(), None)
+                assert rc != 0 and b"fp16 handle" in n._lib.mcm_last_error(n._h)
+            else:
+                out[name + "_x2"] = n.score_images_x2(px, txt).clone()
+            torch.cuda.synchronize()
+            assert n.kernel_faults == 0
+        finally:
+            n.close()
+    assert torch.equal(out["full"], out["three"]) and torch.equal(out["full"], out["none"])      # the fp16 arm: same bits
+    assert torch.equal(out["full_x2"], out["three_x2"])                                            # the split arm: chunked = whole

@@ -86,24 +86,88 @@ def live_pmc_traffic(args):
     return fam, per, "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 3 steps each"
 
 
-class SmiSampler(threading.Thread):
-    """sclk (MHz) and package power (W) of device 0 every `period` s through rocm-smi."""
+def physical_gpu_index(local):
+    """Index rocm-smi / sysfs know device ordinal `local` of this process by: the launcher may have narrowed the visible set."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                ids = [int(x) for x in v.split(",") if x.strip() != ""]
+                if local < len(ids):
+                    return ids[local]
+            except ValueError:
+                pass
+    return local
 
-    def __init__(self, period=0.5):
+
+def _sysfs_card(local):
+    """/sys/class/drm/cardN/device of device ordinal `local`, matched by PCI address (torch reports it); None when the
+    container does not show amdgpu's sysfs or the address cannot be matched."""
+    import glob
+
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(local)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if os.path.basename(os.path.realpath(dev)).lower().startswith(want) and os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                return dev
+        except OSError:
+            pass
+    return None
+
+
+class SmiSampler(threading.Thread):
+    """sclk (MHz) and package power (W) of ONE device every `period` s: amdgpu's sysfs files when the container shows them
+    (pp_dpm_sclk's starred level, hwmon power1_average / power1_input: no subprocess — every rank of an N-GPU run samples its
+    own GPU), else `rocm-smi -d <index>`.  `device` = this process's device ordinal."""
+
+    def __init__(self, period=0.5, device=0):
         super().__init__(daemon=True)
         self.period, self.samples, self._stop_evt = period, [], threading.Event()
+        self.device = int(device)
+        self.card = _sysfs_card(self.device)
+        self.index = physical_gpu_index(self.device)
+        self.source = "sysfs " + os.path.realpath(self.card) if self.card else f"rocm-smi -d {self.index}"
 
-    def run(self):
+    def _read_sysfs(self):
+        import glob
         import re
 
+        clk = re.search(r"(\d+)\s*Mhz\s*\*", open(os.path.join(self.card, "pp_dpm_sclk")).read(), re.I)
+        for f in sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "power1_average")) +
+                        glob.glob(os.path.join(self.card, "hwmon", "hwmon*", "power1_input"))):
+            try:
+                uw = float(open(f).read().strip())
+            except (OSError, ValueError):
+                continue
+            if clk and uw > 0:
+                return int(clk.group(1)), uw * 1e-6
+        return None
+
+    def _read_smi(self):
+        import re
+
+        out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True,
+                             timeout=5).stdout
+        clk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
+        pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        return (int(clk.group(1)), float(pw.group(1))) if clk and pw else None
+
+    def run(self):
         while not self._stop_evt.is_set():
             try:
-                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
-                                     timeout=5).stdout
-                clk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
-                pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
-                if clk and pw:
-                    self.samples.append((int(clk.group(1)), float(pw.group(1))))
+                got = self._read_sysfs() if self.card else None
+                if got is None:
+                    if self.card:   # the files are there but unreadable / empty: fall back for good
+                        self.card, self.source = None, f"rocm-smi -d {self.index}"
+                    got = self._read_smi()
+                if got:
+                    self.samples.append(got)
             except Exception:
                 pass
             self._stop_evt.wait(self.period)
@@ -112,11 +176,10 @@ class SmiSampler(threading.Thread):
         self._stop_evt.set()
         self.join(timeout=10)
         busy = [s for s in self.samples if s[1] > 300]
-        if not busy:
-            return {"samples": len(self.samples), "busy_samples": 0}
-        return {"samples": len(self.samples), "busy_samples": len(busy),
-                "sclk_mhz_mean": sum(s[0] for s in busy) / len(busy),
-                "power_w_mean": sum(s[1] for s in busy) / len(busy)}
+        out = {"samples": len(self.samples), "busy_samples": len(busy), "source": self.source}
+        if busy:
+            out.update(sclk_mhz_mean=sum(s[0] for s in busy) / len(busy), power_w_mean=sum(s[1] for s in busy) / len(busy))
+        return out
 
 
 def cpu_baseline(geo, sd, ids, mask, K, px_batches, max_seconds, native_first):
@@ -401,8 +464,8 @@ def ingest_legs(net, txt, B, steps, which):
     return out
 
 
-def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3, x2=False):
-    """Throughput of one more arm on the same workload, 3 timed steps after one warm-up step, outside the timed region
+def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=10, x2=False):
+    """Throughput of one more arm on the same workload, `steps` timed steps after two warm-up steps, outside the timed region
     of the headline number: (images/s, GEMM-family TFLOP/s by HIP events, fraction of that dtype's dense MFMA peak)."""
     import torch
 
@@ -414,6 +477,7 @@ def arm_leg(geo, sd, precision, weight_operands, B, K, ids, px, device, steps=3,
         txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
         out = torch.empty(B, device=px.device)
         run = net.score_images_x2 if x2 else net.score_images   # x2: the split-activation arm (chunks of mcm_x2_max_batch)
+        run(px, txt, 1.0, "MCM", out=out)
         run(px, txt, 1.0, "MCM", out=out)
         net.profile(True)
         net.profile_read()
@@ -567,10 +631,12 @@ def refined_leg(net, geo, sd, txt, ids, mask, B, K, device, two_level=True):
         torch.cuda.empty_cache()
 
 
-def config_legs(device, steps=3):
-    """BASELINE configs 4 and 2 on this device, 3 timed steps each after one warm-up step (like `arms`): ViT-L/14 fp16 batch 256
-    K = 1000 (config 4's per-GPU work) and ViT-B/16 K = 100 batch 512 in bf16 (the dtype config 2 names) and fp16; plus
-    configs 4 and 3 at the nearest full-round batch (255, 665)."""
+def config_legs(device, steps=12):
+    """BASELINE configs 4 and 2 on this device, `steps` timed steps each after two warm-up steps (like `arms`; 12 since round 6 —
+    3 steps could not carry a 2 % claim): ViT-L/14 fp16 batch 256 K = 1000 (config 4's per-GPU work) and
+    ViT-B/16 K = 100 batch 512 in bf16 (the dtype config 2 names) and fp16; plus configs 4 and 3 at the nearest full-round batch
+    (255, 665) NEXT TO the same work at BASELINE's batch measured by the same leg (c3_B16_fp16_b512: the control of the
+    full-round-batch claim, EXPERIMENTS.md R5.11 / R6)."""
     import torch
 
     from mcm_amd.config import geometry
@@ -584,6 +650,7 @@ def config_legs(device, steps=3):
                                    # the same work at a batch whose GEMMs fill every tile round (ClipGeometry.full_round_batches,
                                    # EXPERIMENTS.md R5.11): what a caller free to choose its batch gets per image
                                    ("c4_L14_fp16_b255", "ViT-L/14", "fp16", 255, 1000),
+                                   ("c3_B16_fp16_b512", "ViT-B/16", "fp16", 512, 1000),
                                    ("c3_B16_fp16_b665", "ViT-B/16", "fp16", 665, 1000)):
         try:
             geo = geometry(ckpt)
