@@ -34,7 +34,7 @@ OOD_LAYOUT = {"iNaturalist": ("iNaturalist",), "SUN": ("SUN",), "places365": ("P
 
 def clip_layout_vocab():
     """vocab.json / merges.txt with CLIP's id layout, the merges learned from test_tokenizer_bpe's corpus."""
-    from test_tokenizer_bpe import train_bpe
+    from tests.test_tokenizer_bpe import train_bpe
 
     small, merges = train_bpe(400)
     toks = [t for t, _ in sorted(small.items(), key=lambda kv: kv[1]) if not t.startswith("<|")]
@@ -47,7 +47,7 @@ def clip_layout_vocab():
 
 
 def class_names_100():
-    from test_tokenizer_bpe import CORPUS
+    from tests.test_tokenizer_bpe import CORPUS
 
     words = sorted({w for w in CORPUS.lower().split() if w.isalpha() and len(w) > 2})
     names = []
