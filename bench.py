@@ -52,7 +52,7 @@ DEFAULT_PRECISION = "fp16"  # the 16-bit mode that holds AUROC/FPR95 to the fp32
 LINE_LIMIT = 4096           # bytes of the printed line (a 33.6 KB line left the driver with parsed = null)
 # harness A/B switches (libmcm_hip_harness.so, mcm_debug_*): `--harness gemm_variant=3,ln_tail=1`; never the shipped policy
 HARNESS_KEYS = {"gemm_variant": "mcm_debug_gemm_variant", "attn_variant": "mcm_debug_attention_variant",
-                "ln_fold": "mcm_debug_ln_fold", "ln_tail": "mcm_debug_ln_tail", "patch_fold": "mcm_debug_patch_fold",
+                "ln_fold": "mcm_debug_ln_fold", "ln_tail": "mcm_debug_ln_tail", "ln_cluster": "mcm_debug_ln_cluster", "patch_fold": "mcm_debug_patch_fold",
                 "group_n": "mcm_debug_gemm_group_n", "nsplit": "mcm_debug_nsplit", "qkv_chunks": "mcm_debug_qkv_chunks",
                 "gemm_dbg": "mcm_debug_gemm_dbg"}
 

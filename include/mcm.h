@@ -465,6 +465,13 @@ int mcm_debug_qkv_head_major(int32_t on);
  * GEMM's kernel by the waves that have run out of tiles (same bits as the LayerNorm launch); 0 (default, shipped) =
  * every LayerNorm is its own launch.  Measured equal at ViT-B/16 batch 512, slower on smaller problems, DESIGN.md 5.5. */
 int mcm_debug_ln_tail(int32_t on);
+/* A/B (round 6): 1 = the LayerNorm behind a whole-batch out-proj / fc2 of a 16-bit vision tower is written by that GEMM's own
+ * EPILOGUE from the accumulator registers: the N / 256 workgroups that hold the tiles of one 256-row panel act as one
+ * full-row tile — row moments exchanged through an XCD's L2, no re-read of the residual stream, no LayerNorm launch
+ * (gemm_arms.hpp "LNC"; the full-row epilogue of VERDICT r5 item 2).  Scores agree with the shipped path to fp32 round-off
+ * (Chan-combined slot moments instead of whole-row two-pass statistics), not bit for bit.  0 (default) = shipped behaviour.
+ * Waits that gave up are counted by mcm_debug_ln_tail_timeouts. */
+int mcm_debug_ln_cluster(int32_t on);
 /* Tickets of the LayerNorm tail that gave up waiting for their rows (a bounded spin: wrong rows rather than a hung
  * device); 0 in a correct run.  Synchronises the device. */
 int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host);

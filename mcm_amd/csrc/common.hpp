@@ -278,6 +278,12 @@ struct GemmArgs {
   float ln_eps;
   unsigned int* ln_state;  // 8 regions (one per XCD) of ln_rs words: [ln_cap8] row-tile counters, tickets, finished
   int ln_rs, ln_cap8;      //   workgroups, timeouts; all zero between launches (the kernel leaves it so)
+  // LayerNorm by the row panel's CLUSTER (round 6 arm, gemm_arms.hpp "LNC"; needs ln_g / ln_b / ln_y / ln_state and fold_part):
+  // 1 = the N / 256 workgroups that hold the tiles of one 256-row panel act as ONE full-row tile — each keeps its new residual
+  // values in the accumulator registers, publishes its 64-column row moments (fold_part), waits for the panel's other
+  // workgroups through a counter in ln_state, combines the N / 64 slot moments of its rows and writes the LayerNorm output
+  // from registers: no LayerNorm launch and no re-read of the residual stream.  0 = off (the shipped library never sets it).
+  int lnc;
 };
 // head-major rows of a 16-bit output as the kernels see them: the shipped library never sets GemmArgs::hm (an A/B arm of
 // the harness library), so outside -DMCM_HARNESS builds the layout tests fold away at compile time

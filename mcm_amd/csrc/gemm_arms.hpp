@@ -723,6 +723,226 @@ __device__ __forceinline__ void ln_finish(const GemmArgs& a, int xcd, char* smem
   }
 }
 
+// =========================================================================================
+// LayerNorm by the row panel's cluster (LNC; round 6; EPI_RESID, 16-bit operand modes, N = 768 / 1024).
+// VERDICT r5 item 2 asked for the one design that removes LayerNorm's own re-read of the residual stream: a FULL-ROW
+// (BN = N) residual-GEMM epilogue that emits the LayerNorm output from registers.  A 256 x 768 register tile does not
+// exist on this part (384 KB of accumulators per CU; a 64- or 128-row full-row tile re-stages all of W per 64 / 128
+// rows and no longer double-buffers: EXPERIMENTS.md R6.2), but the full-row TILE does — spread over the N / 256
+// workgroups that hold the tiles of one 256-row panel.  They sit on ONE XCD (row tile = mt * 8 + xcd) and are walked
+// n-fastest, i.e. by consecutive workgroups of the same round, so they finish within a few microseconds of each other.
+// The K loop is untouched; the epilogue of a wave (128 rows x 64 columns) becomes
+//   A  as the plain residual form: bounce, (acc + bias) + resid, store x — and the new values STAY in the accumulator
+//      registers (bounced layout); per row the 64-column moments (sum, centred sum of squares: slot_moments, the fold's)
+//      go to fold_part[column / 64][row];
+//   B  publish: vmcnt(0), one L2 atomic on the counter of (row panel, upper / lower 128 rows) — the two halves are
+//      waves 0-3 / 4-7 of every workgroup, whose epilogues run in DIFFERENT phases of the ping-pong schedule, so a
+//      half waits only for the same half of its partner workgroups (12 waves at N = 768) — then poll that counter
+//      (bounded: a lost partner costs wrong rows and a counted timeout, not a hung GPU), buffer_inv sc1;
+//   C  lane L merges the N / 64 slot moments of rows 2L, 2L + 1 slot by slot (Chan et al.) into (mean, rstd) and parks
+//      them in the wave's LDS window;
+//   D  LayerNorm from registers: ((v - mean) rstd) gamma + beta (ln_row.hpp's ln_scale arithmetic), packed, stored.
+// Nothing re-reads x; 23 LayerNorm launches disappear.  Deadlock-free: every workgroup of the grid is resident, a wave
+// publishes BEFORE it waits, workgroups take their tiles in list order, and a wave's partners hold tiles at most two list
+// positions away — by induction over the list the earliest waiting tile's partners are never blocked before they publish.
+// Statistics: slot-wise two-pass moments combined by Chan's formula — as accurate as the LayerNorm kernel's two-pass
+// row statistics, not bit-identical to them (the summation order differs): an A/B arm, compared at fp32 round-off.
+// ln_state per XCD: [ln_cap8] counters (index row-panel * 2 + half), +1 finished workgroups, +2 timeouts.
+// =========================================================================================
+// Kernel arguments that only the LNC epilogue reads, fetched from the kernarg segment INSIDE the epilogue (scalar loads
+// from inline asm): as ordinary uses of `a` hipcc loads them at kernel entry and keeps 20 more scalar registers live across
+// the K loop, whose spills to VGPR lanes push the loop's fragment offsets to scratch — and a scratch reload in the compute
+// phase comes with a vmcnt(0) that drains the LDS-DMA stream (ISA-audited: tests/test_isa_audit.py).
+template <typename T, int OFF>
+__device__ __forceinline__ T karg() {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "a scalar or a pointer");
+  const void* kp = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (sizeof(T) == 8) {
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(kp), "n"(OFF) : "memory");
+    return __builtin_bit_cast(T, v);
+  } else {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(kp), "n"(OFF) : "memory");
+    return __builtin_bit_cast(T, v);
+  }
+}
+#define LNC_ARG(field) karg<decltype(GemmArgs::field), (int)offsetof(GemmArgs, field)>()
+struct LncArgs {   // the epilogue's own copy of what it needs of GemmArgs
+  const float *bias, *ln_g, *ln_b;
+  float* resid;
+  void* ln_y;
+  float2* fold_part;
+  float ln_eps;
+  int M, N, ldo, ln_cap8;
+};
+__device__ __forceinline__ LncArgs lnc_args() {
+  LncArgs r;
+  r.bias = LNC_ARG(bias); r.ln_g = LNC_ARG(ln_g); r.ln_b = LNC_ARG(ln_b); r.resid = LNC_ARG(resid); r.ln_y = LNC_ARG(ln_y);
+  r.fold_part = LNC_ARG(fold_part); r.ln_eps = LNC_ARG(ln_eps); r.M = LNC_ARG(M); r.N = LNC_ARG(N); r.ldo = LNC_ARG(ldo);
+  r.ln_cap8 = LNC_ARG(ln_cap8);
+  return r;
+}
+template <int PREC, int NS>
+__device__ __forceinline__ void lnc_row_stats(const LncArgs& a, int mw, int lane, char* scratch) {
+  // rows mw + 2 lane, + 1: the (sum, m2) pairs of the N / 64 slots, 16 bytes per lane and slot, merged slot by slot in slot
+  // order (Chan et al.: n, mean, M2 of the union of two sets) — four slots in flight at a time: the 128 accumulator registers
+  // are live, a row's 16 slot records at once would spill
+  const char* pb = (const char*)(a.fold_part + mw);
+  float n = 0.f, m0 = 0.f, q0 = 0.f, m1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int j0 = 0; j0 < NS; j0 += 4) {
+    f32x4_t p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gload16(p[j], pb + (size_t)(j0 + j) * a.M * 8, (uint32_t)lane * 16u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(p[j]));
+      const float w = 64.0f / (n + 64.0f);          // weight of the new slot in the union
+      const float d0 = p[j][0] * (1.0f / 64.0f) - m0, d1 = p[j][2] * (1.0f / 64.0f) - m1;
+      q0 += p[j][1] + d0 * d0 * (n * w);
+      q1 += p[j][3] + d1 * d1 * (n * w);
+      m0 += d0 * w;
+      m1 += d1 * w;
+      n += 64.0f;
+    }
+  }
+  const f32x4_t st = {m0, 1.0f / sqrtf(q0 / n + a.ln_eps), m1, 1.0f / sqrtf(q1 / n + a.ln_eps)};
+  *(f32x4_t*)(scratch + lane * 16) = st;   // row r of the wave's 128: (mean, rstd) at scratch + 8 r
+}
+template <int PREC, int MF>
+__device__ __forceinline__ void wave_epilogue_resid_lnc(f32x4_t (&acc)[4][MF], int mw, int nw, int lane,
+                                                        char* scratch, float& amax, const unsigned int* reg, uint32_t ctr_off,
+                                                        uint32_t need) {
+  static_assert(MF == 8, "the wait counts below are written out for 8 chunks");
+  const LncArgs a = lnc_args();
+  const int fr = lane & 15, g = lane >> 4;
+  const int rrow = lane >> 4, c16 = lane & 15;
+  const uint32_t voff = (uint32_t)(rrow * a.ldo + c16 * 4) * 4u;  // bytes, fp32 rows
+  // rows are visited in order, 4 at a time: a load pointer and a store pointer walk down the tile by one scalar add each
+  // (per-row-group bases computed up front cost 64 scalar registers and push loop state into VGPR lanes: gemm.hip)
+  const size_t step = (size_t)a.ldo * 16;  // bytes per 4 fp32 rows
+  const char* lp = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
+  const char* sp = lp;
+  const char* pbase = (const char*)(a.fold_part + (size_t)(nw >> 6) * a.M + mw);
+  const uint32_t poff = (uint32_t)(((c16 >> 2) * 16 + (c16 & 3) * 4 + rrow) * 8);
+  // ---- A: the plain residual form; the new rows stay in `acc` (bounced layout: acc[t][c] = rows c*16 + t*4 + rrow,
+  // columns c16*4 .. +3), their slot moments leave for fold_part.  Queue at the wait of chunk c, oldest first:
+  // [loads c] [stores c-1: 4 x (+ 1 moments after chunks 3 and 7)] [loads c+1]
+  f32x4_t bia;
+  gload16(bia, a.bias + nw, (uint32_t)c16 * 16u);
+  f32x4_t buf[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    gload16(buf[0][t], lp, voff);
+    lp += step;
+  }
+  float ms = 0.f, mq = 0.f;
+#pragma unroll
+  for (int c = 0; c < MF; ++c) {
+    if (c + 1 < MF) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        gload16(buf[(c + 1) & 1][t], lp, voff);
+        lp += step;
+      }
+    }
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) *(f32x4_t*)(scratch + fr * 256 + (((g * 4 + fj) ^ fr) << 4)) = acc[fj][c];
+    f32x4_t v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 4 + rrow;
+      v[t] = *(const f32x4_t*)(scratch + row * 256 + ((c16 ^ row) << 4));
+    }
+    if (c == 0) {
+      wait_vmcnt_pin<4>(buf[0]);
+      asm volatile("" : "+v"(bia));
+    } else if (c + 1 == MF) {
+      wait_vmcnt_pin<4>(buf[c & 1]);
+    } else if (c == 4) {
+      wait_vmcnt_pin<9>(buf[c & 1]);   // stores of chunk 3 include the first moments store
+    } else {
+      wait_vmcnt_pin<8>(buf[c & 1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = (v[t] + bia) + buf[c & 1][t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      gstore16(sp, voff, v[t]);
+      sp += step;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float sm, sq;
+      slot_moments(v[t], sm, sq);
+      const bool mine = c16 == (c & 3) * 4 + t;
+      ms = mine ? sm : ms;
+      mq = mine ? sq : mq;
+      acc[t][c] = v[t];
+    }
+    if ((c & 3) == 3) {
+      const u32x2_t pm = {__builtin_bit_cast(uint32_t, ms), __builtin_bit_cast(uint32_t, mq)};
+      gstore8(pbase + (size_t)(c >> 2) * 64 * 8, poff, pm);
+    }
+  }
+  // ---- B: publish this wave's moments, wait for the rest of the row panel's half
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) l2_atomic_add(reg, ctr_off, 1u);
+  {
+    int spins = 0;
+    while (wave_l2_add_ret(reg, ctr_off, 0u, lane) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 19)) {  // never in a correct run: count it and go on (wrong rows beat a hung box)
+        if (lane == 0) l2_atomic_add(reg, (uint32_t)(a.ln_cap8 + 2) * 4u, 1u);
+        break;
+      }
+    }
+  }
+  asm volatile("buffer_inv sc1" ::: "memory");
+  // ---- C: (mean, rstd) of the wave's 128 rows into its LDS window; gamma / beta of the lane's 4 columns.  Every lane-derived
+  // address from here on comes from a fresh opaque copy of the lane id: computed early (hipcc would) they are live across
+  // pass A, where 128 accumulators + 48 row registers leave no room
+  int l2 = lane;
+  asm volatile("" : "+v"(l2));
+  const int rrow2 = l2 >> 4, c162 = l2 & 15;
+  f32x4_t gam, bet;
+  gload16(gam, a.ln_g + nw, (uint32_t)c162 * 16u);
+  gload16(bet, a.ln_b + nw, (uint32_t)c162 * 16u);
+  if (a.N == 768) lnc_row_stats<PREC, 12>(a, mw, l2, scratch);
+  else lnc_row_stats<PREC, 16>(a, mw, l2, scratch);   // (route admits 768 and 1024 only)
+  asm volatile("" : "+v"(gam), "+v"(bet));               // (covered by lnc_row_stats' vmcnt(0): they are older)
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- D: LayerNorm of the rows in registers (ln_row.hpp ln_center_sq / ln_scale arithmetic), packed, stored
+  const char* yp = (const char*)a.ln_y + ((size_t)mw * a.ldo + nw) * 2;
+  const size_t ystep = (size_t)a.ldo * 8;   // bytes per 4 16-bit rows
+  const uint32_t yoff = (uint32_t)(rrow2 * a.ldo + c162 * 4) * 2u;  // bytes, 16-bit rows
+#pragma unroll
+  for (int c = 0; c < MF; ++c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t st = *(const f32x2_t*)(scratch + (c * 16 + t * 4 + rrow2) * 8);
+      f32x4_t y;
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[t][c][e] - st[0]) * st[1], gam[e], bet[e]);
+      }
+      sat_track<PREC>(amax, y[0], y[1]);
+      sat_track<PREC>(amax, y[2], y[3]);
+      if constexpr (PREC == MCM_PREC_F16) asm volatile("" : "+v"(amax));
+      const u32x2_t yy = {pack2<PREC>(y[0], y[1]), pack2<PREC>(y[2], y[3])};
+      gstore8(yp, yoff, yy);
+      yp += ystep;
+    }
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (vmcnt is a 6-bit counter: never more than 28 stores in flight)
+    __builtin_amdgcn_sched_barrier(0);                   // (chunk by chunk: hoisting all 32 LDS reads of (mean, rstd) costs 64 registers)
+  }
+}
+
 // BAL (balanced DMA): waves 0-3 stage their X half and W rows 0-127, waves 4-7 their X half and W rows 128-255 —
 // 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
 // waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
@@ -734,9 +954,10 @@ __device__ __forceinline__ void ln_finish(const GemmArgs& a, int xcd, char* smem
 // EPI_GELU the consumer form of wave_epilogue_lds; a wave then carries 6 registers of row / column data across its last
 // compute phase instead of 16 bias registers.
 // LNT: LayerNorm in the tail (above)
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false, bool LNC = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   static_assert(!LNT || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG), "LNT: plain residual form");
+  static_assert(!LNC || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG && !LNT), "LNC: plain residual form");
   using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -758,6 +979,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
       sat_report<PREC>(am, a.sat);
       ln_finish(a, xcd, smem);
     }
+    if constexpr (LNC) ln_finish(a, xcd, smem);   // (counted among the XCD's finished workgroups: the last one zeroes the counters)
     return;
   }
   const int nk = (a.K * ES) / ROWB;
@@ -941,6 +1163,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
           wave_epilogue_lds<PREC, EPI, 8, true>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
         else if constexpr (FOLD)
           wave_epilogue_resid_fold<PREC, 8>(a, acc, em0 + wr * 128, en0 + wc * 64, le, win, amax);
+        else if constexpr (LNC)
+          wave_epilogue_resid_lnc<PREC, 8>(acc, em0 + wr * 128, en0 + wc * 64, le, win, amax,
+                                           LNC_ARG(ln_state) + (size_t)xcd * LNC_ARG(ln_rs),
+                                           (uint32_t)((((em0 / BM) >> 3) * 2 + wr) * 4), (uint32_t)(nbn * 4));
         else
           wave_epilogue_f32_interior<EPI, 8>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win);
       }
@@ -1099,8 +1325,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     if (pub >= 0 && lane == 0) l2_atomic_add(a.ln_state + (size_t)xcd * a.ln_rs, (uint32_t)pub * 4u, 1u);
     ln_tail<PREC>(a, xcd, nmt_x, lane, amax);
   }
-  if constexpr (EPI <= EPI_GELU || FOLD || LNT) sat_report<PREC>(amax, a.sat);
-  if constexpr (LNT) ln_finish(a, xcd, smem);
+  if constexpr (EPI <= EPI_GELU || FOLD || LNT || LNC) sat_report<PREC>(amax, a.sat);
+  if constexpr (LNT || LNC) ln_finish(a, xcd, smem);
   PPT_DUMP();
 }
 
@@ -1545,16 +1771,16 @@ hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false>
+template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false, bool LNC = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>,
+    hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT, LNC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set.set();
   }
-  hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT, LNC>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 template <int PREC, int EPI>
@@ -1575,7 +1801,7 @@ hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
 template <int PREC, int EPI>
 bool route(int& v, const GemmArgs& a, hipStream_t s, hipError_t* err) {
   const bool whole = a.M % p256::BM == 0 && a.N % p256::BN == 0;
-  const bool fold = a.fold_z != nullptr || a.fold_rs != nullptr;
+  const bool fold = !a.lnc && (a.fold_z != nullptr || a.fold_rs != nullptr);
   *err = hipErrorInvalidValue;
   if (fold) {  // LayerNorm fold: measured slower than the LayerNorm launches (EXPERIMENTS.md)
     if constexpr (EPI != EPI_PATCH && PREC != MCM_PREC_F32) {
@@ -1586,6 +1812,14 @@ bool route(int& v, const GemmArgs& a, hipStream_t s, hipError_t* err) {
       } else if constexpr (EPI <= EPI_GELU) {
         if (v == 0 && sides) *err = launch_tile_fold<PREC, EPI>(a, s);
       }
+    }
+    return true;
+  }
+  if (a.ln_y && a.lnc) {  // LayerNorm by the row panel's cluster (LNC): counters for two halves per row panel
+    if constexpr (EPI == EPI_RESID && PREC != MCM_PREC_F32) {
+      if (v == 5 && whole && (a.N == 768 || a.N == 1024) && a.ldo == a.N && a.ln_g && a.ln_b && a.ln_state && a.fold_part && a.bias &&
+          a.ln_cap8 >= 2 * ((a.M / p256::BM + 7) / 8) && persistent_grid() % 8 == 0)
+        *err = launch_pp<PREC, EPI, false, false, false, false, true>(a, s);
     }
     return true;
   }

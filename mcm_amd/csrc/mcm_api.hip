@@ -327,10 +327,14 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
 // An A/B arm: bit-identical, equal at ViT-B/16 batch 512, +0.5 % at ViT-L/14, -1 ... -7 % on smaller problems
 #ifdef MCM_HARNESS
 int g_ln_tail = 0;  // mcm_debug_ln_tail
+int g_ln_cluster = 0;  // mcm_debug_ln_cluster: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp "LNC", round 6)
 #elif defined(MCM_LN_TAIL)  // A/B build of the shipped library with the tail on
 constexpr int g_ln_tail = 1;
 #else
 constexpr int g_ln_tail = 0;
+#endif
+#ifndef MCM_HARNESS
+constexpr int g_ln_cluster = 0;
 #endif
 // The tail's coherence argument needs every workgroup with the same blockIdx & 7 on the same XCD (one L2).  That is
 // how the dispatcher deals workgroups in the default (SPX) mode; it is checked on the device, once per handle, with
@@ -404,12 +408,18 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   };
   bool ln1_folded = false;  // h->ln holds gamma1 o x and h->fold_rs the row statistics of this layer's layer_norm1
   // LayerNorm in the tail: the residual GEMMs of whole-batch layers also produce the LayerNorm that follows them
-  const bool tail_ok = g_ln_tail && !x2 && !can_fold && !t.split && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
-                       gemm_ln_tail_ok(P, Mp, D);
+  const bool tail_ok0 = g_ln_tail && !x2 && !can_fold && !t.split && h->ln_state && Mp % 256 == 0 && Mp / 256 <= h->ln_cap8 * 8 &&
+                        gemm_ln_tail_ok(P, Mp, D);
+  // LayerNorm by the row panel's cluster (LNC, harness arm): the same hand-over of gamma / beta / output / counters, plus the
+  // slot-moment buffer; the residual epilogue itself writes the LayerNorm output (no idle-wave tickets, no re-read of x)
+  const bool cluster_ok = g_ln_cluster && !g_ln_tail && !x2 && !can_fold && !t.split && h->ln_state && h->fold_part && Mp % 256 == 0 &&
+                          2 * ((Mp / 256 + 7) / 8) <= h->ln_cap8 && gemm_ln_tail_ok(P, Mp, D);
   auto with_tail = [&](GemmArgs& g, const float* gamma, const float* beta) {
     g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
     g.ln_state = h->ln_state; g.ln_rs = h->ln_rs; g.ln_cap8 = h->ln_cap8;
+    if (cluster_ok) { g.lnc = 1; g.fold_part = h->fold_part; }
   };
+  const bool tail_ok = tail_ok0 || cluster_ok;   // either arm: the residual GEMM also produces the LayerNorm behind it
   bool ln1_by_tail = false;  // h->ln already holds this layer's layer_norm1 (written by the previous layer's fc2)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
@@ -660,7 +670,7 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
 #endif
 #if defined(MCM_HARNESS) || defined(MCM_LN_TAIL)  // LayerNorm in the tail (A/B arm): its counters, if the device qualifies
   if (!rc && c.precision != MCM_PREC_F32 && (c.v_width == 768 || c.v_width == 1024) && xcd_round_robin(h, gemm_persistent_grid())) {
-    h->ln_cap8 = (int)((mv / 256 + 7) / 8);
+    h->ln_cap8 = 2 * (int)((mv / 256 + 7) / 8);  // (x 2: the cluster arm counts the upper and lower half of a row panel separately)
     h->ln_rs = (h->ln_cap8 + 3 + 63) / 64 * 64;  // words per XCD region: whole 256-B blocks, no line shared between XCDs
     const size_t bytes = (size_t)8 * h->ln_rs * sizeof(unsigned int);
     rc = dev_alloc(h, (void**)&h->ln_state, bytes);
@@ -1375,6 +1385,10 @@ int mcm_debug_ln_fold(int32_t on) {  // 0 (shipped behaviour): every LayerNorm a
 
 int mcm_debug_ln_tail(int32_t on) {  // 1: LayerNorm in the tail of the residual GEMMs; 0 (shipped behaviour): LayerNorm launches
   g_ln_tail = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_ln_cluster(int32_t on) {  // 1: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp LNC); 0 (shipped behaviour): LayerNorm launches
+  g_ln_cluster = on ? 1 : 0;
   return MCM_OK;
 }
 int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host) {  // tickets that gave up waiting (0 in a correct run)

@@ -175,7 +175,10 @@ class SmiSampler(threading.Thread):
     def stop(self):
         self._stop_evt.set()
         self.join(timeout=10)
-        busy = [s for s in self.samples if s[1] > 300]
+        # busy samples: within 30 % of the highest power seen (an idle MI355X draws 250 - 300 W, a loaded one up to 1.4 kW; a
+        # fixed 300-W line mistook idle samples of a warm part for load, and dropped every sample of a light workload)
+        top = max((s[1] for s in self.samples), default=0.0)
+        busy = [s for s in self.samples if s[1] >= 0.7 * top]
         out = {"samples": len(self.samples), "busy_samples": len(busy), "source": self.source}
         if busy:
             out.update(sclk_mhz_mean=sum(s[0] for s in busy) / len(busy), power_w_mean=sum(s[1] for s in busy) / len(busy))
