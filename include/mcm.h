@@ -413,11 +413,10 @@ int mcm_kernel_faults(const mcm_handle* h);
  * and tools, never by the product path).  Process-wide switches.
  * GEMM variant: -1 the shipped size policy (64x128 / 128x128 tile kernels, persistent 256x256, ping-pong),
  * 0 = the 128x128 tile kernel always, 11 = the 64x128 tile kernel always, 3/4 = persistent 256x256 2-stage (4: counted
- * epilogue stores), 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3);
- * arms of gemm_arms.hpp: 1/2 = persistent 256x128 3-stage (2: counted epilogue stores), 6 = the ping-pong loop on 32x32x16
- * MFMAs (16-bit modes), 7 = ping-pong with balanced DMA (8 + 8 pieces per step), 8 = ping-pong with staggered epilogues,
- * 9 = the flagged ping-pong text with every flag off (honours mcm_debug_gemm_group_n) — 6 ... 9: whole tiles, others run as 5.
- * Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
+ * epilogue stores), 5 = persistent 256x256 ping-pong (problems whose M and N are multiples of 256; others run as 3),
+ * 9 = the flagged ping-pong text of gemm_arms.hpp with every flag off (honours mcm_debug_gemm_group_n; whole tiles, others as 5).
+ * Removed in round 6 after measuring negative (EXPERIMENTS.md "Removed arms"): 1/2 persistent 256x128 3-stage, 6 the ping-pong
+ * loop on 32x32x16 MFMAs, 7 balanced DMA, 8 staggered epilogues.  Returns MCM_OK, or MCM_EINVAL for an unknown variant. */
 int mcm_debug_gemm_variant(int32_t variant);
 /* 16-bit attention kernel: 1 = the shipped policy (the transpose-read kernel; its persistent form at the B/16 shape from 16 jobs
  * per CU on), 0 = the round-1 kernel, 10 = XCD-aware deal of the (sequence, head) workgroups, 11 = the q-blocks dealt to the waves
@@ -452,7 +451,7 @@ int mcm_debug_patch_fold(int32_t on);
    rounds 2 - 3 for every workgroup (A/B). */
 int mcm_debug_resize_fused_only(int32_t on);
 /* 0 (shipped): the persistent GEMM kernels launch one workgroup per CU; n (a multiple of 8): n workgroups, so that two
-   handles on two streams can share the chip (tools/dual_stream_probe.py). */
+   handles on two streams can share the chip (tools/dual_stream_probe.py, removed in round 6: git history). */
 int mcm_debug_persistent_grid(int32_t n);
 /* A/B: 1 = the LayerNorms of the vision tower between a residual GEMM and its consumer folded into the two GEMM
  * epilogues (16-bit modes, widths that are multiples of 256; bit-identical for every batch size); 0 (default, the

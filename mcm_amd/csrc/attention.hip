@@ -21,18 +21,6 @@
 // Measurements: DESIGN.md section 4.2.
 #include "common.hpp"
 
-// -DMCM_ATTN_TRACE (tools/attn_trace.hip only): cycle stamps of a workgroup's phases, one record per (workgroup, wave)
-#ifdef MCM_ATTN_TRACE
-__device__ unsigned long long* g_attn_trace = nullptr;   // [workgroups][8 waves][8 stamps]
-#define ATTN_STAMP(k)                                                                                                   \
-  do {                                                                                                                  \
-    if (g_attn_trace && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8)                                              \
-      g_attn_trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();             \
-  } while (0)
-#else
-#define ATTN_STAMP(k) do {} while (0)
-#endif
-
 namespace {
 
 __device__ __forceinline__ int ktile_off(int r, int c) {  // same image as the GEMM tile
@@ -229,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 //   * V stays row-major in LDS ([key][64 d], 128-B rows, the 32-B column segment XORed with
 //     (key>>1)&3) and is filled by LDS-DMA exactly like K.  The PV A-operand (V^T, 4 keys x 16 dims
 //     per 16-lane group) comes from ds_read_b64_tr_b16: lane i of a group passes the address of 4
-//     contiguous dims of key i/4 and receives dim i of the 4 keys (tools/isa_probe.hip).  Gone: 8
+//     contiguous dims of key i/4 and receives dim i of the 4 keys (tools/isa_probe.hip, removed in round 6: git history).  Gone: 8
 //     global V loads, ~64 ds_write_b32 and the XOR address arithmetic per thread, and the bank
 //     conflicts of the transposing writes.  The read address is lane_base[dt] + tile * 2048: one VGPR
 //     per 16-dim block, everything else immediate offsets.
@@ -323,15 +311,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
   const uint16_t* base = X2 ? qkv + (size_t)seq * L * rs + h * 128
                             : MCM_HM(hm) ? qkv + ((size_t)h * hm + (size_t)seq * L) * 64 : qkv + (size_t)seq * L * rs + h * 64;
   const int fr = lane & 15, g = lane >> 4;
-  ATTN_STAMP(0);   // workgroup running
-#ifdef MCM_ATTN_TRACE
-  if (g_attn_trace && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {  // where it runs: (XCC id << 32) | HW_ID
-    unsigned int hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_attn_trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 7] = ((unsigned long long)(xcc & 0xfu) << 32) | hw;
-  }
-#endif
 
   // ---- every global read is issued up front: Q fragments of this wave's q-blocks, K, V
   const int nqb = (qrows + 15) / 16;
@@ -367,11 +346,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
       }
     }
   }
-  ATTN_STAMP(1);   // every load issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ATTN_STAMP(2);   // this wave's loads landed
   __syncthreads();
-  ATTN_STAMP(3);   // everybody's loads landed
 
   int koff[2];
 #pragma unroll
@@ -536,9 +512,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_tr_kernel(const uint16_t* _
         if constexpr (X2) *(uint4*)(orow + 64 + (2 * pr + (g & 1)) * 16 + (g & 2) * 4) = widel[pr];
       }
     }
-    ATTN_STAMP(4 + i);   // q-block i of this wave done (stores issued)
   }
-  ATTN_STAMP(6);   // wave done
 }
 
 // ---- persistent, specialised form of the 16-bit kernel (round 5, EXPERIMENTS.md R5.9) -------------------------------------
@@ -1049,7 +1023,7 @@ hipError_t launch_tr_x2(const void* qkv, void* out, int nseq, int L, int heads, 
 
 
 // Waves per workgroup.  The q-blocks of a sequence are dealt round-robin to the waves, so the slowest wave has
-// ceil(q-blocks / waves) of them.  Measured at B/16 batch 512 / L/14 batch 256 (tools/attn_probe.py, same
+// ceil(q-blocks / waves) of them.  Measured at B/16 batch 512 / L/14 batch 256 (tools/attn_probe.py — removed in round 6 —, same
 // box, old kernel 215 / 295 us): 4 waves (4-3-3-3 blocks) 164 - 167 / 183 - 186 us, 5 - 6 waves 171 - 178, 7 waves
 // 154 - 168, **8 waves (2-2-2-2-2-1-1-1) 149 - 153 / 156 - 158 us**; occupancy bounds 1 ... 4 waves per SIMD make no
 // difference at 8 waves (90 / 116 VGPRs either way), 6 and more cost spills.  Results are bit-identical

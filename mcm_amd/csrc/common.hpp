@@ -85,7 +85,7 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
 }
 // fp16 overflow guard.  MODE.FP16_OVFL (bit 23) makes every f32 -> f16 conversion of the wave saturate
 // finite out-of-range values to +-65504 instead of +-inf (inf and NaN inputs stay what they are).
-// Measured on gfx950 (tools/isa_probe.hip): v_cvt_pk_f16_f32 honours it — 65520, 7e4, 1e6, 3.4e38 all
+// Measured on gfx950 (tools/isa_probe.hip, removed in round 6: git history): v_cvt_pk_f16_f32 honours it — 65520, 7e4, 1e6, 3.4e38 all
 // give 65504.  One scalar instruction per wave, nothing per element: an activation that leaves the
 // fp16 range (a QuickGELU output or a q/k/v value above 65504) costs that element's precision, not an
 // inf that turns the whole row into NaN at the next LayerNorm.  Set once at kernel entry by every kernel
@@ -104,7 +104,7 @@ __device__ __forceinline__ void enter_precision_mode() {
 // pass) and is the last VMEM instruction of its wave.
 template <int PREC>
 __device__ __forceinline__ void sat_track(float& amax, float a, float b) {
-#ifndef MCM_NO_SAT_TRACK  // (defined only for the overhead A/B build of tools/_call.sh)
+#ifndef MCM_NO_SAT_TRACK  // (defined only for an overhead A/B build: make CXXFLAGS+=-DMCM_NO_SAT_TRACK)
   if constexpr (PREC == MCM_PREC_F16) amax = fmaxf(fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
 #endif
 }

@@ -1258,9 +1258,8 @@ int persistent_grid();
 
 #ifdef MCM_HARNESS
 int g_variant = -1;  // -1 auto (the shipped size policy), 0 the 128x128 tile kernel always, 3/4 persistent 256x256 (4: counted
-                     // stores), 5 ping-pong 256x256 (whole tiles only, else 3), 11 the 64x128 tile kernel always; arms
-                     // (gemm_arms.hpp): 1/2 persistent 256x128, 6 ping-pong on 32x32x16 MFMAs, 7 balanced DMA, 8 staggered
-                     // epilogues, 9 the flagged ping-pong text with every flag off (all: whole tiles, else as 5)
+                     // stores), 5 ping-pong 256x256 (whole tiles only, else 3), 11 the 64x128 tile kernel always; 9 the flagged
+                     // ping-pong text of gemm_arms.hpp with every flag off (whole tiles, else as 5).  1/2/6/7/8: removed in round 6
 int variant() { return g_variant; }
 #else
 constexpr int variant() { return -1; }  // the shipped library has the size policy of launch_one only
@@ -1489,9 +1488,6 @@ hipError_t launch_gemm(int prec, int epi, const GemmArgs& a_in, hipStream_t s) {
     return hipErrorInvalidValue;
   if (a.xsplit && a.ldx % 128) return hipErrorInvalidValue;
   if (epi_x2(epi) && (a.N % 64 || a.ldo % 128)) return hipErrorInvalidValue;
-#ifdef MCM_HARNESS
-  if (a.ksplit && (variant() == 1 || variant() == 2 || variant() == 6)) return hipErrorInvalidValue;  // (arms without the split staging)
-#endif
   // head-major outputs: 16-bit store epilogues only, whole 64-column blocks
   if (a.hm && (a.hm < a.M || a.N % 64 || epi > EPI_GELU || prec == MCM_PREC_F32)) return hipErrorInvalidValue;
 #ifndef MCM_HARNESS

@@ -4,11 +4,12 @@
 // (libmcm_hip_harness.so, tools/gemm_bench), -DMCM_LN_FOLD / -DMCM_LN_TAIL (make fold / make tail).  libmcm_hip.so does
 // not contain a line of this file.  What each arm measured: EXPERIMENTS.md.
 //
-//   arms::gemm_persist_kernel     persistent 256x128, 3 LDS stages (variants 1 / 2): bound by the L1 -> LDS DMA path
-//   arms::gemm_pp_kernel          the shipped ping-pong kernel with its A/B flags: BAL (balanced DMA, variant 7), STAG
-//                                 (staggered epilogues, 8), FOLD (LayerNorm fold producer / consumer epilogues), LNT
-//                                 (LayerNorm in the tail of the residual GEMMs), the in-loop ablation bits, phase timing
-//   arms::gemm_pp32_kernel        the ping-pong loop on 32x32x16 MFMAs (variant 6): same cycles, more power, lower clock
+//   arms::gemm_pp_kernel          the shipped ping-pong kernel with its A/B flags: FOLD (LayerNorm fold producer / consumer
+//                                 epilogues), LNT (LayerNorm in the tail of the residual GEMMs), LNC (round 6: LayerNorm by
+//                                 the row panel's cluster of workgroups — the full-row epilogue), the grouped tile walk
+//                                 (variant 9), the in-loop ablation bits, phase timing
+// Removed in round 6 (measured negative in rounds 2 - 4; EXPERIMENTS.md "Removed arms", git history): the persistent 256x128
+// 3-stage kernel (variants 1 / 2), the ping-pong loop on 32x32x16 MFMAs (6), balanced DMA (7), staggered epilogues (8).
 //   arms::gemm_tile_kernel        the 128x128 tile kernel with the LayerNorm-fold consumer epilogue
 //   arms::wave_epilogue(_lds)     the epilogues with the fold consumer form and the dbg store bits
 // The copies of shipped code in here (tile kernel, ping-pong kernel, the two epilogues) are the round-3 text with every
@@ -324,153 +325,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const GemmArgs a) {
   load_bias(a, n0 + wc * 64 + g * 16, bv);
   float amax = 0.f;
   wave_epilogue<PREC, EPI, 4, FOLD>(a, acc, bv, m0 + wr * 64, n0 + wc * 64, fr, g, amax);
-  sat_report<PREC>(amax, a.sat);
-}
-
-// =========================================================================================
-// persistent 256x128 kernel, 3-stage LDS-DMA pipeline running across tile boundaries
-// =========================================================================================
-namespace persist {
-constexpr int BM = 256, BN = 128;
-constexpr int A_BYTES = BM * ROWB;           // 32 KiB
-constexpr int W_BYTES = BN * ROWB;           // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-constexpr int NSTAGE = 3;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB
-constexpr int LOADS_PER_STAGE = 6;               // LDS-DMA instructions per wave per stage
-}  // namespace persist
-
-template <int PREC, int EPI, bool COUNT_STORES>
-__global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmArgs a) {
-  using namespace persist;
-  enter_precision_mode<PREC>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = prec_esize(PREC);
-  // store instructions per wave per full tile: 4 rows x (2 x 16 B bf16 | 4 x 16 B fp32)
-  constexpr int STORES_PER_EPI = (PREC != MCM_PREC_F32 && EPI <= EPI_GELU) ? 8 : 16;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
-
-  // ---- tile schedule: M-tiles are striped over the 8 XCDs (mt = mtl*8 + xcd); the G/8
-  // workgroups of an XCD walk that XCD's (mtl, nt) list n-fastest, so concurrently running
-  // CUs of one XCD share X row panels through their L2.
-  const int nbn = (a.N + BN - 1) / BN;
-  const int nbm = (a.M + BM - 1) / BM;
-  const int G8 = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int nmt_x = (nbm - xcd + 7) >> 3;
-  const int ntl_x = nmt_x * nbn;
-  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
-  const int total = ntl * nk;
-
-  // ---- LDS-DMA source geometry of this lane (constant): piece i covers tile rows
-  // i*64 + r0, 16-B chunk `chunk` (swizzled)
-  const int r0 = wave * 8 + (lane >> 4) * 2 + ((lane & 15) >> 3);
-  const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
-  const char* gx[4];
-  const char* gw[2];
-  int ji = 0, kti = 0;  // issue cursor: tile index (of this workgroup) and K-step
-  auto set_issue_tile = [&](int i) {
-    int mtl, nt;
-    tile_of(jx + i * G8, nmt_x, nbn, a.gn, mtl, nt);
-    const int m0 = (mtl * 8 + xcd) * BM, n0 = nt * BN;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      gx[p] = (const char*)a.x + ((size_t)min(m0 + p * 64 + r0, a.M - 1) * a.ldx) * ES + chunk * 16;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      gw[p] = (const char*)a.w + ((size_t)min(n0 + p * 64 + perm_n(r0), a.N - 1) * a.K) * ES + chunk * 16;
-  };
-  const uint32_t lds0 = lds_addr(smem);
-  auto issue = [&](int st) {
-    const uint32_t base = lds0 + st * STAGE_BYTES;
-    const size_t ko = (size_t)kti * ROWB;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      glds16(gx[p] + ko, __builtin_amdgcn_readfirstlane(base + (p * 8 + wave) * 1024));
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      glds16(gw[p] + ko, __builtin_amdgcn_readfirstlane(base + A_BYTES + (p * 8 + wave) * 1024));
-    if (++kti == nk) {
-      kti = 0;
-      if (++ji < ntl) set_issue_tile(ji);
-    }
-  };
-
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, g = lane >> 4;
-  const int foff[2] = {frag_off(fr, g, 0), frag_off(fr, g, 1)};
-  const int xbase = wr * 64 * ROWB;
-  const int wbase = A_BYTES + wc * 64 * ROWB;
-
-  f32x4_t acc[4][4];
-  zero_acc(acc);
-  float amax = 0.f;
-
-  set_issue_tile(0);
-  int issued = 0;
-  for (; issued < 2 && issued < total; ++issued) issue(issued);
-  int st = 0;          // LDS stage of step s
-  int ist = 2;         // LDS stage the next issue goes to
-  int jc = 0, ktc = 0; // compute cursor
-  int since_epi = 1000;
-  int cm0, cn0;        // origin of the tile being computed
-  {
-    int mtl, nt;
-    tile_of(jx, nmt_x, nbn, a.gn, mtl, nt);
-    cm0 = (mtl * 8 + xcd) * BM;
-    cn0 = nt * BN;
-  }
-  f32x4_t bv[4];
-#pragma unroll
-  for (int fj = 0; fj < 4; ++fj) bv[fj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const bool counted = nk >= 3;  // short K: every wait is vmcnt(0)
-  for (int s = 0; s < total; ++s) {
-    // Stage s must have landed; everything issued after it may stay in flight.  VMEM issue
-    // order around a tile boundary (tile ends at step e):
-    //   step e  : [DMA stage e+2] ........ [epilogue stores, E per wave]
-    //   step e+1: [bias loads, 4] [DMA stage e+3]
-    //   step e+2: [DMA stage e+4]
-    // so the ops younger than the awaited stage are 6+E at e+1, 10+E at e+2, else 6.
-    if (counted && issued > s + 1) {
-      if (COUNT_STORES && since_epi == 1) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI>();
-      else if (COUNT_STORES && since_epi == 2) wait_vmcnt<LOADS_PER_STAGE + STORES_PER_EPI + 4>();
-      else wait_vmcnt<LOADS_PER_STAGE>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (ktc == 0 && a.bias) load_bias_async(a, cn0 + wc * 64 + g * 16, bv);
-    if (issued < total) {  // refill the stage that step s-1 just finished reading
-      if (!ABL(1)) issue(ist);
-      ist = ist == NSTAGE - 1 ? 0 : ist + 1;
-      ++issued;
-    }
-    const char* sb = smem + st * STAGE_BYTES;
-    if (!ABL(2)) wave_kstep<PREC, 4>(sb + xbase, sb + wbase, foff, acc);
-    st = st == NSTAGE - 1 ? 0 : st + 1;
-    ++since_epi;
-    if (++ktc == nk) {
-      if (!counted) wait_vmcnt<0>();  // bias was issued in this very tile's first step
-#pragma unroll
-      for (int fj = 0; fj < 4; ++fj) asm volatile("" : "+v"(bv[fj]));
-      if (!DBG(4)) wave_epilogue<PREC, EPI, 4>(a, acc, bv, cm0 + wr * 64, cn0 + wc * 64, fr, g, amax);
-      zero_acc(acc);
-      // only a full tile issues exactly STORES_PER_EPI stores per wave; ragged tiles fall back
-      // to waiting for the stores as well
-      since_epi = (cm0 + BM <= a.M && cn0 + BN <= a.N) ? 0 : 1000;
-      ktc = 0;
-      if (++jc < ntl) {
-        int mtl, nt;
-        tile_of(jx + jc * G8, nmt_x, nbn, a.gn, mtl, nt);
-        cm0 = (mtl * 8 + xcd) * BM;
-        cn0 = nt * BN;
-      }
-    }
-  }
   sat_report<PREC>(amax, a.sat);
 }
 
@@ -943,21 +797,14 @@ __device__ __forceinline__ void wave_epilogue_resid_lnc(f32x4_t (&acc)[4][MF], i
   }
 }
 
-// BAL (balanced DMA): waves 0-3 stage their X half and W rows 0-127, waves 4-7 their X half and W rows 128-255 —
-// 8 + 8 pieces per step instead of 12 + 4.  The W pieces of waves 4-7 are issued FIRST in their memory phase and
-// waited for at its END (vmcnt <= their 4 X pieces), one barrier before waves 0-3 read them; the stage they go to
-// was last read (W fragments, by these very waves) a whole step earlier, so no ring of three is needed.
-// STAG (staggered epilogues): waves 0-3 run the epilogue of a finished tile BEFORE the barrier that ends the phase
-// in which waves 4-7 still compute that tile's last K-step, waves 4-7 theirs one phase later, under the first compute
-// phase of waves 0-3 on the next tile: each group's stores and conversions run beside the other group's MFMAs.
 // FOLD (LayerNorm fold, 16-bit modes): EPI_RESID runs the producer epilogue (wave_epilogue_resid_fold), EPI_STORE /
 // EPI_GELU the consumer form of wave_epilogue_lds; a wave then carries 6 registers of row / column data across its last
 // compute phase instead of 16 bias registers.
 // LNT: LayerNorm in the tail (above)
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false, bool LNC = false>
+template <int PREC, int EPI, bool FOLD = false, bool LNT = false, bool LNC = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
-  static_assert(!LNT || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG), "LNT: plain residual form");
-  static_assert(!LNC || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !BAL && !STAG && !LNT), "LNC: plain residual form");
+  static_assert(!LNT || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD), "LNT: plain residual form");
+  static_assert(!LNC || (EPI == EPI_RESID && PREC != MCM_PREC_F32 && !FOLD && !LNT), "LNC: plain residual form");
   using namespace p256;
   enter_precision_mode<PREC>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1049,11 +896,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 #endif
       glds16s(tx + kox + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
     } else {
-      const int q = BAL ? grp * 4 + (i - 4) : i - 4;
+      const int q = i - 4;
       glds16s(tw + ko + (size_t)((q >> 1) * 64 + (q & 1) * 8) * sw, lk.voff_w, base + A_BYTES + q * 4096);
     }
   };
-  constexpr int NP0 = BAL ? 8 : 12;  // pieces per step of waves 0-3
+  constexpr int NP0 = 12;  // pieces per step of waves 0-3
   auto issue_done = [&]() {
     if (++kti == nk) {
       kti = 0;
@@ -1182,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
     const LaneK lk = lane_consts();
 #pragma unroll
     for (int i = 0; i < NP0; ++i)
-      if (BAL || i < 4 || !grp) piece(lk, 0, i);
+      if (i < 4 || !grp) piece(lk, 0, i);
   }
   issue_done();
   wait_vmcnt<0>();
@@ -1220,7 +1067,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NP0; ++i) piece(lk, si, i);
         issue_done();
-        if constexpr (!STAG) phase_barrier();
+        phase_barrier();
       }
       epilogue();
       if constexpr (LNT) pub = (em0 / BM) >> 3;
@@ -1244,36 +1091,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
           piece(lk, si, i);
         }
       } else {
-        if constexpr (BAL) {  // W first: it has to land within this phase
 #pragma unroll
-          for (int i = 4; i < 8; ++i) {
-            readf(lk, sr, 2 * (i - 4));
-            readf(lk, sr, 2 * (i - 4) + 1);
-            piece(lk, si, i);
-          }
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            readf(lk, sr, 8 + 2 * i);
-            readf(lk, sr, 8 + 2 * i + 1);
-            piece(lk, si, i);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
-            piece(lk, si, i);
-          }
+          for (int j = 0; j < 4; ++j) readf(lk, sr, 4 * i + j);
+          piece(lk, si, i);
         }
       }
       issue_done();
     }
     pin_frags();
-    if constexpr (BAL) {
-      if (grp) wait_vmcnt<4>();  // everything older than this phase's 4 X pieces: the W pieces waves 0-3 read next
-    }
     PPT(0);
-    if (!split || STAG) phase_barrier();
+    if (!split) phase_barrier();
     PPT(1);
     // ---- compute phase of step s
     if constexpr (FOLD_OUT) {
@@ -1330,421 +1159,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs a) {
   PPT_DUMP();
 }
 
-// =========================================================================================
-// ping-pong kernel on v_mfma_f32_32x32x16_{f16,bf16} (16-bit operand modes only).  Same tile (256x256),
-// wave tiles (128x64), LDS image, DMA schedule and phase structure as gemm_pp_kernel; the compute phase
-// issues 32 MFMAs of 32 cycles instead of 64 of 16.  Why it pays here and did not in the barrier-locked
-// kernel: in the compute phase the MFMAs run back to back from registers, and a
-// 16x16x32 issues every ~19 cycles instead of 16 (the per-instruction issue overhead is paid per MFMA),
-// a 32x32x16 every ~32-33 instead of 32; it also reads its A/B operands from the register file half as
-// often per FLOP, which is energy on a part that sits at its power limit.
-//
-// Fragment maps (guide section 3): A = W block (32 tile columns x 16 k), B = X block (32 rows x 16 k),
-// lane l supplies row (l & 31), 16-B chunk (2 ks + (l >> 5)) of the 128-B K-step row — the existing
-// pair/XOR LDS image serves 32-row fragments conflict-free as well (the four 16-lane groups of a
-// ds_read_b128 touch 8 distinct row pairs).  D: lane (j = l & 31, h = l >> 5), register r holds
-// (X row j, W-block row 4h + 8(r >> 2) + (r & 3)); W rows are staged in the order perm_n32 so that this
-// is tile column h*16 + r: a lane owns 16 consecutive columns of its row in each of the two 32-column
-// blocks of the wave tile.
-// =========================================================================================
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-__device__ __forceinline__ int perm_n32(int i) {  // LDS row i (0..31) of a 32-row W block holds this block column
-  return ((i >> 2) & 1) * 16 + (i >> 3) * 4 + (i & 3);
-}
-template <int PREC>
-__device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {  // 32x32x16, fp32 acc
-  if constexpr (PREC == MCM_PREC_F16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4_t quad(const f32x16_t& v, int q) {
-  return (f32x4_t){v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-}
-
-// 16-bit epilogue of a full 128x64 wave tile held as acc[xb][wb] (32x32 blocks).  Unit = one block
-// (32 rows x 32 columns = 2 KiB of 16-bit), units in wb-major order ping-ponging between the two halves
-// of the wave's 4-KiB window like wave_epilogue_lds; a lane writes its 32 B of row j, the read-back puts
-// four lanes on a 64-B row, so one store instruction writes 16 rows x 64 B.  bv[wb][q]: bias of columns
-// nw + wb*32 + h*16 + q*4 .. +3; bv[1] is loaded here (asm, counted) and first used by unit 4.
-template <int PREC, int EPI>
-__device__ __forceinline__ void wave_epilogue16_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2], f32x4_t (&bv0)[4],
-                                                    int mw, int nw, int lane, char* scratch, float& amax) {
-  const int j = lane & 31, h = lane >> 5;
-  f32x4_t bv1[4];
-  if (a.bias) {
-    const float* p = a.bias + nw + 32 + h * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv1[q]) : "v"(p + q * 4) : "memory");
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bv1[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
-  const int rrow = lane >> 2, c4 = lane & 3;  // read-back: 4 lanes per 64-B row
-  auto write_unit = [&](int u, const f32x4_t (&bv)[4]) {
-    const int wb = u >> 2, xb = u & 3;
-    f32x4_t v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = quad(acc[xb][wb], q) + bv[q];
-      if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[q][t] = quick_gelu_fast(v[q][t]);
-      }
-      sat_track<PREC>(amax, v[q][0], v[q][1]);
-      sat_track<PREC>(amax, v[q][2], v[q][3]);
-    }
-    char* w = scratch + (u & 1) * 2048 + j * 64;
-    const int sw = (j >> 1) & 3;
-    *(uint4*)(w + (((h * 2) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[0][0], v[0][1]), pack2<PREC>(v[0][2], v[0][3]),
-                                                      pack2<PREC>(v[1][0], v[1][1]), pack2<PREC>(v[1][2], v[1][3]));
-    *(uint4*)(w + (((h * 2 + 1) ^ sw) << 4)) = make_uint4(pack2<PREC>(v[2][0], v[2][1]), pack2<PREC>(v[2][2], v[2][3]),
-                                                          pack2<PREC>(v[3][0], v[3][1]), pack2<PREC>(v[3][2], v[3][3]));
-  };
-  auto read_unit = [&](int u, uint4 (&r)[2]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 16 + rrow;
-      r[t] = *(const uint4*)(scratch + (u & 1) * 2048 + row * 64 + ((c4 ^ ((row >> 1) & 3)) << 4));
-    }
-  };
-  const int lane_off = rrow * a.ldo + c4 * 8;  // elements
-  auto store_unit = [&](int u, const uint4 (&r)[2]) {
-    const int wb = u >> 2, xb = u & 3;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint16_t* rowbase = (uint16_t*)a.out + (size_t)(mw + xb * 32 + t * 16) * a.ldo + nw + wb * 32;
-      if (!DBG(16)) store16_stream(rowbase + lane_off, r[t]);
-    }
-  };
-  write_unit(0, bv0);
-#pragma unroll
-  for (int u = 1; u < 8; ++u) {
-    uint4 r[2];
-    read_unit(u - 1, r);
-    if (u == 4) {
-      // VMEM queue behind the four bv1 loads: the stores of units 0..2 (2 each)
-      asm volatile("s_waitcnt vmcnt(6)" : "+v"(bv1[0]), "+v"(bv1[1]), "+v"(bv1[2]), "+v"(bv1[3])::"memory");
-    }
-    if (u < 4) write_unit(u, bv0);
-    else write_unit(u, bv1);
-    store_unit(u - 1, r);
-  }
-  {
-    uint4 r[2];
-    read_unit(7, r);
-    store_unit(7, r);
-  }
-}
-
-// fp32-row epilogue (residual read-modify-write) of the same wave tile.  Unit = one 32x32 block = 32 rows x
-// 128 B = the whole 4-KiB window; eight lanes read a row back, so every global access instruction moves
-// 8 rows x 128 B.  The bias (of the four columns a lane owns AFTER the bounce) is added after the bounce:
-// (acc + b) + resid, the order of every other GEMM kernel here.  All global accesses are asm, counted:
-// queue at the wait of unit u, oldest first: [loads u] [stores u-1] [loads u+1]  =>  vmcnt <= 8.
-__device__ __forceinline__ void wave_epilogue_resid_b32(const GemmArgs& a, const f32x16_t (&acc)[4][2],
-                                                        const f32x4_t (&bvf)[2], int mw, int nw, int lane, char* scratch) {
-  const int j = lane & 31, h = lane >> 5;
-  const int rrow = lane >> 3, c8 = lane & 7;
-  const uint32_t voff = (uint32_t)(rrow * a.ldo + c8 * 4) * 4u;  // bytes
-  const char* base = (const char*)a.resid + ((size_t)mw * a.ldo + nw) * 4;
-  auto rowbase = [&](int u, int t) {
-    const int wb = u >> 2, xb = u & 3;
-    return base + ((size_t)(xb * 32 + t * 8) * a.ldo + wb * 32) * 4;
-  };
-  f32x4_t buf[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) gload16(buf[0][t], rowbase(0, t), voff);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int wb = u >> 2, xb = u & 3;
-    if (u + 1 < 8) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) gload16(buf[(u + 1) & 1][t], rowbase(u + 1, t), voff);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *(f32x4_t*)(scratch + j * 128 + (((h * 4 + q) ^ (j & 7)) << 4)) = quad(acc[xb][wb], q);
-    f32x4_t v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = t * 8 + rrow;
-      v[t] = *(const f32x4_t*)(scratch + row * 128 + ((c8 ^ (row & 7)) << 4)) + bvf[wb];
-    }
-    if (u == 0 || u + 1 == 8) wait_vmcnt_pin<4>(buf[u & 1]);
-    else wait_vmcnt_pin<8>(buf[u & 1]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] += buf[u & 1][t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gstore16(rowbase(u, t), voff, v[t]);
-  }
-}
-
-template <int PREC, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp32_kernel(const GemmArgs a) {
-  using namespace p256;
-  static_assert(PREC != MCM_PREC_F32 && EPI != EPI_PATCH, "16-bit operand modes, interior tiles");
-  enter_precision_mode<PREC>();
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
-  const int grp = wave >> 2, w4 = wave & 3;
-
-  const int nbn = a.N / BN, nbm = a.M / BM;
-  const int G8 = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int nmt_x = (nbm - xcd + 7) >> 3;
-  const int ntl_x = nmt_x * nbn;
-  const int ntl = jx < ntl_x ? (ntl_x - jx + G8 - 1) / G8 : 0;
-  if (ntl == 0) return;
-  const int nk = (a.K * ES) / ROWB;
-  const int total = ntl * nk;
-
-  const int dmt = G8 / nbn, dnt = G8 - dmt * nbn;
-  struct Cursor { int mtl, nt; };
-  auto cursor_next = [&](Cursor& c) {
-    c.mtl += dmt;
-    c.nt += dnt;
-    if (c.nt >= nbn) { c.nt -= nbn; ++c.mtl; }
-  };
-  auto mt_of = [&](int mtl) { return a.rev ? nmt_x - 1 - mtl : mtl; };
-  const size_t sx = (size_t)a.ldx * ES, sw = (size_t)a.K * ES;  // row strides in bytes
-
-  // ---- LDS-DMA side: exactly gemm_pp_kernel's (12 pieces per step from waves 0-3, 4 from waves 4-7), only the
-  // order of the W rows inside a 32-row block differs (perm_n32)
-  struct LaneK { uint32_t voff_x, voff_w; int fo0; };
-  auto lane_consts = [&]() {
-    int l = lane;
-    asm volatile("" : "+v"(l));
-    const int rr = (l >> 4) * 2 + ((l & 15) >> 3);
-    const int chunk = (l & 7) ^ (((w4 & 1) << 2) | (l >> 4));
-    LaneK c;
-    c.voff_x = (uint32_t)(rr * (uint32_t)sx + chunk * 16);
-    c.voff_w = (uint32_t)(perm_n32(w4 * 8 + rr) * (uint32_t)sw + chunk * 16);
-    const int j = l & 31, h = l >> 5;
-    c.fo0 = (j >> 1) * 256 + ((((j & 1) << 3) | ((h ^ (j >> 1)) & 7)) << 4);  // K16 sub-step ks: fo0 ^ (ks << 5)
-    return c;
-  };
-  Cursor ci{jx / nbn, jx % nbn};
-  int ji = 0, kti = 0;
-  const char *tx, *tw;
-  auto set_issue_tile = [&]() {
-    const int m0 = (mt_of(ci.mtl) * 8 + xcd) * BM, n0 = ci.nt * BN;
-    tx = (const char*)a.x + (size_t)(m0 + grp * 128 + w4 * 8) * sx;
-    tw = (const char*)a.w + (size_t)n0 * sw;
-  };
-  const uint32_t lds0 = lds_addr(smem);
-  auto piece = [&](const LaneK& lk, int st, int i) {  // i: 0-3 X pieces, 4-11 W pieces (waves 0-3 only)
-    const uint32_t base = lds0 + st * STAGE_BYTES + w4 * 1024;
-    const size_t ko = (size_t)kti * ROWB;
-    if (i < 4) {
-      glds16s(tx + ko + (size_t)(i * 32) * sx, lk.voff_x, base + (grp * 16 + i * 4) * 1024);
-    } else {
-      const int q = i - 4;  // LDS rows q*32 + w4*8 + rr of the W panel = tile columns q*32 + perm_n32(w4*8 + rr)
-      glds16s(tw + ko + (size_t)(q * 32) * sw, lk.voff_w, base + A_BYTES + q * 4096);
-    }
-  };
-  auto issue_done = [&]() {
-    if (++kti == nk) {
-      kti = 0;
-      if (++ji < ntl) {
-        cursor_next(ci);
-        set_issue_tile();
-      }
-    }
-  };
-
-  // ---- MFMA side: wave tile 128 x 64 = 4 X blocks x 2 W blocks of 32x32, K-step = 4 sub-steps of 16
-  const int wr = wave >> 2, wc = wave & 3;
-  const int xbase = wr * 128 * ROWB;
-  const int wbase = A_BYTES + wc * 64 * ROWB;
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  // memory phase: all 8 W fragments and the X fragments of sub-steps 0 and 1 (64 registers); the X fragments of
-  // sub-steps 2 and 3 replace them during the compute phase, each after its last use
-  u32x4_t xf[2][4], wf[4][2];
-  auto readf = [&](const LaneK& lk, int st, int i) {  // memory-phase read i of 16, in order of first use
-    const char* sb = smem + st * STAGE_BYTES;
-    if (i < 2) wf[0][i] = *(const u32x4_t*)(sb + wbase + i * 4096 + lk.fo0);
-    else if (i < 6) xf[0][i - 2] = *(const u32x4_t*)(sb + xbase + (i - 2) * 4096 + lk.fo0);
-    else if (i < 8) wf[1][i - 6] = *(const u32x4_t*)(sb + wbase + (i - 6) * 4096 + (lk.fo0 ^ 32));
-    else if (i < 12) xf[1][i - 8] = *(const u32x4_t*)(sb + xbase + (i - 8) * 4096 + (lk.fo0 ^ 32));
-    else wf[2 + ((i - 12) >> 1)][(i - 12) & 1] =
-        *(const u32x4_t*)(sb + wbase + ((i - 12) & 1) * 4096 + (lk.fo0 ^ ((2 + ((i - 12) >> 1)) << 5)));
-  };
-  auto pin_frags = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) asm volatile("" : "+v"(wf[k][f]));
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(xf[k][f]));
-  };
-  f32x16_t acc[4][2];
-  float amax = 0.f;
-  auto zero = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][w][r] = 0.f;
-  };
-  zero();
-  auto compute = [&](int fo0, int st) {
-    const char* sb = smem + st * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int xb = 0; xb < 4; ++xb) {
-#pragma unroll
-        for (int wb = 0; wb < 2; ++wb)
-          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks][xb]), acc[xb][wb]);
-        xf[ks][xb] = *(const u32x4_t*)(sb + xbase + xb * 4096 + (fo0 ^ ((ks + 2) << 5)));
-      }
-#pragma unroll
-    for (int ks = 2; ks < 4; ++ks)
-#pragma unroll
-      for (int xb = 0; xb < 4; ++xb)
-#pragma unroll
-        for (int wb = 0; wb < 2; ++wb)
-          acc[xb][wb] = mfma32<PREC>(__builtin_bit_cast(uint4, wf[ks][wb]), __builtin_bit_cast(uint4, xf[ks & 1][xb]), acc[xb][wb]);
-  };
-
-  Cursor cc{jx / nbn, jx % nbn};
-  int em0 = 0, en0 = 0;  // tile whose epilogue is pending
-  // bias registers of the pending tile, asm loads issued at the top of its last compute phase: 16-bit outputs
-  // need the 16 columns of the lane's first block (the second block's are loaded inside the epilogue), the
-  // fp32-row form the 4 + 4 columns the lane owns after the LDS bounce
-  constexpr bool RESID = (EPI == EPI_RESID);
-  f32x4_t bv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  auto bias_issue = [&](int n0) {
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    if constexpr (RESID) {
-      const float* p = a.bias + n0 + wc * 64 + (le & 7) * 4;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[0]) : "v"(p) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[1]) : "v"(p + 32) : "memory");
-    } else {
-      const float* p = a.bias + n0 + wc * 64 + (le >> 5) * 16;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(p + q * 4) : "memory");
-    }
-  };
-  auto epilogue = [&]() {
-    int le = lane;
-    asm volatile("" : "+v"(le));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
-    if (!DBG(4)) {
-      char* win = smem + 2 * STAGE_BYTES + wave * 4096;
-      if constexpr (RESID) {
-        const f32x4_t bvf[2] = {bv[0], bv[1]};
-        wave_epilogue_resid_b32(a, acc, bvf, em0 + wr * 128, en0 + wc * 64, le, win);
-      } else {
-        wave_epilogue16_b32<PREC, EPI>(a, acc, bv, em0 + wr * 128, en0 + wc * 64, le, win, amax);
-      }
-    }
-    zero();
-  };
-  set_issue_tile();
-  {
-    const LaneK lk = lane_consts();
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-      if (i < 4 || !grp) piece(lk, 0, i);
-  }
-  issue_done();
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (grp) {  // waves 4-7 run one phase behind
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  int ktc = 0;
-  bool pend = false;
-  auto phase_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int s = 0; s < total; ++s) {
-    const int sr = s & 1, si = sr ^ 1;
-    const bool split = pend && !grp;
-    int fo0;
-    if (pend) {
-      if (!grp) {
-        const LaneK lk = lane_consts();
-#pragma unroll
-        for (int i = 0; i < 12; ++i) piece(lk, si, i);
-        issue_done();
-        phase_barrier();
-      }
-      epilogue();
-      if (!grp) {
-        const LaneK lk = lane_consts();
-        fo0 = lk.fo0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) readf(lk, sr, i);
-      }
-    }
-    if (!split) {
-      const LaneK lk = lane_consts();
-      fo0 = lk.fo0;
-      if (!grp) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          if (i < 8) {
-            readf(lk, sr, 2 * i);
-            readf(lk, sr, 2 * i + 1);
-          }
-          piece(lk, si, i);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) readf(lk, sr, 4 * i + jj);
-          piece(lk, si, i);
-        }
-      }
-      issue_done();
-    }
-    pin_frags();
-    if (!split) phase_barrier();
-    // ---- compute phase of step s
-    if (ktc == nk - 1 && a.bias) bias_issue(cc.nt * BN);  // covered by the wait that ends this phase
-    __builtin_amdgcn_s_setprio(1);
-    compute(fo0, sr);
-    __builtin_amdgcn_s_setprio(0);
-    wait_vmcnt<0>();  // this wave's pieces of step s+1, issued a phase ago
-    phase_barrier();
-    pend = false;
-    if (++ktc == nk) {
-      ktc = 0;
-      pend = true;
-      em0 = (mt_of(cc.mtl) * 8 + xcd) * BM;
-      en0 = cc.nt * BN;
-      cursor_next(cc);
-    }
-  }
-  if (!grp) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  if (pend) epilogue();
-  if constexpr (!RESID) sat_report<PREC>(amax, a.sat);
-}
-
-
-
 // ---- launchers of the arms ----------------------------------------------------------------------------------------
 template <int PREC, int EPI>
 hipError_t launch_tile_fold(const GemmArgs& a, hipStream_t s) {
@@ -1759,43 +1173,18 @@ hipError_t launch_tile_fold(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((arms::gemm_tile_kernel<PREC, EPI, true>), dim3(nbn * nbm), dim3(256), tile::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-template <int PREC, int EPI, bool CS>
-hipError_t launch_persist(const GemmArgs& a, hipStream_t s) {
-  static PerDeviceFlag attr_set;
-  if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<PREC, EPI, CS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, persist::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set.set();
-  }
-  hipLaunchKernelGGL((gemm_persist_kernel<PREC, EPI, CS>), dim3(persistent_grid()), dim3(512), persist::LDS_BYTES, s, a);
-  return hipGetLastError();
-}
-template <int PREC, int EPI, bool BAL = false, bool STAG = false, bool FOLD = false, bool LNT = false, bool LNC = false>
+template <int PREC, int EPI, bool FOLD = false, bool LNT = false, bool LNC = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT, LNC>,
+    hipError_t e = hipFuncSetAttribute((const void*)arms::gemm_pp_kernel<PREC, EPI, FOLD, LNT, LNC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set.set();
   }
-  hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, BAL, STAG, FOLD, LNT, LNC>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, FOLD, LNT, LNC>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-template <int PREC, int EPI>
-hipError_t launch_pp32(const GemmArgs& a, hipStream_t s) {
-  static PerDeviceFlag attr_set;
-  if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp32_kernel<PREC, EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p256::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set.set();
-  }
-  hipLaunchKernelGGL((gemm_pp32_kernel<PREC, EPI>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
-  return hipGetLastError();
-}
-
 // Routing of a launch to an arm.  Returns true when the launch is the arms' business (`*err` then holds its status),
 // false when the shipped kernels of gemm.hip take it.  v = size_policy(M, N) (with a forced variant already applied).
 template <int PREC, int EPI>
@@ -1808,7 +1197,7 @@ bool route(int& v, const GemmArgs& a, hipStream_t s, hipError_t* err) {
       const bool sides = EPI == EPI_RESID ? (a.fold_z && a.fold_g && a.fold_part && a.bias && !a.fold_rs)
                                           : (a.fold_rs && a.fold_c && a.bias && !a.fold_z);
       if (v == 5 && sides && whole && a.ldo == a.N) {
-        *err = launch_pp<PREC, EPI, false, false, true>(a, s);
+        *err = launch_pp<PREC, EPI, true>(a, s);
       } else if constexpr (EPI <= EPI_GELU) {
         if (v == 0 && sides) *err = launch_tile_fold<PREC, EPI>(a, s);
       }
@@ -1819,7 +1208,7 @@ bool route(int& v, const GemmArgs& a, hipStream_t s, hipError_t* err) {
     if constexpr (EPI == EPI_RESID && PREC != MCM_PREC_F32) {
       if (v == 5 && whole && (a.N == 768 || a.N == 1024) && a.ldo == a.N && a.ln_g && a.ln_b && a.ln_state && a.fold_part && a.bias &&
           a.ln_cap8 >= 2 * ((a.M / p256::BM + 7) / 8) && persistent_grid() % 8 == 0)
-        *err = launch_pp<PREC, EPI, false, false, false, false, true>(a, s);
+        *err = launch_pp<PREC, EPI, false, false, true>(a, s);
     }
     return true;
   }
@@ -1827,23 +1216,14 @@ bool route(int& v, const GemmArgs& a, hipStream_t s, hipError_t* err) {
     if constexpr (EPI == EPI_RESID && PREC != MCM_PREC_F32) {
       if (v == 5 && whole && (a.N == 768 || a.N == 1024) && a.ldo == a.N && a.ln_g && a.ln_b && a.ln_state &&
           a.ln_cap8 * 8 >= a.M / p256::BM && persistent_grid() % 8 == 0)
-        *err = launch_pp<PREC, EPI, false, false, false, true>(a, s);
+        *err = launch_pp<PREC, EPI, false, true>(a, s);
     }
     return true;
   }
 #ifdef MCM_HARNESS
-  if (v == 1) { *err = launch_persist<PREC, EPI, false>(a, s); return true; }
-  if (v == 2) { *err = launch_persist<PREC, EPI, true>(a, s); return true; }
-  if (v == 7 || v == 8 || v == 6 || v == 9) {  // arms of the ping-pong kernel: whole tiles only, else as 5
+  if (v == 9) {  // the flagged text of the ping-pong kernel with every flag off (honours mcm_debug_gemm_group_n): whole tiles, else as 5
     if constexpr (EPI != EPI_PATCH) {
-      if (whole) {
-        if (v == 7) { *err = launch_pp<PREC, EPI, true>(a, s); return true; }          // balanced DMA
-        if (v == 8) { *err = launch_pp<PREC, EPI, false, true>(a, s); return true; }   // staggered epilogues
-        if (v == 9) { *err = launch_pp<PREC, EPI>(a, s); return true; }                // the flagged text with every flag off
-        if constexpr (PREC != MCM_PREC_F32) {
-          if (v == 6 && !a.hm) { *err = launch_pp32<PREC, EPI>(a, s); return true; }   // 32x32x16 MFMAs
-        }
-      }
+      if (whole) { *err = launch_pp<PREC, EPI>(a, s); return true; }
     }
     v = 5;
   }

@@ -300,7 +300,7 @@ int g_qkv_chunks = 1;  // A/B: QKV projection + attention per chunk of the batch
 int g_ln_fold = 0;     // A/B: 1 = LayerNorm fold (mcm_debug_ln_fold); 0 = every LayerNorm as its own launch (shipped)
 #else
 constexpr int g_qkv_chunks = 1;
-#ifdef MCM_LN_FOLD  // A/B build of the shipped library with the fold on (tools/_call.sh: libmcm_hip_fold.so)
+#ifdef MCM_LN_FOLD  // A/B build of the shipped library with the fold on (make fold: libmcm_hip_fold.so, tools/bench_with_lib.py)
 constexpr int g_ln_fold = 1;
 #else
 constexpr int g_ln_fold = 0;
@@ -1437,7 +1437,7 @@ int mcm_debug_qkv_chunks(int32_t n) {
 }
 
 int mcm_debug_gemm_variant(int32_t variant) {
-  if (variant < -1 || (variant > 9 && variant != 11)) return MCM_EINVAL;
+  if (variant != -1 && variant != 0 && variant != 3 && variant != 4 && variant != 5 && variant != 9 && variant != 11) return MCM_EINVAL;
   gemm_set_variant(variant);
   return MCM_OK;
 }

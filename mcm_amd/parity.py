@@ -32,7 +32,7 @@ HEADLINE_PIXELS = dict(amp=1.5, tile=0.0, weights="fp16-exact")
 CONFIG3_OOD_SETS = (("iNaturalist", 10000, 11), ("SUN", 10000, 12), ("places365", 10000, 13), ("dtd", 5640, 14))
 
 
-# A second operating point.  What a random-init tower can be made to give (tools/spread_probe.py,
+# A second operating point.  What a random-init tower can be made to give (tools/spread_probe.py — removed in round 6, git history —,
 # profiles/r04_b_spread_probe.txt): a strong per-class texture (`tile`) widens the per-image score spread from 0.13 % to
 # 0.6 % of |score| (std 1.4e-6 -> 6.5e-6; it saturates there — at T = 1 and K = 1000 the softmax is nearly flat,
 # d score / d cos = 1/K, so even a real checkpoint's cosines spread the score by only a few 1e-5), which puts fp16's

@@ -238,7 +238,7 @@ def test_linear_full_size_variants_bitwise(tiny_net, harness_net, N, K, epi, pre
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (-1, 3, 4, 5, 6, 7, 8, 9):
+        for variant in (-1, 3, 4, 5, 9):
             for _ in range(3):
                 got = run(variant)
                 assert torch.equal(got.view(bits[got.element_size()]), ref.view(bits[ref.element_size()])), \
@@ -362,7 +362,7 @@ def test_linear_l14_shapes_pingpong_bitwise(tiny_net, harness_net, N, K, epi):
     try:
         ref = run(0)
         assert torch.isfinite(ref.float()).all()
-        for variant in (-1, 5, 6, 7, 8):
+        for variant in (-1, 5, 9):
             for _ in range(2):  # mcm_op_linear alternates the walk direction per launch: both get exercised
                 got = run(variant)
                 view = torch.int32 if epi == 2 else torch.int16
@@ -647,7 +647,7 @@ def test_fp16_saturation_counter_in_the_persistent_gemm_kernels(tiny_net, harnes
     ws = w.clone()
     ws[300, :] = 250.0     # 250 * 250 * 128 = 8e6
     try:
-        for variant in (-1, 0, 3, 5, 6, 7, 8):
+        for variant in (-1, 0, 3, 5, 9):
             net = tiny_net if variant < 0 else harness_net
             if variant >= 0:
                 assert net._lib.mcm_debug_gemm_variant(variant) == 0

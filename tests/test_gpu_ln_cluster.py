@@ -69,7 +69,9 @@ def test_ln_cluster_equals_the_layernorm_launches_to_round_off(ckpt, precision, 
         assert float(cos.min()) > 1 - (1e-6 if precision == "fp16" else 1e-4)
         ragged = torch.cat([net.score_images(px[: batch // 2 + 3], txt).clone(),
                             net.score_images(px[batch // 2 + 3:], txt).clone()])
-        assert torch.equal(ragged, first)  # pad rows, other row-tile counts, the same state buffer: rows are independent
+        # pad rows, other row-tile counts, the same state buffer.  (Not bitwise: a sub-batch too small for the ping-pong kernel
+        # takes the LayerNorm LAUNCHES, whose statistics are summed in another order than the cluster's.)
+        assert float((ragged - first).abs().max()) <= tol * float(launched.abs().max())
         assert _timeouts(net) == 0
     finally:
         net._lib.mcm_debug_ln_cluster(0)

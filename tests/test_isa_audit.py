@@ -48,11 +48,11 @@ def gemm_isa_harness(tmp_path_factory):
 
 def _kernel(isa, prec, epi, fold=0, arms=None):
     """The shipped gemm_pp_kernel<PREC, EPI> (gemm.hip) or — with `fold` / `arms` — the flagged text of gemm_arms.hpp:
-    arms::gemm_pp_kernel<PREC, EPI, BAL = false, STAG = false, FOLD = fold, LNT = false>."""
+    arms::gemm_pp_kernel<PREC, EPI, FOLD = fold, LNT = false, LNC = false>."""
     if arms is None:
         arms = bool(fold)
     if arms:
-        pat = r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi%dELb0ELb0ELb%dELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold)
+        pat = r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi%dELb%dELb0ELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi, fold)
     else:
         pat = r"^(_ZN\S*_114gemm_pp_kernelILi%dELi%dEEEv8GemmArgs):\s.*?^\.Lfunc_end" % (prec, epi)
     m = re.search(pat, isa, re.S | re.M)
@@ -105,11 +105,11 @@ def test_pingpong_ln_fold_producer_has_no_scratch_and_only_hand_counted_waits(ge
 
 @pytest.mark.parametrize("prec", [0, 2], ids=["bf16", "fp16"])
 def test_pingpong_residual_kernel_with_the_layernorm_tail_keeps_the_k_loop_clean(gemm_isa_harness, prec):
-    """gemm_pp_kernel<PREC, EPI_RESID, ..., LNT = true> (LayerNorm in the tail): the publication of a finished tile adds a
+    """gemm_pp_kernel<PREC, EPI_RESID, FOLD = false, LNT = true> (LayerNorm in the tail): the publication of a finished tile adds a
     uniform branch and one asm atomic behind the wait that ends a compute phase, the tail itself sits behind the loop —
     the K loop must look exactly like the plain residual kernel's: no scratch, 64 MFMAs, no wait between the LDS-DMA
     issues and the MFMAs, and up to the last MFMA only the hand-written waits."""
-    m = re.search(r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi2ELb0ELb0ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
+    m = re.search(r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi2ELb0ELb1ELb0EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
                   re.S | re.M)
     assert m, "LNT kernel not found"
     lines = m.group(0).splitlines()
@@ -123,6 +123,29 @@ def test_pingpong_residual_kernel_with_the_layernorm_tail_keeps_the_k_loop_clean
     plain_mfma = [i for i, l in enumerate(plain) if "v_mfma_f32_16x16x32" in l]
     waits = lambda ls, end: [l.strip() for l in ls[:end] if "s_waitcnt vmcnt" in l]  # noqa: E731
     assert waits(lines, mfma[-1]) == waits(plain, plain_mfma[-1])
+
+
+@pytest.mark.parametrize("prec", [0, 2], ids=["bf16", "fp16"])
+def test_pingpong_residual_kernel_with_the_cluster_layernorm_keeps_the_k_loop_clean(gemm_isa_harness, prec):
+    """gemm_pp_kernel<PREC, EPI_RESID, false, false, LNC = true> (round 6: the LayerNorm written by the residual epilogue from the
+    accumulator registers).  Its epilogue holds the 128 accumulators live from the residual add to the LayerNorm store, which
+    first cost the K loop its fragment offset (spilled, reloaded in the compute phase behind a vmcnt(0) that drains the LDS-DMA
+    stream) — cured by fetching the epilogue's kernel arguments inside it and by deriving its late addresses from a fresh
+    lane-id copy.  Held here: no scratch access from the LDS-DMA issues of a K-step to its last MFMA, no wait between the DMA
+    issues and the MFMAs, 64 MFMAs, and whatever is still spilled (a lane id, the saturation watch) is touched on the
+    tile-boundary path only: at most 12 scratch instructions in the whole kernel."""
+    m = re.search(r"^(_ZN\S*4arms14gemm_pp_kernelILi%dELi2ELb0ELb0ELb1EEEv8GemmArgs):\s.*?^\.Lfunc_end" % prec, gemm_isa_harness,
+                  re.S | re.M)
+    assert m, "LNC kernel not found"
+    lines = m.group(0).splitlines()
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32" in l]
+    dma = [i for i, l in enumerate(lines) if "global_load_lds_dwordx4" in l]
+    assert len(mfma) == 64
+    start = max(i for i in dma if i < mfma[0])
+    hot = lines[start - 150:mfma[-1] + 1]
+    assert not any("scratch_" in l for l in hot), [l for l in hot if "scratch_" in l]
+    assert not any("s_waitcnt vmcnt" in l for l in lines[start:mfma[0]])
+    assert sum("scratch_" in l for l in lines) <= 12
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2], ids=["bf16", "fp32", "fp16"])
