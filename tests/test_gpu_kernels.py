@@ -108,9 +108,8 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[-1, 0, 2, 4, 5, 6, 7, 8, 9, 11], ids=["shipped-policy", "tile128", "persist256x128", "persist256x256",
-                                                          "pingpong256x256", "pingpong256x256-mfma32", "pingpong256x256-balanced",
-                                                          "pingpong256x256-staggered", "pingpong256x256-arms-text", "tile64"])
+@pytest.fixture(params=[-1, 0, 4, 5, 9, 11], ids=["shipped-policy", "tile128", "persist256x256", "pingpong256x256",
+                                                  "pingpong256x256-arms-text", "tile64"])   # (arms 1/2/6/7/8 left the tree in round 6)
 def gemm_net(request, tiny_net, harness_net):
     """Every GEMM kernel variant must pass the same parity cases (the shipped policy picks by problem size, so
     small test shapes would otherwise only exercise the tile kernel).  -1 = the shipped library as is; the
@@ -163,7 +162,7 @@ def test_linear(gemm_net, M, N, K, prec, epi):
                                    (300, 256, 128), (1, 512, 256), (700, 768, 768), (129, 256, 3072)])
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-@pytest.mark.parametrize("pp_variant", [5, 6, 7, 8], ids=["mfma16", "mfma32", "balanced-dma", "staggered-epilogues"])
+@pytest.mark.parametrize("pp_variant", [5, 9], ids=["shipped-text", "arms-text"])   # (mfma32 / balanced-dma / staggered: removed in round 6)
 def test_linear_pingpong_interior_shapes_vs_oracle(harness_net, M, N, K, prec, epi, pp_variant):
     tiny_net = harness_net
     """The ping-pong 256x256 kernel only takes problems made of whole tiles, so it gets its own oracle cases:
