@@ -54,7 +54,8 @@ LINE_LIMIT = 4096           # bytes of the printed line (a 33.6 KB l
 HARNESS_KEYS = {"gemm_variant": "mcm_debug_gemm_variant", "attn_variant": "mcm_debug_attention_variant",
                 "ln_fold": "mcm_debug_ln_fold", "ln_tail": "mcm_debug_ln_tail", "ln_cluster": "mcm_debug_ln_cluster", "patch_fold": "mcm_debug_patch_fold",
                 "group_n": "mcm_debug_gemm_group_n", "nsplit": "mcm_debug_nsplit", "qkv_chunks": "mcm_debug_qkv_chunks",
-                "gemm_dbg": "mcm_debug_gemm_dbg", "persistent_grid": "mcm_debug_persistent_grid"}
+                "gemm_dbg": "mcm_debug_gemm_dbg", "persistent_grid": "mcm_debug_persistent_grid",
+                "ln_cluster_spin": "mcm_debug_ln_cluster_spin"}
 
 
 def _r(x, sig=5):
@@ -88,6 +89,9 @@ def short_line(d):
     for k in ("harness", "note"):
         if d.get(k):
             line[k] = str(d[k])[:160]
+    for k in ("lnc_timeouts", "lnc_deferred_segments"):
+        if k in d:
+            line[k] = d[k]
     if d.get("kernel_faults"):
         line["kernel_faults"] = d["kernel_faults"]
     if d.get("per_rank"):   # N > 1: one compact record per rank — own images/s in the timed region, own sustained clock and power
@@ -469,6 +473,12 @@ def main():
         }
         if args.harness_kv:
             line["harness"] = f"libmcm_hip_harness.so with {args.harness} forced: an A/B run, not the shipped policy"
+            if args.harness_kv.get("ln_cluster"):   # the LNC arm's own counters: waits that gave up, segments left to the clean-up launch
+                import ctypes
+                for key, fn in (("lnc_timeouts", "mcm_debug_ln_tail_timeouts"), ("lnc_deferred_segments", "mcm_debug_ln_cluster_deferred")):
+                    n = ctypes.c_uint64(0)
+                    if getattr(net._lib, fn)(net._h, ctypes.byref(n)) == 0:
+                        line[key] = int(n.value)
         if args.graph:
             line["hip_graph"] = "every step is one replay of a captured hipGraph (mcm_amd.engine.GraphedScorer)"
         if args.idle_ms >= 0:

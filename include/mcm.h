@@ -471,6 +471,12 @@ int mcm_debug_ln_tail(int32_t on);
  * (Chan-combined slot moments instead of whole-row two-pass statistics), not bit for bit.  0 (default) = shipped behaviour.
  * Waits that gave up are counted by mcm_debug_ln_tail_timeouts. */
 int mcm_debug_ln_cluster(int32_t on);
+/* LNC, second form (R6.4): polls < 0 (default) = a wave WAITS for its row panel's partner workgroups (the first form); polls >= 0 =
+ * the DEFER form: after that many polls of the partners' counter a wave leaves its 128 x 64 segment's LayerNorm to a clean-up
+ * launch behind the GEMM (one mask word per panel half says which segments are owed; same arithmetic, same bits) and goes on
+ * to its next tile.  mcm_debug_ln_cluster_deferred: segments normalised by the clean-up launches since mcm_create. */
+int mcm_debug_ln_cluster_spin(int32_t polls);
+int mcm_debug_ln_cluster_deferred(mcm_handle* h, uint64_t* count_host);
 /* Tickets of the LayerNorm tail that gave up waiting for their rows (a bounded spin: wrong rows rather than a hung
  * device); 0 in a correct run.  Synchronises the device. */
 int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host);

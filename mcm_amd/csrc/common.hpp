@@ -284,6 +284,9 @@ struct GemmArgs {
   // workgroups through a counter in ln_state, combines the N / 64 slot moments of its rows and writes the LayerNorm output
   // from registers: no LayerNorm launch and no re-read of the residual stream.  0 = off (the shipped library never sets it).
   int lnc;
+  // LNC, defer form (R6.4): polls of the partners' counter a wave spends before it leaves its segment's LayerNorm to
+  // launch_lnc_cleanup (which the caller must then launch behind the GEMM); < 0 = the first form: wait (bounded, counted)
+  int lnc_spin;
 };
 // head-major rows of a 16-bit output as the kernels see them: the shipped library never sets GemmArgs::hm (an A/B arm of
 // the harness library), so outside -DMCM_HARNESS builds the layout tests fold away at compile time
@@ -316,6 +319,10 @@ hipError_t launch_fold_rows(int prec, const float* x, const float* gamma, void* 
 // LayerNorm fold, row side: partial moments [slots][M] -> (rstd, mean * rstd) [M]
 hipError_t launch_fold_stats(const float2* part, int slots, int M, int D, float eps, float2* rs, hipStream_t s);
 #ifdef MCM_HARNESS  // tools/gemm_bench.hip and libmcm_hip_harness.so only
+// LNC defer form: the segments (128 rows x 64 columns) whose LayerNorm the residual GEMM's waves left behind — read from the
+// masks in ln_state, normalised from x and the published slot moments with the in-kernel arithmetic (same bits), masks zeroed
+hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const float* b, void* y, const float2* part, int M, int D,
+                              float eps, unsigned int* ln_state, int ln_rs, int ln_cap8, hipStream_t s, unsigned int* sat);
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 8: see gemm.hip

@@ -1427,6 +1427,12 @@ constexpr int g_group_n = 0, g_dbg = 0;
 // kernel, whole tiles, rows of at most 1024 columns); the host then does not launch the LayerNorm that follows
 #ifdef MCM_HARNESS
 void gemm_set_persistent_grid(int n) { g_grid_override = n; }
+hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const float* b, void* y, const float2* part, int M, int D,
+                              float eps, unsigned int* ln_state, int ln_rs, int ln_cap8, hipStream_t s, unsigned int* sat) {
+  if (prec == MCM_PREC_F16) return arms::launch_lnc_cleanup_p<MCM_PREC_F16>(x, g, b, y, part, M, D, eps, ln_state, ln_rs, ln_cap8, s, sat);
+  if (prec == MCM_PREC_BF16) return arms::launch_lnc_cleanup_p<MCM_PREC_BF16>(x, g, b, y, part, M, D, eps, ln_state, ln_rs, ln_cap8, s, sat);
+  return hipErrorInvalidValue;
+}
 #endif
 int gemm_persistent_grid() { return persistent_grid(); }  // workgroups of the persistent kernels (one per CU, multiple of 8)
 bool gemm_ln_tail_ok(int prec, int M, int N) {

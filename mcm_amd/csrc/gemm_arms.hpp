@@ -628,14 +628,28 @@ struct LncArgs {   // the epilogue's own copy of what it needs of GemmArgs
   void* ln_y;
   float2* fold_part;
   float ln_eps;
-  int M, N, ldo, ln_cap8;
+  int M, N, ldo, ln_cap8, spin;
 };
 __device__ __forceinline__ LncArgs lnc_args() {
   LncArgs r;
   r.bias = LNC_ARG(bias); r.ln_g = LNC_ARG(ln_g); r.ln_b = LNC_ARG(ln_b); r.resid = LNC_ARG(resid); r.ln_y = LNC_ARG(ln_y);
   r.fold_part = LNC_ARG(fold_part); r.ln_eps = LNC_ARG(ln_eps); r.M = LNC_ARG(M); r.N = LNC_ARG(N); r.ldo = LNC_ARG(ldo);
-  r.ln_cap8 = LNC_ARG(ln_cap8);
+  r.ln_cap8 = LNC_ARG(ln_cap8); r.spin = LNC_ARG(lnc_spin);
   return r;
+}
+// one slot's (sum, centred sum of squares) joins the running (n, mean, M2) of a row (Chan et al.) — written out with contraction
+// off: the in-kernel statistics (lnc_row_stats) and the clean-up kernel's (lnc_cleanup_kernel) must agree to the bit, whichever
+// of the two normalises a segment
+__device__ __forceinline__ void chan_join(float n, float& m, float& q, float sum, float m2) {
+#pragma clang fp contract(off)
+  const float w = 64.0f / (n + 64.0f);          // weight of the new slot in the union
+  const float d = sum * (1.0f / 64.0f) - m;
+  q = q + (m2 + (d * d) * (n * w));
+  m = m + d * w;
+}
+__device__ __forceinline__ float chan_rstd(float q, float n, float eps) {
+#pragma clang fp contract(off)
+  return 1.0f / sqrtf(q / n + eps);
 }
 template <int PREC, int NS>
 __device__ __forceinline__ void lnc_row_stats(const LncArgs& a, int mw, int lane, char* scratch) {
@@ -653,16 +667,12 @@ __device__ __forceinline__ void lnc_row_stats(const LncArgs& a, int mw, int lane
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       asm volatile("" : "+v"(p[j]));
-      const float w = 64.0f / (n + 64.0f);          // weight of the new slot in the union
-      const float d0 = p[j][0] * (1.0f / 64.0f) - m0, d1 = p[j][2] * (1.0f / 64.0f) - m1;
-      q0 += p[j][1] + d0 * d0 * (n * w);
-      q1 += p[j][3] + d1 * d1 * (n * w);
-      m0 += d0 * w;
-      m1 += d1 * w;
+      chan_join(n, m0, q0, p[j][0], p[j][1]);
+      chan_join(n, m1, q1, p[j][2], p[j][3]);
       n += 64.0f;
     }
   }
-  const f32x4_t st = {m0, 1.0f / sqrtf(q0 / n + a.ln_eps), m1, 1.0f / sqrtf(q1 / n + a.ln_eps)};
+  const f32x4_t st = {m0, chan_rstd(q0, n, a.ln_eps), m1, chan_rstd(q1, n, a.ln_eps)};
   *(f32x4_t*)(scratch + lane * 16) = st;   // row r of the wave's 128: (mean, rstd) at scratch + 8 r
 }
 template <int PREC, int MF>
@@ -744,7 +754,7 @@ __device__ __forceinline__ void wave_epilogue_resid_lnc(f32x4_t (&acc)[4][MF], i
   // ---- B: publish this wave's moments, wait for the rest of the row panel's half
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) l2_atomic_add(reg, ctr_off, 1u);
-  {
+  if (a.spin < 0) {  // the first form (R6.3): wait for the partners however long it takes
     int spins = 0;
     while (wave_l2_add_ret(reg, ctr_off, 0u, lane) < need) {
       __builtin_amdgcn_s_sleep(2);
@@ -753,6 +763,22 @@ __device__ __forceinline__ void wave_epilogue_resid_lnc(f32x4_t (&acc)[4][MF], i
         break;
       }
     }
+  } else {
+    // DEFER form (R6.4): poll at most a.spin times; a wave whose partners are not there yet (a panel whose tiles straddle two
+    // rounds of the grid: 32 workgroups per XCD, 3 tiles per panel — or plain skew) does not wait: it leaves its 128 x 64
+    // segment to lnc_cleanup_kernel, which finds the segment's bit missing in the panel half's mask, and goes on to its next
+    // tile.  x and the moments are in memory already (A, B); only the LayerNorm output of the segment is owed.
+    int spins = 0;
+    bool ready;
+    for (;;) {
+      ready = wave_l2_add_ret(reg, ctr_off, 0u, lane) >= need;
+      if (ready || spins >= a.spin) break;
+      ++spins;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ready) return;
+    if (lane == 0)
+      asm volatile("global_atomic_or %0, %1, %2" ::"v"(ctr_off + (uint32_t)(a.ln_cap8 + 3) * 4u), "v"(1u << (nw >> 6)), "s"(reg) : "memory");
   }
   asm volatile("buffer_inv sc1" ::: "memory");
   // ---- C: (mean, rstd) of the wave's 128 rows into its LDS window; gamma / beta of the lane's 4 columns.  Every lane-derived
@@ -1185,6 +1211,87 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((arms::gemm_pp_kernel<PREC, EPI, FOLD, LNT, LNC>), dim3(persistent_grid()), dim3(512), p256::LDS_BYTES, s, a);
   return hipGetLastError();
 }
+// LNC defer form: one 4-wave workgroup per (XCD, row panel, half).  Reads the half's mask (bit = 64-column slot whose LayerNorm
+// was written from registers), zeroes it, and — almost always — exits.  Otherwise: (mean, rstd) of the 128 rows from the slot
+// moments (chan_join / chan_rstd: the in-kernel arithmetic), then the missing segments, dealt to the four waves: x from memory
+// (the values the accumulators held), ((v - mean) rstd) gamma + beta with contraction off as in pass D, packed, stored.
+// ln_state word 2 * ln_cap8 + 3 of the XCD's region counts the segments done here (sticky: mcm_debug_ln_cluster_deferred).
+template <int PREC, int NS>
+__global__ __launch_bounds__(256) void lnc_cleanup_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ b, void* __restrict__ y,
+                                                          const float2* __restrict__ part, int M, float eps,
+                                                          unsigned int* state, int ln_rs, int ln_cap8, unsigned int* sat) {
+  enter_precision_mode<PREC>();
+  constexpr int D = NS * 64;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int m0 = ((idx >> 1) * 8 + xcd) * 256 + (idx & 1) * 128;
+  if (m0 >= M) return;
+  unsigned int* reg = state + (size_t)xcd * ln_rs;
+  __shared__ unsigned int smask;
+  __shared__ float2 st[128];
+  if (threadIdx.x == 0) {
+    smask = reg[ln_cap8 + 3 + idx];
+    reg[ln_cap8 + 3 + idx] = 0u;
+  }
+  __syncthreads();
+  const unsigned int miss = ~smask & ((1u << NS) - 1u);
+  if (!miss) return;
+  if (threadIdx.x < 128) {
+    const int r = threadIdx.x;
+    float n = 0.f, m = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const float2 pj = part[(size_t)j * M + m0 + r];
+      chan_join(n, m, q, pj.x, pj.y);
+      n += 64.0f;
+    }
+    st[r] = make_float2(m, chan_rstd(q, n, eps));
+  }
+  if (threadIdx.x == 0) atomicAdd(reg + 2 * ln_cap8 + 3, (unsigned int)__popc(miss));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rr = lane >> 4, c4 = (lane & 15) * 4;
+  float amax = 0.f;
+  int k = 0;
+  for (int sg = 0; sg < NS; ++sg) {
+    if (!((miss >> sg) & 1u)) continue;
+    if ((k++ & 3) != wave) continue;
+    const int c0 = sg * 64 + c4;
+    const float4 gv = *(const float4*)(g + c0), bv = *(const float4*)(b + c0);
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const int r = i * 4 + rr;
+      const float4 v = *(const float4*)(x + (size_t)(m0 + r) * D + c0);
+      const float2 s2 = st[r];
+      float4 o;
+      {
+#pragma clang fp contract(off)
+        o.x = __builtin_fmaf((v.x - s2.x) * s2.y, gv.x, bv.x);
+        o.y = __builtin_fmaf((v.y - s2.x) * s2.y, gv.y, bv.y);
+        o.z = __builtin_fmaf((v.z - s2.x) * s2.y, gv.z, bv.z);
+        o.w = __builtin_fmaf((v.w - s2.x) * s2.y, gv.w, bv.w);
+      }
+      sat_track<PREC>(amax, o.x, o.y);
+      sat_track<PREC>(amax, o.z, o.w);
+      uint2 pk;
+      pk.x = pack2<PREC>(o.x, o.y);
+      pk.y = pack2<PREC>(o.z, o.w);
+      *(uint2*)((uint16_t*)y + (size_t)(m0 + r) * D + c0) = pk;
+    }
+  }
+  sat_report<PREC>(amax, sat);
+}
+template <int PREC>
+hipError_t launch_lnc_cleanup_p(const float* x, const float* g, const float* b, void* y, const float2* part, int M, int D, float eps,
+                                unsigned int* ln_state, int ln_rs, int ln_cap8, hipStream_t s, unsigned int* sat) {
+  const int idxs = 2 * ((M / 256 + 7) / 8);  // (panel, half) pairs per XCD region
+  if (M % 256 || idxs > ln_cap8 || ln_rs < 2 * ln_cap8 + 4) return hipErrorInvalidValue;
+  if (D == 768) hipLaunchKernelGGL((lnc_cleanup_kernel<PREC, 12>), dim3(8 * idxs), dim3(256), 0, s, x, g, b, y, part, M, eps, ln_state, ln_rs, ln_cap8, sat);
+  else if (D == 1024) hipLaunchKernelGGL((lnc_cleanup_kernel<PREC, 16>), dim3(8 * idxs), dim3(256), 0, s, x, g, b, y, part, M, eps, ln_state, ln_rs, ln_cap8, sat);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // Routing of a launch to an arm.  Returns true when the launch is the arms' business (`*err` then holds its status),
 // false when the shipped kernels of gemm.hip take it.  v = size_policy(M, N) (with a forced variant already applied).
 template <int PREC, int EPI>

@@ -328,13 +328,15 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
 #ifdef MCM_HARNESS
 int g_ln_tail = 0;  // mcm_debug_ln_tail
 int g_ln_cluster = 0;  // mcm_debug_ln_cluster: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp "LNC", round 6)
+int g_lnc_spin = -1;   // mcm_debug_ln_cluster_spin: < 0 the first form (wait for the partners); n >= 0 the defer form: n polls, then
+                       // the segment is left to launch_lnc_cleanup behind the GEMM
 #elif defined(MCM_LN_TAIL)  // A/B build of the shipped library with the tail on
 constexpr int g_ln_tail = 1;
 #else
 constexpr int g_ln_tail = 0;
 #endif
 #ifndef MCM_HARNESS
-constexpr int g_ln_cluster = 0;
+constexpr int g_ln_cluster = 0, g_lnc_spin = -1;
 #endif
 // The tail's coherence argument needs every workgroup with the same blockIdx & 7 on the same XCD (one L2).  That is
 // how the dispatcher deals workgroups in the default (SPX) mode; it is checked on the device, once per handle, with
@@ -417,7 +419,19 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   auto with_tail = [&](GemmArgs& g, const float* gamma, const float* beta) {
     g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
     g.ln_state = h->ln_state; g.ln_rs = h->ln_rs; g.ln_cap8 = h->ln_cap8;
-    if (cluster_ok) { g.lnc = 1; g.fold_part = h->fold_part; }
+    if (cluster_ok) { g.lnc = 1; g.fold_part = h->fold_part; g.lnc_spin = g_lnc_spin; }
+  };
+  // LNC defer form: the clean-up launch behind a residual GEMM that ran with GemmArgs::lnc (a few hundred workgroups that read one
+  // mask word and exit, plus the segments the GEMM's waves did not wait for)
+  auto lnc_cleanup = [&](const float* gamma, const float* beta) -> hipError_t {
+#ifdef MCM_HARNESS
+    if (!cluster_ok || g_lnc_spin < 0) return hipSuccess;
+    Scope sc(h, s, MCM_KC_LAYERNORM, 8.0 * Mp * D);
+    return launch_lnc_cleanup(P, h->x, gamma, beta, h->ln, h->fold_part, Mp, D, h->cfg.ln_eps, h->ln_state, h->ln_rs, h->ln_cap8, s,
+                              h->sat_on ? h->sat_dev : nullptr);
+#else
+    return hipSuccess;
+#endif
   };
   const bool tail_ok = tail_ok0 || cluster_ok;   // either arm: the residual GEMM also produces the LayerNorm behind it
   bool ln1_by_tail = false;  // h->ln already holds this layer's layer_norm1 (written by the previous layer's fc2)
@@ -466,6 +480,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     } else if (tail_ok && !cls) {
       with_tail(o, w.ln2w, w.ln2b);  // layer_norm2 by the out-proj kernel's idle waves
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
+      HIP_TRY(h, lnc_cleanup(w.ln2w, w.ln2b));
     } else {
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
       if (!cls) HIP_TRY(h, lnorm(h, s, P, h->x, w.ln2w, w.ln2b, h->ln, M, D, false, x2));
@@ -489,6 +504,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
         ln1_by_tail = true;
       }
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
+      if (ln1_by_tail) HIP_TRY(h, lnc_cleanup(t.L[l + 1].ln1w, t.L[l + 1].ln1b));
     }
   }
   return MCM_OK;
@@ -671,7 +687,8 @@ int mcm_create(const mcm_config* cfg, mcm_handle** out) {
 #if defined(MCM_HARNESS) || defined(MCM_LN_TAIL)  // LayerNorm in the tail (A/B arm): its counters, if the device qualifies
   if (!rc && c.precision != MCM_PREC_F32 && (c.v_width == 768 || c.v_width == 1024) && xcd_round_robin(h, gemm_persistent_grid())) {
     h->ln_cap8 = 2 * (int)((mv / 256 + 7) / 8);  // (x 2: the cluster arm counts the upper and lower half of a row panel separately)
-    h->ln_rs = (h->ln_cap8 + 3 + 63) / 64 * 64;  // words per XCD region: whole 256-B blocks, no line shared between XCDs
+    h->ln_rs = (2 * h->ln_cap8 + 4 + 63) / 64 * 64;  // words per XCD region: whole 256-B blocks, no line shared between XCDs
+                                                     // ([cap8] counters, 3 words, [cap8] segment masks + 1 word of the LNC defer form)
     const size_t bytes = (size_t)8 * h->ln_rs * sizeof(unsigned int);
     rc = dev_alloc(h, (void**)&h->ln_state, bytes);
     if (!rc && hipMemset(h->ln_state, 0, bytes) != hipSuccess) rc = fail(h, MCM_EHIP, "hipMemset LayerNorm-tail state");
@@ -1389,6 +1406,22 @@ int mcm_debug_ln_tail(int32_t on) {  // 1: LayerNorm in the tail of the residual
 }
 int mcm_debug_ln_cluster(int32_t on) {  // 1: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp LNC); 0 (shipped behaviour): LayerNorm launches
   g_ln_cluster = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_ln_cluster_spin(int32_t polls) {  // < 0: the first LNC form (waits); n >= 0: the defer form with n polls (and the clean-up launch)
+  g_lnc_spin = polls < 0 ? -1 : polls;
+  return MCM_OK;
+}
+int mcm_debug_ln_cluster_deferred(mcm_handle* h, uint64_t* count_host) {  // segments the clean-up kernel normalised since mcm_create
+  if (!h || !count_host) return MCM_EINVAL;
+  *count_host = 0;
+  if (!h->ln_state) return MCM_OK;
+  HIP_TRY(h, hipDeviceSynchronize());
+  for (int x = 0; x < 8; ++x) {
+    unsigned int v = 0;
+    HIP_TRY(h, hipMemcpy(&v, h->ln_state + (size_t)x * h->ln_rs + 2 * h->ln_cap8 + 3, sizeof(v), hipMemcpyDeviceToHost));
+    *count_host += v;
+  }
   return MCM_OK;
 }
 int mcm_debug_ln_tail_timeouts(mcm_handle* h, uint64_t* count_host) {  // tickets that gave up waiting (0 in a correct run)

@@ -98,3 +98,48 @@ def test_ln_cluster_in_a_long_run():
     finally:
         net._lib.mcm_debug_ln_cluster(0)
         net.close()
+
+
+def _deferred(net):
+    n = ctypes.c_uint64(0)
+    assert net._lib.mcm_debug_ln_cluster_deferred(net._h, ctypes.byref(n)) == 0
+    return n.value
+
+
+@pytest.mark.parametrize("ckpt,precision,batch", [("ViT-B/16", "fp16", 512), ("ViT-B/16", "bf16", 160), ("ViT-L/14", "fp16", 64)])
+def test_ln_cluster_defer_form_same_bits_as_the_waiting_form(ckpt, precision, batch):
+    """The defer form (mcm_debug_ln_cluster_spin >= 0, R6.4): a wave whose partners have not published within the poll budget
+    leaves its 128 x 64 segment to the clean-up launch, which normalises it from x and the slot moments with the in-kernel
+    arithmetic.  Which segments are deferred depends on timing, the bits must not: budgets 0 (defer whatever is not ready at once),
+    4 and 64 against the waiting form, repeated; with budget 0 segments ARE deferred (otherwise the clean-up path went untested);
+    the masks are left zeroed (a later waiting-form run and the LayerNorm launches still agree)."""
+    geo = geometry(ckpt)
+    sd = _affine_state(geo)
+    ids, _ = make_token_ids(40, seed=2)
+    net = NativeCLIP(geo, sd, device=0, precision=precision, max_batch=batch, max_prompt_tokens=40 * 20, harness=True, weight_operands="single")
+    try:
+        txt = net.get_text_features(input_ids=torch.from_numpy(ids), normalize=True)
+        g = torch.Generator(device="cuda").manual_seed(17)
+        px = torch.randn((batch, 3, geo.image_size, geo.image_size), generator=g, device="cuda")
+        assert net._lib.mcm_debug_ln_cluster(1) == 0
+        assert net._lib.mcm_debug_ln_cluster_spin(-1) == 0
+        waited = net.score_images(px, txt, 1.0, "MCM").clone()
+        assert _deferred(net) == 0
+        seen = {}
+        for budget in (0, 4, 64, 0):
+            assert net._lib.mcm_debug_ln_cluster_spin(budget) == 0
+            before = _deferred(net)
+            for _ in range(3):
+                got = net.score_images(px, txt, 1.0, "MCM").clone()
+                assert torch.equal(got, waited), f"budget {budget}"
+            seen[budget] = _deferred(net) - before
+        print(f"{ckpt} {precision} batch {batch}: segments deferred per 3 passes by poll budget {seen}")
+        assert seen[0] > 0
+        assert net._lib.mcm_debug_ln_cluster_spin(-1) == 0
+        assert torch.equal(net.score_images(px, txt, 1.0, "MCM"), waited)
+        torch.cuda.synchronize()
+        assert _timeouts(net) == 0 and net.kernel_faults == 0
+    finally:
+        net._lib.mcm_debug_ln_cluster_spin(-1)
+        net._lib.mcm_debug_ln_cluster(0)
+        net.close()
