@@ -95,7 +95,7 @@ def process_args(argv=None):
     p.add_argument("--full-round-batch", action="store_true",
                    help="raise --batch-size to the next batch (within 4 x) at which every vision GEMM fills its last tile round of "
                         "the persistent grid on this device (mcm_amd.config.ClipGeometry.full_round_batches; ViT-B/16 on 256 CUs: "
-                        "512 -> 665; ViT-L/14: 256 -> 318, +4 %% images/sec; the chosen batch, or that there is none, is logged).  "
+                        "512 -> 665, +2.6 ... 3.2 %% images/sec; ViT-L/14: 256 -> 318; the chosen batch, or that there is none, is logged).  "
                         "Scores do not depend on the batch they were computed in")
     args = p.parse_args(argv)
     if args.decoder:
