@@ -55,7 +55,7 @@ HARNESS_KEYS = {"gemm_variant": "mcm_debug_gemm_variant", "attn_variant": "mcm_d
                 "ln_fold": "mcm_debug_ln_fold", "ln_tail": "mcm_debug_ln_tail", "ln_cluster": "mcm_debug_ln_cluster", "patch_fold": "mcm_debug_patch_fold",
                 "group_n": "mcm_debug_gemm_group_n", "nsplit": "mcm_debug_nsplit", "qkv_chunks": "mcm_debug_qkv_chunks",
                 "gemm_dbg": "mcm_debug_gemm_dbg", "persistent_grid": "mcm_debug_persistent_grid",
-                "ln_cluster_spin": "mcm_debug_ln_cluster_spin"}
+                "ln_cluster_spin": "mcm_debug_ln_cluster_spin", "ln_row": "mcm_debug_ln_row"}
 
 
 def _r(x, sig=5):

@@ -323,6 +323,9 @@ hipError_t launch_fold_stats(const float2* part, int slots, int M, int D, float 
 // masks in ln_state, normalised from x and the published slot moments with the in-kernel arithmetic (same bits), masks zeroed
 hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const float* b, void* y, const float2* part, int M, int D,
                               float eps, unsigned int* ln_state, int ln_rs, int ln_cap8, hipStream_t s, unsigned int* sat);
+// ROW64 arm (gemm_arms.hpp, R6.7): out-proj / fc2 as 64-row FULL-ROW tiles whose epilogue writes x and the LayerNorm output
+// (GemmArgs: x, w, bias, resid, M % 64 == 0, N in {768, 1024} = ldo, K, ldx, ln_g, ln_b, ln_y, ln_eps, sat)
+hipError_t launch_gemm_row64_ln(int prec, const GemmArgs& a, hipStream_t s, int stages);   // stages: W stages per wave, 2 or 3
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 8: see gemm.hip

@@ -1433,6 +1433,11 @@ hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const fl
   if (prec == MCM_PREC_BF16) return arms::launch_lnc_cleanup_p<MCM_PREC_BF16>(x, g, b, y, part, M, D, eps, ln_state, ln_rs, ln_cap8, s, sat);
   return hipErrorInvalidValue;
 }
+hipError_t launch_gemm_row64_ln(int prec, const GemmArgs& a, hipStream_t s, int stages) {
+  if (prec == MCM_PREC_F16) return arms::launch_row64_ln_p<MCM_PREC_F16>(a, s, stages);
+  if (prec == MCM_PREC_BF16) return arms::launch_row64_ln_p<MCM_PREC_BF16>(a, s, stages);
+  return hipErrorInvalidValue;
+}
 #endif
 int gemm_persistent_grid() { return persistent_grid(); }  // workgroups of the persistent kernels (one per CU, multiple of 8)
 bool gemm_ln_tail_ok(int prec, int M, int N) {

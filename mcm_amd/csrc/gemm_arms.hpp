@@ -581,8 +581,8 @@ __device__ __forceinline__ void ln_finish(const GemmArgs& a, int xcd, char* smem
 // LayerNorm by the row panel's cluster (LNC; round 6; EPI_RESID, 16-bit operand modes, N = 768 / 1024).
 // VERDICT r5 item 2 asked for the one design that removes LayerNorm's own re-read of the residual stream: a FULL-ROW
 // (BN = N) residual-GEMM epilogue that emits the LayerNorm output from registers.  A 256 x 768 register tile does not
-// exist on this part (384 KB of accumulators per CU; a 64- or 128-row full-row tile re-stages all of W per 64 / 128
-// rows and no longer double-buffers: EXPERIMENTS.md R6.2), but the full-row TILE does — spread over the N / 256
+// exist on this part (768 KB of accumulators against a 512-KB register file; a 128-row full-row tile needs 192 accumulator registers; the 64-row
+// one was built and measured, ROW64 below / EXPERIMENTS.md R6.7: -21 %), but the full-row TILE does — spread over the N / 256
 // workgroups that hold the tiles of one 256-row panel.  They sit on ONE XCD (row tile = mt * 8 + xcd) and are walked
 // n-fastest, i.e. by consecutive workgroups of the same round, so they finish within a few microseconds of each other.
 // The K loop is untouched; the epilogue of a wave (128 rows x 64 columns) becomes
@@ -1290,6 +1290,211 @@ hipError_t launch_lnc_cleanup_p(const float* x, const float* g, const float* b, 
   else if (D == 1024) hipLaunchKernelGGL((lnc_cleanup_kernel<PREC, 16>), dim3(8 * idxs), dim3(256), 0, s, x, g, b, y, part, M, eps, ln_state, ln_rs, ln_cap8, sat);
   else return hipErrorInvalidValue;
   return hipGetLastError();
+}
+
+// =========================================================================================
+// ROW64 (round 6, EXPERIMENTS.md R6.7): the LITERAL full-row tile of VERDICT r5 item 2 — BM = 64 rows x BN = N (768 / 1024)
+// in ONE workgroup, so that the residual GEMM's epilogue owns whole rows: (acc + bias) + resid -> x (written once), exact
+// two-pass row statistics over the workgroup's 8 waves, LayerNorm written from the accumulator registers.  No LayerNorm
+// launch, no re-read of x, no cross-workgroup traffic at all (LNC's cost).  Built to be MEASURED (R6.7: -21.5 %, TA-bound K loop);
+// 8 waves side by side, wave w = columns [w N/8, (w+1) N/8) of all 64 rows: 4 x FW accumulator tiles (96 / 128 registers).
+// K-step = 32 elements (64 B per row): W is wave-PRIVATE (only wave w reads W rows [w N/8, ...)), double-buffered per wave by
+// LDS-DMA and waited for with the wave's own vmcnt — no barrier; X (64 rows, shared) is staged XG K-steps at a time by waves
+// 0 - 3, one barrier per XG K-steps.  LDS piece = 16 rows x 64 B; the 16-byte chunk c of row r sits at slot c ^ ((r >> 2) & 3)
+// (applied to the lane's global source address, the DMA destination is lane-linear), so a fragment read — lane (fr, g) reads
+// slot g ^ ((fr >> 2) & 3) of row fr — touches 16 distinct 16-byte slots per 16-lane group.  Persistent over 64-row tiles.
+// Statistics: per-wave partial sums in a fixed order, exchanged through LDS — two-pass like the LayerNorm kernel, another
+// summation order: scores equal the launched path's to fp32 round-off (as LNC), not bit for bit.
+// =========================================================================================
+namespace row64 {
+constexpr int BM = 64, KS = 64;   // rows per tile; bytes of K per row per K-step
+template <int FW, int NST> constexpr int xg() { return NST == 3 ? 2 : FW <= 6 ? 4 : 2; }    // K-steps per X group
+template <int FW, int NST> constexpr int xbuf() { return BM * KS * xg<FW, NST>(); }         // bytes of one X group
+template <int FW> constexpr int wstage() { return FW * 1024; }                             // bytes of one wave's W stage
+// NST = 3 (W two K-steps ahead; N = 768 only): 16 + 144 KiB = all of the CU's LDS, the statistics scratch then aliases X group 0
+template <int FW, int NST> constexpr int lds_bytes() { return 2 * xbuf<FW, NST>() + 8 * NST * wstage<FW>() + (NST == 3 ? 0 : 2 * 8 * BM * 4); }
+}  // namespace row64
+
+template <int PREC, int FW, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_row64_ln_kernel(const GemmArgs a) {
+  using namespace row64;
+  static_assert(PREC != MCM_PREC_F32, "16-bit operand modes");
+  static_assert(NST == 2 || NST == 3, "W stages per wave");
+  enter_precision_mode<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XG = xg<FW, NST>(), XBUF = xbuf<FW, NST>(), WST = wstage<FW>(), NW = FW * 16, N = 8 * NW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int nk = a.K * 2 / KS;           // K-steps (a.K 16-bit elements per row)
+  const int ntiles = a.M / BM;
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t wlds = lds0 + 2 * XBUF + wave * NST * WST;
+  float* scratch = (float*)(NST == 3 ? smem : smem + 2 * XBUF + 8 * NST * WST);   // [2][8 waves][64 rows]; NST = 3: over X group 0
+  // DMA source of this lane inside a piece: row r = lane >> 2, slot lane & 3 holds chunk (lane & 3) ^ ((r >> 2) & 3)
+  const int pr = lane >> 2, pc = (lane & 3) ^ ((pr >> 2) & 3);
+  const size_t sx = (size_t)a.ldx * 2, sw = (size_t)a.K * 2;
+  const char* wsrc = (const char*)a.w + (size_t)(wave * NW + pr) * sw + pc * 16;
+  const int foff = fr * 64 + ((g ^ ((fr >> 2) & 3)) << 4);
+  float amax = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * BM;
+    const char* xsrc = (const char*)a.x + (size_t)(m0 + pr) * sx + pc * 16;
+    auto issue_w = [&](int kt) {
+      const uint32_t base = wlds + (kt % NST) * WST;
+#pragma unroll
+      for (int f = 0; f < FW; ++f) glds16(wsrc + (size_t)(f * 16) * sw + (size_t)kt * KS, base + f * 1024);
+    };
+    auto issue_x = [&](int gi) {   // waves 0 - 3: row block `wave` of the XG K-steps of group gi
+      const uint32_t base = lds0 + (gi & 1) * XBUF;
+#pragma unroll
+      for (int j = 0; j < XG; ++j)
+        glds16(xsrc + (size_t)(wave * 16) * sx + (size_t)(gi * XG + j) * KS, base + (j * 4 + wave) * 1024);
+    };
+    f32x4_t acc[4][FW];
+#pragma unroll
+    for (int fx = 0; fx < 4; ++fx)
+#pragma unroll
+      for (int fw = 0; fw < FW; ++fw) acc[fx][fw] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (wave < 4) issue_x(0);
+    issue_w(0);
+    if constexpr (NST == 3) issue_w(1);   // (nk >= 2 always: K >= 64)
+    for (int kt = 0; kt < nk; ++kt) {
+      const int j = kt % XG, gi = kt / XG;
+      // W stays NST - 1 K-steps ahead; the wait lets exactly the pieces of the steps after kt stay in flight (X pieces are issued
+      // at group starts, XG steps before their first reader: always among the completed)
+      if (kt + NST - 1 < nk) {
+        issue_w(kt + NST - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * FW) : "memory");
+      } else if (NST == 3 && kt + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (j == 0) {
+        __builtin_amdgcn_s_barrier();   // X group gi is in LDS for everyone; everyone is done with group gi - 1
+        asm volatile("" ::: "memory");
+        if ((gi + 1) * XG < nk && wave < 4) issue_x(gi + 1);
+      }
+      const char* xb = smem + (gi & 1) * XBUF + j * 4096 + foff;
+      const char* wb = smem + 2 * XBUF + wave * NST * WST + (kt % NST) * WST + foff;
+      uint4 xf[4], wf[FW];
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) xf[fx] = *(const uint4*)(xb + fx * 1024);
+#pragma unroll
+      for (int fw = 0; fw < FW; ++fw) wf[fw] = *(const uint4*)(wb + fw * 1024);
+#pragma unroll
+      for (int fw = 0; fw < FW; ++fw)
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) acc[fx][fw] = mfma16<PREC>(wf[fw], xf[fx], acc[fx][fw]);
+    }
+    // ---- epilogue: lane (fr, g) holds rows m0 + fx*16 + fr, columns wave*NW + fw*16 + g*4 .. +3
+    if constexpr (NST == 3) __syncthreads();   // (the scratch lies over X group 0: every wave has read its last fragments)
+    const int n0 = wave * NW + g * 4;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int fw = 0; fw < FW; ++fw) {
+        const f32x4_t bia = *(const f32x4_t*)(a.bias + n0 + fw * 16);
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+          float* xr = a.resid + (size_t)(m0 + fx * 16 + fr) * a.ldo + n0 + fw * 16;
+          const f32x4_t v = (acc[fx][fw] + bia) + *(const f32x4_t*)xr;
+          *(f32x4_t*)xr = v;
+          acc[fx][fw] = v;
+          rs[fx] += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      }
+    }
+    auto exchange = [&](float (&part)[4], int buf) {   // wave partials -> row totals (fixed order over the waves)
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        part[fx] += __shfl_xor(part[fx], 16, 64);
+        part[fx] += __shfl_xor(part[fx], 32, 64);
+      }
+      float* sc = scratch + buf * 8 * BM;
+      if (g == 0) {
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) sc[wave * BM + fx * 16 + fr] = part[fx];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += sc[w * BM + fx * 16 + fr];
+        part[fx] = t;
+      }
+    };
+    exchange(rs, 0);
+    float mean[4], q[4];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        mean[fx] = rs[fx] / (float)N;
+        q[fx] = 0.f;
+#pragma unroll
+        for (int fw = 0; fw < FW; ++fw) {
+          const f32x4_t d = acc[fx][fw] - mean[fx];
+          acc[fx][fw] = d;
+          q[fx] += __builtin_fmaf(d[0], d[0], d[1] * d[1]) + __builtin_fmaf(d[2], d[2], d[3] * d[3]);
+        }
+      }
+    }
+    exchange(q, 1);
+    {
+#pragma clang fp contract(off)
+      float rstd[4];
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) rstd[fx] = 1.0f / sqrtf(q[fx] / (float)N + a.ln_eps);
+#pragma unroll
+      for (int fw = 0; fw < FW; ++fw) {
+        const f32x4_t gam = *(const f32x4_t*)(a.ln_g + n0 + fw * 16), bet = *(const f32x4_t*)(a.ln_b + n0 + fw * 16);
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+          f32x4_t y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf(acc[fx][fw][e] * rstd[fx], gam[e], bet[e]);
+          sat_track<PREC>(amax, y[0], y[1]);
+          sat_track<PREC>(amax, y[2], y[3]);
+          uint2 pk;
+          pk.x = pack2<PREC>(y[0], y[1]);
+          pk.y = pack2<PREC>(y[2], y[3]);
+          *(uint2*)((uint16_t*)a.ln_y + (size_t)(m0 + fx * 16 + fr) * N + n0 + fw * 16) = pk;
+        }
+      }
+    }
+    __syncthreads();   // the scratch and the X buffers are free for the next tile
+  }
+  sat_report<PREC>(amax, a.sat);
+}
+template <int PREC, int FW, int NST>
+hipError_t launch_row64_ln_f(const GemmArgs& a, hipStream_t s) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_row64_ln_kernel<PREC, FW, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       row64::lds_bytes<FW, NST>());
+    if (e != hipSuccess) return e;
+    attr_set.set();
+  }
+  const int ntiles = a.M / row64::BM, grid = ntiles < persistent_grid() ? ntiles : persistent_grid();
+  constexpr int lds = row64::lds_bytes<FW, NST>();
+  hipLaunchKernelGGL((gemm_row64_ln_kernel<PREC, FW, NST>), dim3(grid), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+// stages: 2 or 3 W stages per wave (3: N = 768 only — 160 KiB of LDS; other widths run 2)
+template <int PREC>
+hipError_t launch_row64_ln_p(const GemmArgs& a, hipStream_t s, int stages) {
+  if (a.M <= 0 || a.M % row64::BM || a.K % 128 || a.ldo != a.N || a.xsplit || a.ksplit || !a.bias || !a.resid || !a.ln_g || !a.ln_b ||
+      !a.ln_y)
+    return hipErrorInvalidValue;
+  if (a.N == 768) return stages == 3 ? launch_row64_ln_f<PREC, 6, 3>(a, s) : launch_row64_ln_f<PREC, 6, 2>(a, s);
+  if (a.N == 1024) return launch_row64_ln_f<PREC, 8, 2>(a, s);
+  return hipErrorInvalidValue;
 }
 
 // Routing of a launch to an arm.  Returns true when the launch is the arms' business (`*err` then holds its status),

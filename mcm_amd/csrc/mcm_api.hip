@@ -328,6 +328,7 @@ hipError_t lnorm_strided(mcm_handle* h, hipStream_t s, int prec, const float* x,
 #ifdef MCM_HARNESS
 int g_ln_tail = 0;  // mcm_debug_ln_tail
 int g_ln_cluster = 0;  // mcm_debug_ln_cluster: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp "LNC", round 6)
+int g_ln_row = 0;      // mcm_debug_ln_row: out-proj / fc2 + the LayerNorm behind them as 64-row FULL-ROW tiles (gemm_arms.hpp ROW64, R6.7)
 int g_lnc_spin = -1;   // mcm_debug_ln_cluster_spin: < 0 the first form (wait for the partners); n >= 0 the defer form: n polls, then
                        // the segment is left to launch_lnc_cleanup behind the GEMM
 #elif defined(MCM_LN_TAIL)  // A/B build of the shipped library with the tail on
@@ -336,7 +337,7 @@ constexpr int g_ln_tail = 1;
 constexpr int g_ln_tail = 0;
 #endif
 #ifndef MCM_HARNESS
-constexpr int g_ln_cluster = 0, g_lnc_spin = -1;
+constexpr int g_ln_cluster = 0, g_lnc_spin = -1, g_ln_row = 0;
 #endif
 // The tail's coherence argument needs every workgroup with the same blockIdx & 7 on the same XCD (one L2).  That is
 // how the dispatcher deals workgroups in the default (SPX) mode; it is checked on the device, once per handle, with
@@ -433,7 +434,21 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     return hipSuccess;
 #endif
   };
-  const bool tail_ok = tail_ok0 || cluster_ok;   // either arm: the residual GEMM also produces the LayerNorm behind it
+  // ROW64 arm (harness): the residual GEMM as 64-row full-row tiles whose epilogue writes x and the LayerNorm output
+  const bool row_ok = g_ln_row && !g_ln_tail && !g_ln_cluster && !x2 && !can_fold && !t.split && P != MCM_PREC_F32 && Mp % 64 == 0 &&
+                      (D == 768 || D == 1024) && t.ff % 128 == 0;
+  auto row_gemm = [&](GemmArgs g, const float* gamma, const float* beta) -> hipError_t {
+#ifdef MCM_HARNESS
+    g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
+    g.M = Mp; g.sat = h->sat_on ? h->sat_dev : nullptr;
+    Scope sc(h, s, MCM_KC_GEMM, 2.0 * g.M * (double)g.N * g.K, g.N == g.K ? MCM_KC_GEMM_OUTPROJ : MCM_KC_GEMM_FC2);
+    return launch_gemm_row64_ln(P, g, s, g_ln_row == 2 ? 3 : 2);
+#else
+    (void)g; (void)gamma; (void)beta;
+    return hipErrorInvalidValue;
+#endif
+  };
+  const bool tail_ok = tail_ok0 || cluster_ok || row_ok;   // any of the arms: the residual GEMM also produces the LayerNorm behind it
   bool ln1_by_tail = false;  // h->ln already holds this layer's layer_norm1 (written by the previous layer's fc2)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& w = t.L[l];
@@ -477,6 +492,8 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     o.M = Mr; o.N = D; o.K = D; o.ldx = rs; o.ldo = rs; o.ksplit = ks; o.xsplit = xs;
     if (fold2) {
       HIP_TRY(h, produce(o, w.ln2w));
+    } else if (row_ok && !cls) {
+      HIP_TRY(h, row_gemm(o, w.ln2w, w.ln2b));
     } else if (tail_ok && !cls) {
       with_tail(o, w.ln2w, w.ln2b);  // layer_norm2 by the out-proj kernel's idle waves
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
@@ -499,12 +516,17 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     if (ln1_folded) {
       HIP_TRY(h, produce(f2, t.L[l + 1].ln1w));
     } else {
-      if (tail_ok && !cls && l + 1 < t.layers) {  // the next layer's layer_norm1 (all rows, also in front of a row-0-only layer)
-        with_tail(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b);
+      if (row_ok && !cls && l + 1 < t.layers) {
         ln1_by_tail = true;
+        HIP_TRY(h, row_gemm(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b));
+      } else {
+        if (tail_ok && !cls && l + 1 < t.layers) {  // the next layer's layer_norm1 (all rows, also in front of a row-0-only layer)
+          with_tail(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b);
+          ln1_by_tail = true;
+        }
+        HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
+        if (ln1_by_tail) HIP_TRY(h, lnc_cleanup(t.L[l + 1].ln1w, t.L[l + 1].ln1b));
       }
-      HIP_TRY(h, gemm(h, s, P, EPI_RESID, f2));
-      if (ln1_by_tail) HIP_TRY(h, lnc_cleanup(t.L[l + 1].ln1w, t.L[l + 1].ln1b));
     }
   }
   return MCM_OK;
@@ -1406,6 +1428,10 @@ int mcm_debug_ln_tail(int32_t on) {  // 1: LayerNorm in the tail of the residual
 }
 int mcm_debug_ln_cluster(int32_t on) {  // 1: LayerNorm by the row panel's cluster of workgroups (gemm_arms.hpp LNC); 0 (shipped behaviour): LayerNorm launches
   g_ln_cluster = on ? 1 : 0;
+  return MCM_OK;
+}
+int mcm_debug_ln_row(int32_t on) {  // 1: out-proj / fc2 + LayerNorm as 64-row full-row tiles (gemm_arms.hpp ROW64); 0 (shipped behaviour): launches
+  g_ln_row = on == 2 ? 2 : on ? 1 : 0;   // 2: three W stages per wave (N = 768)
   return MCM_OK;
 }
 int mcm_debug_ln_cluster_spin(int32_t polls) {  // < 0: the first LNC form (waits); n >= 0: the defer form with n polls (and the clean-up launch)

@@ -101,6 +101,7 @@ def load_library(harness: bool = False):
         L.mcm_debug_ln_tail.argtypes = [i32]
         L.mcm_debug_ln_cluster.argtypes = [i32]
         L.mcm_debug_ln_cluster_spin.argtypes = [i32]
+        L.mcm_debug_ln_row.argtypes = [i32]
         L.mcm_debug_ln_cluster_deferred.argtypes = [vp, vp]
         L.mcm_debug_ln_tail_timeouts.argtypes = [vp, vp]
         L.mcm_debug_gemm_dbg.argtypes = [i32]
@@ -164,7 +165,7 @@ HARNESS_ONLY_SYMBOLS = ["mcm_debug_gemm_variant", "mcm_debug_attention_variant",
                         "mcm_debug_gemm_group_n", "mcm_debug_patch_fold", "mcm_debug_resize_fused_only",
                         "mcm_debug_persistent_grid", "mcm_debug_op_attention", "mcm_debug_attn_spin_budget",
                         "mcm_debug_clear_faults", "mcm_debug_ln_cluster", "mcm_debug_ln_cluster_spin",
-                        "mcm_debug_ln_cluster_deferred"]
+                        "mcm_debug_ln_cluster_deferred", "mcm_debug_ln_row"]
 
 
 def _stream_ptr():
