@@ -478,7 +478,8 @@ int mcm_debug_ln_cluster(int32_t on);
 int mcm_debug_ln_cluster_spin(int32_t polls);
 /* A/B (round 6, R6.7): 1 = out-proj / fc2 of a whole-batch 16-bit vision layer run as 64-row FULL-ROW tiles (one workgroup holds
  * 64 x 768 / 1024 outputs) whose epilogue writes x once and the LayerNorm output from the accumulator registers — the literal
- * design of VERDICT r5 item 2, no cross-workgroup traffic (gemm_arms.hpp ROW64).  Round-off-equal to the shipped path. */
+ * design of VERDICT r5 item 2, no cross-workgroup traffic (gemm_arms.hpp ROW64).  Round-off-equal to the shipped path.
+ * 2 = three W stages per wave (N = 768); 3 / 4 = as 1 / 2 on a piece-contiguous copy of the weight, built on first use. */
 int mcm_debug_ln_row(int32_t on);
 int mcm_debug_ln_cluster_deferred(mcm_handle* h, uint64_t* count_host);
 /* Tickets of the LayerNorm tail that gave up waiting for their rows (a bounded spin: wrong rows rather than a hung

@@ -287,6 +287,8 @@ struct GemmArgs {
   // LNC, defer form (R6.4): polls of the partners' counter a wave spends before it leaves its segment's LayerNorm to
   // launch_lnc_cleanup (which the caller must then launch behind the GEMM); < 0 = the first form: wait (bounded, counted)
   int lnc_spin;
+  // ROW64 arm: 1 = `w` is the blocked image launch_row64_block_w writes ([K-step of 32][16-row block][1 KiB piece])
+  int wblk;
 };
 // head-major rows of a 16-bit output as the kernels see them: the shipped library never sets GemmArgs::hm (an A/B arm of
 // the harness library), so outside -DMCM_HARNESS builds the layout tests fold away at compile time
@@ -326,6 +328,7 @@ hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const fl
 // ROW64 arm (gemm_arms.hpp, R6.7): out-proj / fc2 as 64-row FULL-ROW tiles whose epilogue writes x and the LayerNorm output
 // (GemmArgs: x, w, bias, resid, M % 64 == 0, N in {768, 1024} = ldo, K, ldx, ln_g, ln_b, ln_y, ln_eps, sat)
 hipError_t launch_gemm_row64_ln(int prec, const GemmArgs& a, hipStream_t s, int stages);   // stages: W stages per wave, 2 or 3
+hipError_t launch_row64_block_w(const void* w, void* blocked, int N, int K, hipStream_t s);   // 16-bit [N, K] -> the ROW64 piece image
 void gemm_set_group_n(int gn);
 void gemm_set_dbg(int d);
 void gemm_set_variant(int v);  // -1 auto (the shipped policy), 0 ... 8: see gemm.hip

@@ -1433,6 +1433,12 @@ hipError_t launch_lnc_cleanup(int prec, const float* x, const float* g, const fl
   if (prec == MCM_PREC_BF16) return arms::launch_lnc_cleanup_p<MCM_PREC_BF16>(x, g, b, y, part, M, D, eps, ln_state, ln_rs, ln_cap8, s, sat);
   return hipErrorInvalidValue;
 }
+hipError_t launch_row64_block_w(const void* w, void* blocked, int N, int K, hipStream_t s) {
+  if (N % 16 || K % 32) return hipErrorInvalidValue;
+  const size_t nchunks = (size_t)N * K / 8;
+  hipLaunchKernelGGL(arms::row64_block_w_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, (const uint4*)w, (uint4*)blocked, N, K);
+  return hipGetLastError();
+}
 hipError_t launch_gemm_row64_ln(int prec, const GemmArgs& a, hipStream_t s, int stages) {
   if (prec == MCM_PREC_F16) return arms::launch_row64_ln_p<MCM_PREC_F16>(a, s, stages);
   if (prec == MCM_PREC_BF16) return arms::launch_row64_ln_p<MCM_PREC_BF16>(a, s, stages);

@@ -1334,7 +1334,12 @@ __global__ __launch_bounds__(512, 2) void gemm_row64_ln_kernel(const GemmArgs a)
   // DMA source of this lane inside a piece: row r = lane >> 2, slot lane & 3 holds chunk (lane & 3) ^ ((r >> 2) & 3)
   const int pr = lane >> 2, pc = (lane & 3) ^ ((pr >> 2) & 3);
   const size_t sx = (size_t)a.ldx * 2, sw = (size_t)a.K * 2;
-  const char* wsrc = (const char*)a.w + (size_t)(wave * NW + pr) * sw + pc * 16;
+  // W pieces: rows of the [N, K] operand (16 half cache lines per piece), or — a.wblk — the blocked image, where piece
+  // (K-step kt, 16-row block b) is the 1 KiB at ((kt * N / 16) + b) * 1024, already in LDS order: eight whole cache lines
+  const char* wsrc = a.wblk ? (const char*)a.w + (size_t)(wave * FW) * 1024 + lane * 16
+                            : (const char*)a.w + (size_t)(wave * NW + pr) * sw + pc * 16;
+  const size_t wpf = a.wblk ? (size_t)1024 : (size_t)16 * sw;            // bytes from a wave's fragment f to f + 1
+  const size_t wpk = a.wblk ? (size_t)(N / 16) * 1024 : (size_t)KS;      // ... from K-step kt to kt + 1
   const int foff = fr * 64 + ((g ^ ((fr >> 2) & 3)) << 4);
   float amax = 0.f;
 
@@ -1344,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void gemm_row64_ln_kernel(const GemmArgs a)
     auto issue_w = [&](int kt) {
       const uint32_t base = wlds + (kt % NST) * WST;
 #pragma unroll
-      for (int f = 0; f < FW; ++f) glds16(wsrc + (size_t)(f * 16) * sw + (size_t)kt * KS, base + f * 1024);
+      for (int f = 0; f < FW; ++f) glds16(wsrc + f * wpf + kt * wpk, base + f * 1024);
     };
     auto issue_x = [&](int gi) {   // waves 0 - 3: row block `wave` of the XG K-steps of group gi
       const uint32_t base = lds0 + (gi & 1) * XBUF;
@@ -1471,6 +1476,17 @@ __global__ __launch_bounds__(512, 2) void gemm_row64_ln_kernel(const GemmArgs a)
     __syncthreads();   // the scratch and the X buffers are free for the next tile
   }
   sat_report<PREC>(amax, a.sat);
+}
+// [N, K] 16-bit operand -> the blocked piece image (one thread per 16-byte chunk)
+__global__ void row64_block_w_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int N, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // destination chunk index
+  const size_t nchunks = (size_t)N * K / 8;
+  if (i >= nchunks) return;
+  const int lane = (int)(i & 63);
+  const size_t piece = i >> 6;
+  const int nb = N / 16, b = (int)(piece % nb), kt = (int)(piece / nb);
+  const int r = lane >> 2, c = (lane & 3) ^ ((r >> 2) & 3);
+  out[i] = w[((size_t)(b * 16 + r) * K + (size_t)kt * 32) / 8 + c];
 }
 template <int PREC, int FW, int NST>
 hipError_t launch_row64_ln_f(const GemmArgs& a, hipStream_t s) {

@@ -38,6 +38,9 @@ struct LayerW {
   const float *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;               // fp32 masters
   // LayerNorm fold (vision tower, 16-bit modes): c = W gamma and b' = b + W beta of the two GEMMs that follow a LayerNorm
   float *cqkv = nullptr, *bqkvf = nullptr, *c1 = nullptr, *b1f = nullptr;
+  // ROW64 arm, blocked W (harness; built on first use): wo / w2 as [K-step of 32][16-row block][1 KiB piece, chunks XOR-ed] — the
+  // LDS image of a piece, contiguous in memory, so that every LDS-DMA piece is eight whole cache lines (gemm_arms.hpp ROW64)
+  void *wo_blk = nullptr, *w2_blk = nullptr;
 };
 
 struct Tower {
@@ -437,14 +440,23 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
   // ROW64 arm (harness): the residual GEMM as 64-row full-row tiles whose epilogue writes x and the LayerNorm output
   const bool row_ok = g_ln_row && !g_ln_tail && !g_ln_cluster && !x2 && !can_fold && !t.split && P != MCM_PREC_F32 && Mp % 64 == 0 &&
                       (D == 768 || D == 1024) && t.ff % 128 == 0;
-  auto row_gemm = [&](GemmArgs g, const float* gamma, const float* beta) -> hipError_t {
+  auto row_gemm = [&](GemmArgs g, const float* gamma, const float* beta, void** blk) -> hipError_t {
 #ifdef MCM_HARNESS
     g.ln_g = gamma; g.ln_b = beta; g.ln_y = h->ln; g.ln_eps = h->cfg.ln_eps;
     g.M = Mp; g.sat = h->sat_on ? h->sat_dev : nullptr;
+    if (g_ln_row >= 3) {   // blocked W: built once per weight (not inside a graph capture: the first call allocates)
+      if (!*blk) {
+        if (dev_alloc(h, blk, (size_t)g.N * g.K * 2)) return hipErrorOutOfMemory;
+        hipError_t e = launch_row64_block_w(g.w, *blk, g.N, g.K, s);
+        if (e != hipSuccess) return e;
+      }
+      g.w = *blk;
+      g.wblk = 1;
+    }
     Scope sc(h, s, MCM_KC_GEMM, 2.0 * g.M * (double)g.N * g.K, g.N == g.K ? MCM_KC_GEMM_OUTPROJ : MCM_KC_GEMM_FC2);
-    return launch_gemm_row64_ln(P, g, s, g_ln_row == 2 ? 3 : 2);
+    return launch_gemm_row64_ln(P, g, s, (g_ln_row == 2 || g_ln_row == 4) ? 3 : 2);
 #else
-    (void)g; (void)gamma; (void)beta;
+    (void)g; (void)gamma; (void)beta; (void)blk;
     return hipErrorInvalidValue;
 #endif
   };
@@ -493,7 +505,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     if (fold2) {
       HIP_TRY(h, produce(o, w.ln2w));
     } else if (row_ok && !cls) {
-      HIP_TRY(h, row_gemm(o, w.ln2w, w.ln2b));
+      HIP_TRY(h, row_gemm(o, w.ln2w, w.ln2b, const_cast<void**>(&t.L[l].wo_blk)));
     } else if (tail_ok && !cls) {
       with_tail(o, w.ln2w, w.ln2b);  // layer_norm2 by the out-proj kernel's idle waves
       HIP_TRY(h, gemm(h, s, P, EPI_RESID, o));
@@ -518,7 +530,7 @@ int run_layers(mcm_handle* h, hipStream_t s, const Tower& t, int nseq, int L, bo
     } else {
       if (row_ok && !cls && l + 1 < t.layers) {
         ln1_by_tail = true;
-        HIP_TRY(h, row_gemm(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b));
+        HIP_TRY(h, row_gemm(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b, const_cast<void**>(&t.L[l].w2_blk)));
       } else {
         if (tail_ok && !cls && l + 1 < t.layers) {  // the next layer's layer_norm1 (all rows, also in front of a row-0-only layer)
           with_tail(f2, t.L[l + 1].ln1w, t.L[l + 1].ln1b);
@@ -1431,7 +1443,7 @@ int mcm_debug_ln_cluster(int32_t on) {  // 1: LayerNorm by the row panel's clust
   return MCM_OK;
 }
 int mcm_debug_ln_row(int32_t on) {  // 1: out-proj / fc2 + LayerNorm as 64-row full-row tiles (gemm_arms.hpp ROW64); 0 (shipped behaviour): launches
-  g_ln_row = on == 2 ? 2 : on ? 1 : 0;   // 2: three W stages per wave (N = 768)
+  g_ln_row = (on >= 1 && on <= 4) ? on : 0;   // 2 / 4: three W stages per wave (N = 768); 3 / 4: W in the blocked layout
   return MCM_OK;
 }
 int mcm_debug_ln_cluster_spin(int32_t polls) {  // < 0: the first LNC form (waits); n >= 0: the defer form with n polls (and the clean-up launch)

@@ -25,11 +25,12 @@ def _affine_state(geo):
     return sd
 
 
-@pytest.mark.parametrize("stages", [1, 2], ids=["2-stage", "3-stage"])   # mcm_debug_ln_row(1 / 2): W one / two K-steps ahead
+# mcm_debug_ln_row(1 / 2): W one / two K-steps ahead; 3 / 4: the same with W in the blocked (piece-contiguous) layout
+@pytest.mark.parametrize("stages", [1, 2, 3, 4], ids=["2-stage", "3-stage", "2-stage-blockedW", "3-stage-blockedW"])
 @pytest.mark.parametrize("ckpt,precision,batch", [("ViT-B/16", "fp16", 160), ("ViT-B/16", "bf16", 512),
                                                    ("ViT-L/14", "fp16", 64), ("ViT-B/32", "fp16", 512), ("ViT-B/16", "fp16", 3)])
 def test_full_row_tiles_equal_the_launched_layernorms_to_round_off(ckpt, precision, batch, stages):
-    if stages == 2 and ckpt == "ViT-L/14":
+    if stages in (2, 4) and ckpt == "ViT-L/14":
         pytest.skip("three W stages need N = 768 (160 KiB of LDS); N = 1024 runs two")
     geo = geometry(ckpt)
     sd = _affine_state(geo)
