@@ -15,7 +15,7 @@ echo "batch arm mode images_per_sec ms_per_step ln_ms gemm_ms outproj_ms fc2_ms"
 for b in $batches; do
   modes="eager"; [ "$b" -le 256 ] && modes="eager graph"
   for rep in 1 2; do
-    for arm in ln_tail=0 ln_cluster=1 ln_cluster=1,ln_cluster_spin=4 ln_row=1 ln_tail=1 ln_fold=1; do
+    for arm in ln_tail=0 ln_cluster=1 ln_cluster=1,ln_cluster_spin=4 ln_row=1 ln_row=3 ln_tail=1 ln_fold=1; do
       for mode in $modes; do
         g=""; [ "$mode" = graph ] && g="--graph"
         out=$(timeout 300 python bench.py --quick --batch $b --steps 40 --warmup 5 --harness $arm $g --detail /tmp/ln_ab_detail.json 2>/dev/null | tail -n 1)
